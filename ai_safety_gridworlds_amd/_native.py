@@ -1,0 +1,102 @@
+"""ctypes binding of libsgw.so (include/sgw.h).  No CPU fallback: if the library is missing or a
+HIP call fails, the error is raised -- the product path never silently degrades."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsgw.so")
+
+MAX_CELLS, MAX_K, MAX_M, MAX_AGENTS, N_PARAMS, ENV_ALIGN = 320, 16, 16, 4, 48, 64
+ABI_VERSION = 1
+
+ISLAND_NAVIGATION_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INTERRUPTIBILITY, FIREMAKER_EX_MA = range(5)
+FIRST, MID, LAST, DEAD = 0, 1, 2, 3
+TERM_NONE = 255
+
+
+class SgwError(RuntimeError):
+  pass
+
+
+class Spec(C.Structure):
+  """Mirror of `struct sgw_spec` (include/sgw.h)."""
+  _fields_ = [
+      ("family", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("K", C.c_int32),
+      ("M", C.c_int32), ("A", C.c_int32), ("max_iterations", C.c_int32),
+      ("start_cell", C.c_int32 * MAX_AGENTS),
+      ("action_lo", C.c_int32), ("n_actions", C.c_int32), ("flags", C.c_int32),
+      ("reserved", C.c_int32 * 3),
+      ("dim_slot", (C.c_int8 * MAX_K) * MAX_AGENTS),
+      ("metric_slot", C.c_int8 * MAX_M),
+      ("params", C.c_double * N_PARAMS),
+      ("value_map", C.c_float * 128),
+      ("static_board", C.c_uint8 * MAX_CELLS),
+      ("art", C.c_uint8 * MAX_CELLS),
+      ("aux", C.c_uint8 * MAX_CELLS),
+  ]
+
+
+OUT_FIELDS = ("board", "obs_board", "reward", "cumulative", "step_type", "term_reason",
+              "actual_action", "discount", "hidden", "safety", "metrics", "frame")
+
+
+class Out(C.Structure):
+  """Mirror of `struct sgw_out`: device pointers (0 = skip that output)."""
+  _fields_ = [(n, C.c_void_p) for n in OUT_FIELDS]
+
+
+_lib = None
+
+
+def lib():
+  """Load libsgw.so (building it with hipcc if the sources are newer / it is absent)."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  from . import build as _build
+  try:
+    path = _build.build()
+  except Exception as ex:   # no hipcc: use a prebuilt .so if one travelled with the tree
+    if not os.path.exists(LIB_PATH):
+      raise SgwError("libsgw.so is missing and cannot be built (%s); the engine has no CPU fallback" % ex)
+    path = LIB_PATH
+  L = C.CDLL(path)
+  L.sgw_last_error.restype = C.c_char_p
+  L.sgw_create.argtypes = [C.POINTER(Spec), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+  L.sgw_destroy.argtypes = [C.c_void_p]
+  for f in ("sgw_n_envs", "sgw_n_pad", "sgw_state_bytes"):
+    getattr(L, f).restype = C.c_int64
+    getattr(L, f).argtypes = [C.c_void_p]
+  L.sgw_state_words.argtypes = [C.c_void_p]
+  L.sgw_set_episode_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
+  L.sgw_set_rng_state.argtypes = [C.c_void_p, C.c_void_p]
+  L.sgw_reset.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Out), C.c_void_p]
+  L.sgw_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Out), C.c_void_p]
+  L.sgw_rollout.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_int, C.POINTER(Out),
+                            C.c_void_p, C.c_void_p]
+  L.sgw_fill_actions.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]
+  L.sgw_accumulate_returns.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+  L.sgw_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                            C.c_void_p, C.c_void_p]
+  L.sgw_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+  L.sgw_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+  if L.sgw_abi_version() != ABI_VERSION:
+    raise SgwError("libsgw.so ABI %d != binding ABI %d" % (L.sgw_abi_version(), ABI_VERSION))
+  if L.sgw_sizeof_spec() != C.sizeof(Spec) or L.sgw_sizeof_out() != C.sizeof(Out):
+    raise SgwError("struct layout mismatch between libsgw.so and the ctypes mirror "
+                   "(spec %d vs %d, out %d vs %d)" % (L.sgw_sizeof_spec(), C.sizeof(Spec),
+                                                      L.sgw_sizeof_out(), C.sizeof(Out)))
+  _lib = L
+  return L
+
+
+EXPORTS = [
+    "sgw_abi_version", "sgw_last_error", "sgw_sizeof_spec", "sgw_sizeof_out", "sgw_create",
+    "sgw_destroy", "sgw_n_envs", "sgw_n_pad", "sgw_state_bytes", "sgw_set_episode_bits",
+    "sgw_set_rng_state", "sgw_reset", "sgw_step", "sgw_rollout", "sgw_fill_actions",
+    "sgw_accumulate_returns", "sgw_observe", "sgw_state_words", "sgw_get_state", "sgw_set_state"]
+
+
+def check(rc, what=""):
+  if rc != 0:
+    raise SgwError("%s failed (%d): %s" % (what or "libsgw call", rc, lib().sgw_last_error().decode()))

@@ -1,0 +1,276 @@
+// sgw_api.hip -- host side of libsgw.so: the C ABI declared in include/sgw.h.
+// Thin by design: validates arguments, owns the engine's device state, launches k_engine<F>.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/sgw.h"
+#include "sgw_boat.hpp"
+#include "sgw_island.hpp"
+#include "sgw_kernels.hpp"
+#include "sgw_safeint.hpp"
+
+using namespace sgw;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, const char* detail = "") {
+  snprintf(g_err, sizeof(g_err), fmt, detail);
+  return code;
+}
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      snprintf(g_err, sizeof(g_err), "%s failed: %s", #expr, hipGetErrorString(e_));     \
+      return SGW_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+
+struct sgw_engine {
+  sgw_spec spec;
+  KSpec ks;
+  int device;
+  long long n_envs, n_pad, env_id_base;
+  uint8_t* tables_dev;     // static_board | art | aux | value_map
+  uint64_t* state_dev;     // [words][n_pad]
+  const uint8_t* ep_bits;
+  int ep_bits_n;
+  unsigned long long ep_seed;
+  size_t lds_bytes;
+};
+
+static int family_words(const sgw_spec& sp) {
+  switch (sp.family) {
+    case SGW_ISLAND_NAVIGATION_EX: return Island::words(sp.K);
+    case SGW_BOAT_RACE_EX:
+    case SGW_BOAT_RACE: return Boat::words(sp.K, sp.H * sp.W);
+    case SGW_SAFE_INTERRUPTIBILITY: return SafeInt::words();
+    default: return -1;
+  }
+}
+
+extern "C" {
+
+int sgw_abi_version(void) { return SGW_ABI_VERSION; }
+const char* sgw_last_error(void) { return g_err; }
+int sgw_sizeof_spec(void) { return (int)sizeof(sgw_spec); }
+int sgw_sizeof_out(void) { return (int)sizeof(sgw_out); }
+
+int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int device, sgw_engine** out_engine) {
+  if (!spec || !out_engine) return fail(SGW_ERR_ARG, "sgw_create: null argument");
+  *out_engine = nullptr;
+  if (n_envs <= 0) return fail(SGW_ERR_ARG, "sgw_create: n_envs must be positive");
+  const int HW = spec->H * spec->W;
+  if (spec->H <= 0 || spec->W <= 0 || HW > SGW_MAX_CELLS || spec->H > 255 || spec->W > 255)
+    return fail(SGW_ERR_ARG, "sgw_create: board size out of range");
+  if (spec->K < 1 || spec->K > SGW_MAX_K || spec->M < 0 || spec->M > SGW_MAX_M || spec->A < 1 ||
+      spec->A > SGW_MAX_AGENTS)
+    return fail(SGW_ERR_ARG, "sgw_create: K/M/A out of range");
+  if (spec->max_iterations < 1 || spec->max_iterations > 65535)
+    return fail(SGW_ERR_ARG, "sgw_create: max_iterations must be in [1, 65535]");
+  for (int ag = 0; ag < spec->A; ++ag)
+    if (spec->start_cell[ag] < 0 || spec->start_cell[ag] >= HW)
+      return fail(SGW_ERR_ARG, "sgw_create: start_cell outside the board");
+  for (int ag = 0; ag < SGW_MAX_AGENTS; ++ag)
+    for (int u = 0; u < SGW_MAX_K; ++u)
+      if (spec->dim_slot[ag][u] >= spec->K) return fail(SGW_ERR_ARG, "sgw_create: dim_slot >= K");
+  for (int m = 0; m < SGW_MAX_M; ++m)
+    if (spec->metric_slot[m] >= spec->M && spec->metric_slot[m] >= 0)
+      return fail(SGW_ERR_ARG, "sgw_create: metric_slot >= M");
+  const int words = family_words(*spec);
+  if (words < 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_create: unknown game family");
+
+  HIP_TRY(hipSetDevice(device));
+  sgw_engine* e = new (std::nothrow) sgw_engine();
+  if (!e) return fail(SGW_ERR_NOMEM, "sgw_create: out of host memory");
+  e->spec = *spec;
+  e->device = device;
+  e->n_envs = n_envs;
+  e->n_pad = (n_envs + SGW_ENV_ALIGN - 1) / SGW_ENV_ALIGN * SGW_ENV_ALIGN;
+  e->env_id_base = env_id_base;
+  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0;
+
+  KSpec& k = e->ks;
+  memset(&k, 0, sizeof(k));
+  k.family = spec->family; k.H = spec->H; k.W = spec->W; k.HW = HW; k.K = spec->K; k.M = spec->M;
+  k.A = spec->A; k.max_iterations = spec->max_iterations; k.flags = spec->flags;
+  k.action_lo = spec->action_lo; k.n_actions = spec->n_actions; k.words = words;
+  memcpy(k.start_cell, spec->start_cell, sizeof(k.start_cell));
+  memcpy(k.dim_slot, spec->dim_slot, sizeof(k.dim_slot));
+  memcpy(k.metric_slot, spec->metric_slot, sizeof(k.metric_slot));
+  memcpy(k.params, spec->params, sizeof(k.params));
+  e->lds_bytes = lds_total_bytes(HW, spec->A, spec->K, spec->M);
+
+  const size_t tbytes = 3 * SGW_MAX_CELLS + 512;
+  uint8_t host_tables[3 * SGW_MAX_CELLS + 512];
+  memset(host_tables, 0, sizeof(host_tables));
+  memcpy(host_tables, spec->static_board, HW);
+  memcpy(host_tables + SGW_MAX_CELLS, spec->art, HW);
+  memcpy(host_tables + 2 * SGW_MAX_CELLS, spec->aux, HW);
+  memcpy(host_tables + 3 * SGW_MAX_CELLS, spec->value_map, 512);
+
+  hipError_t err = hipMalloc((void**)&e->tables_dev, tbytes);
+  if (err == hipSuccess) err = hipMemcpy(e->tables_dev, host_tables, tbytes, hipMemcpyHostToDevice);
+  const size_t sbytes = (size_t)words * (size_t)e->n_pad * 8;
+  if (err == hipSuccess) err = hipMalloc((void**)&e->state_dev, sbytes);
+  // step_type ST_NONE (3) in every env's core word => the first sgw_step auto-resets
+  if (err == hipSuccess) err = hipMemset(e->state_dev, 0, sbytes);
+  if (err != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "sgw_create: device allocation failed: %s", hipGetErrorString(err));
+    if (e->tables_dev) (void)hipFree(e->tables_dev);
+    if (e->state_dev) (void)hipFree(e->state_dev);
+    delete e;
+    return SGW_ERR_HIP;
+  }
+  *out_engine = e;
+  // mark "never reset": run a masked reset with an all-zero effect is not needed; core word 0 has
+  // step_type bits = 0 (FIRST) after memset, so set them to ST_NONE explicitly.
+  {
+    uint64_t none = (uint64_t)ST_NONE << 32 | (uint64_t)TERM_NONE4 << 36;
+    uint64_t* host = (uint64_t*)malloc((size_t)e->n_pad * 8);
+    if (!host) { sgw_destroy(e); *out_engine = nullptr; return fail(SGW_ERR_NOMEM, "sgw_create: out of host memory"); }
+    for (long long i = 0; i < e->n_pad; ++i) host[i] = none;
+    err = hipMemcpy(e->state_dev, host, (size_t)e->n_pad * 8, hipMemcpyHostToDevice);
+    free(host);
+    if (err != hipSuccess) {
+      snprintf(g_err, sizeof(g_err), "sgw_create: state init failed: %s", hipGetErrorString(err));
+      sgw_destroy(e); *out_engine = nullptr;
+      return SGW_ERR_HIP;
+    }
+  }
+  return SGW_OK;
+}
+
+int sgw_destroy(sgw_engine* e) {
+  if (!e) return SGW_OK;
+  if (e->tables_dev) (void)hipFree(e->tables_dev);
+  if (e->state_dev) (void)hipFree(e->state_dev);
+  delete e;
+  return SGW_OK;
+}
+
+int64_t sgw_n_envs(const sgw_engine* e) { return e ? e->n_envs : 0; }
+int64_t sgw_n_pad(const sgw_engine* e) { return e ? e->n_pad : 0; }
+int sgw_state_words(const sgw_engine* e) { return e ? e->ks.words : 0; }
+int64_t sgw_state_bytes(const sgw_engine* e) { return e ? (int64_t)e->ks.words * e->n_pad * 8 : 0; }
+
+int sgw_set_episode_bits(sgw_engine* e, const uint8_t* bits_dev, int n_per_env, uint64_t seed) {
+  if (!e) return fail(SGW_ERR_ARG, "sgw_set_episode_bits: null engine");
+  if (bits_dev && n_per_env <= 0) return fail(SGW_ERR_ARG, "sgw_set_episode_bits: n_per_env must be positive");
+  e->ep_bits = bits_dev; e->ep_bits_n = bits_dev ? n_per_env : 0; e->ep_seed = seed;
+  return SGW_OK;
+}
+
+int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev) {
+  (void)pcg_state_dev;
+  if (!e) return fail(SGW_ERR_ARG, "sgw_set_rng_state: null engine");
+  return fail(SGW_ERR_UNSUPPORTED, "sgw_set_rng_state: this game family has no env-side RNG stream");
+}
+
+static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
+  HIP_TRY(hipSetDevice(e->device));
+  a.sp = e->ks; a.tables = e->tables_dev; a.state = e->state_dev;
+  a.n_pad = e->n_pad; a.n_envs = e->n_envs; a.env_id_base = e->env_id_base;
+  a.ep_bits = e->ep_bits; a.ep_bits_n = e->ep_bits_n; a.ep_seed = e->ep_seed;
+  const dim3 grid((unsigned)(e->n_pad / WAVE)), block(WAVE);
+  switch (e->spec.family) {
+    case SGW_ISLAND_NAVIGATION_EX:
+      hipLaunchKernelGGL(k_engine<Island>, grid, block, e->lds_bytes, st, a); break;
+    case SGW_BOAT_RACE_EX:
+    case SGW_BOAT_RACE:
+      hipLaunchKernelGGL(k_engine<Boat>, grid, block, e->lds_bytes, st, a); break;
+    case SGW_SAFE_INTERRUPTIBILITY:
+      hipLaunchKernelGGL(k_engine<SafeInt>, grid, block, e->lds_bytes, st, a); break;
+    default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
+  }
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
+int sgw_reset(sgw_engine* e, const uint8_t* mask_dev, const sgw_out* out, void* stream) {
+  if (!e) return fail(SGW_ERR_ARG, "sgw_reset: null engine");
+  KArgs a; memset(&a, 0, sizeof(a));
+  a.mode = MODE_RESET; a.mask = mask_dev; a.T = 1;
+  if (out) a.out = *out;
+  return launch(e, a, (hipStream_t)stream);
+}
+
+int sgw_step(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, void* stream) {
+  if (!e) return fail(SGW_ERR_ARG, "sgw_step: null engine");
+  if (!actions_dev) return fail(SGW_ERR_ARG, "sgw_step: null actions");
+  KArgs a; memset(&a, 0, sizeof(a));
+  a.mode = MODE_STEP; a.actions = actions_dev; a.T = 1;
+  if (out) a.out = *out;
+  return launch(e, a, (hipStream_t)stream);
+}
+
+int sgw_rollout(sgw_engine* e, int T, uint64_t seed, int64_t step0, int write_every, const sgw_out* out,
+                double* ep_accum_dev, void* stream) {
+  if (!e) return fail(SGW_ERR_ARG, "sgw_rollout: null engine");
+  if (T < 1) return fail(SGW_ERR_ARG, "sgw_rollout: T must be >= 1");
+  if (e->spec.n_actions < 1) return fail(SGW_ERR_ARG, "sgw_rollout: spec has no action range");
+  KArgs a; memset(&a, 0, sizeof(a));
+  a.mode = MODE_STEP; a.actions = nullptr; a.T = T; a.seed = seed; a.step0 = step0;
+  a.write_every = write_every; a.ep_accum = ep_accum_dev;
+  if (out) a.out = *out;
+  return launch(e, a, (hipStream_t)stream);
+}
+
+int sgw_fill_actions(sgw_engine* e, int T, uint64_t seed, int64_t step0, int8_t* actions_dev, void* stream) {
+  if (!e || !actions_dev || T < 1) return fail(SGW_ERR_ARG, "sgw_fill_actions: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  long long total = (long long)T * e->n_envs * e->spec.A;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_fill_actions, dim3(blocks), dim3(256), 0, (hipStream_t)stream, actions_dev, e->n_envs,
+                     e->spec.A, T, seed, step0, e->env_id_base, e->spec.action_lo, e->spec.n_actions);
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
+int sgw_accumulate_returns(sgw_engine* e, const double* cumulative_dev, const uint8_t* step_type_dev,
+                           double* ep_accum_dev, void* stream) {
+  if (!e || !cumulative_dev || !step_type_dev || !ep_accum_dev)
+    return fail(SGW_ERR_ARG, "sgw_accumulate_returns: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  int blocks = (int)((e->n_envs + 255) / 256);
+  hipLaunchKernelGGL(k_accumulate_returns, dim3(blocks), dim3(256), 0, (hipStream_t)stream, cumulative_dev,
+                     step_type_dev, e->n_envs, e->spec.A * e->spec.K, ep_accum_dev);
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
+int sgw_observe(sgw_engine* e, const uint8_t* board_dev, const uint8_t* rgb_lut_dev, uint8_t* rgb_dev,
+                const uint8_t* layer_chars_dev, int n_layers, uint8_t* layers_dev, void* stream) {
+  if (!e || !board_dev) return fail(SGW_ERR_ARG, "sgw_observe: null argument");
+  if (rgb_dev && !rgb_lut_dev) return fail(SGW_ERR_ARG, "sgw_observe: rgb requested without a LUT");
+  if (layers_dev && (!layer_chars_dev || n_layers < 1)) return fail(SGW_ERR_ARG, "sgw_observe: bad layer list");
+  HIP_TRY(hipSetDevice(e->device));
+  long long total = e->n_envs * e->ks.HW;
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(k_observe, dim3(blocks), dim3(256), 0, (hipStream_t)stream, board_dev, e->n_envs, e->ks.HW,
+                     rgb_lut_dev, rgb_dev, layer_chars_dev, n_layers, layers_dev);
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
+int sgw_get_state(sgw_engine* e, uint64_t* state_dev, void* stream) {
+  if (!e || !state_dev) return fail(SGW_ERR_ARG, "sgw_get_state: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(state_dev, e->state_dev, (size_t)sgw_state_bytes(e), hipMemcpyDeviceToDevice,
+                         (hipStream_t)stream));
+  return SGW_OK;
+}
+
+int sgw_set_state(sgw_engine* e, const uint64_t* state_dev, void* stream) {
+  if (!e || !state_dev) return fail(SGW_ERR_ARG, "sgw_set_state: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(e->state_dev, state_dev, (size_t)sgw_state_bytes(e), hipMemcpyDeviceToDevice,
+                         (hipStream_t)stream));
+  return SGW_OK;
+}
+
+}  // extern "C"

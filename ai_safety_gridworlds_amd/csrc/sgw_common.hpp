@@ -1,0 +1,177 @@
+// sgw_common.hpp -- device-side building blocks shared by every game family (gfx950 / wave64).
+//
+// Execution model: one lane per env, one 64-lane wavefront per workgroup (64 envs), grid =
+// N_pad / 64.  Everything a wave needs that is identical for all envs (level tables) is staged
+// in LDS once per workgroup; per-env state lives in HBM as struct-of-arrays 8-byte columns
+// (state[word][env]) so every state load/store is one fully coalesced 512-byte wave access.
+// Env-major outputs ([N, H*W] boards, [N, K] reward vectors) are transposed through LDS so the
+// wave writes its 64 rows as one contiguous run of 16-byte-per-lane stores.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sgw.h"
+
+namespace sgw {
+
+constexpr int WAVE = 64;
+
+// ---- kernel arguments (by value => kernarg segment => scalar loads) -------------------------
+struct KSpec {
+  int family, H, W, HW, K, M, A, max_iterations, flags, action_lo, n_actions, words;
+  int start_cell[SGW_MAX_AGENTS];
+  int8_t dim_slot[SGW_MAX_AGENTS][SGW_MAX_K];
+  int8_t metric_slot[SGW_MAX_M];
+  double params[SGW_N_PARAMS];
+};
+
+struct KArgs {
+  KSpec sp;
+  const uint8_t* tables;     // device copy: static_board | art | aux (3 x SGW_MAX_CELLS) | value_map f32[128]
+  uint64_t* state;           // [words][n_pad]
+  long long n_pad, n_envs, env_id_base;
+  const int8_t* actions;     // [n, A] or nullptr (synthetic)
+  const uint8_t* mask;       // reset mask or nullptr
+  const uint8_t* ep_bits;    // per-episode external bits [n, ep_bits_n] or nullptr
+  int ep_bits_n;
+  unsigned long long ep_seed;
+  sgw_out out;
+  int mode;                  // 0 = step, 1 = reset(mask)
+  int T;                     // rollout length (1 for step)
+  unsigned long long seed;
+  long long step0;
+  int write_every;
+  double* ep_accum;
+};
+
+enum { MODE_STEP = 0, MODE_RESET = 1 };
+enum { ST_FIRST = 0, ST_MID = 1, ST_LAST = 2, ST_NONE = 3 };   // ST_NONE: never reset yet
+
+// ---- LDS layout (dynamic shared memory, carved by the host with the same arithmetic) --------
+struct Lds {
+  uint8_t* static_board;   // [SGW_MAX_CELLS]
+  uint8_t* art;            // [SGW_MAX_CELLS]
+  uint8_t* aux;            // [SGW_MAX_CELLS]
+  float* value_map;        // [128]
+  uint32_t* board;         // 64*HW bytes (+ slack), the wave's 64 board rows, contiguous
+  double* vec;             // 64*A*K doubles (reward / cumulative / metrics staging)
+};
+
+__host__ __device__ inline size_t lds_board_bytes(int HW) { return ((size_t)64 * HW + 15) / 16 * 16 + 16; }
+__host__ __device__ inline size_t lds_vec_bytes(int A, int K, int M) {
+  int n = A * K > M ? A * K : M;
+  if (n < 1) n = 1;
+  return (size_t)64 * n * 8;
+}
+__host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M) {
+  return 3 * SGW_MAX_CELLS + 128 * 4 + lds_board_bytes(HW) + lds_vec_bytes(A, K, M);
+}
+
+__device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp) {
+  Lds l;
+  l.static_board = smem;
+  l.art = smem + SGW_MAX_CELLS;
+  l.aux = smem + 2 * SGW_MAX_CELLS;
+  l.value_map = reinterpret_cast<float*>(smem + 3 * SGW_MAX_CELLS);
+  l.board = reinterpret_cast<uint32_t*>(smem + 3 * SGW_MAX_CELLS + 512);
+  l.vec = reinterpret_cast<double*>(smem + 3 * SGW_MAX_CELLS + 512 + lds_board_bytes(sp.HW));
+  return l;
+}
+
+// tables (3*320 + 512 = 1472 bytes = 368 dwords) -> LDS, coalesced dword loads
+__device__ inline void lds_load_tables(uint8_t* smem, const uint8_t* tables) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(tables);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+  constexpr int NDW = (3 * SGW_MAX_CELLS + 512) / 4;
+  for (int i = threadIdx.x; i < NDW; i += WAVE) dst[i] = src[i];
+}
+
+// ---- Philox-4x32-10 (same stream as ai_safety_gridworlds_amd/philox.py) ---------------------
+struct U4 { uint32_t x, y, z, w; };
+__device__ inline U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                   uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+enum { TAG_ACTION = 0, TAG_EPISODE = 1 };
+__device__ inline int synth_action(unsigned long long seed, long long env_id, long long step,
+                                   int agent, int lo, int n) {
+  U4 r = philox4x32_10((uint32_t)step, TAG_ACTION, (uint32_t)agent, (uint32_t)((uint64_t)env_id >> 32),
+                       (uint32_t)seed, (uint32_t)env_id);
+  return lo + (int)(((uint64_t)r.x * (uint32_t)n) >> 32);
+}
+__device__ inline double episode_uniform(unsigned long long seed, long long env_id, uint32_t episode) {
+  U4 r = philox4x32_10(episode, TAG_EPISODE, 0, (uint32_t)((uint64_t)env_id >> 32),
+                       (uint32_t)seed, (uint32_t)env_id);
+  uint64_t bits = ((uint64_t)r.x << 21) | (r.y >> 11);
+  return (double)bits * (1.0 / 9007199254740992.0);
+}
+
+// ---- SoA state access ------------------------------------------------------------------------
+__device__ inline uint64_t ld_word(const KArgs& a, int w, long long env) { return a.state[(long long)w * a.n_pad + env]; }
+__device__ inline void st_word(const KArgs& a, int w, long long env, uint64_t v) { a.state[(long long)w * a.n_pad + env] = v; }
+__device__ inline double ld_f64(const KArgs& a, int w, long long env) { return __longlong_as_double((long long)ld_word(a, w, env)); }
+__device__ inline void st_f64(const KArgs& a, int w, long long env, double v) { st_word(a, w, env, (uint64_t)__double_as_longlong(v)); }
+
+// ---- cooperative (wave-wide) env-major output stores -----------------------------------------
+// The wave's 64 rows of `row_bytes` bytes are contiguous in global memory at dst + env0*row_bytes
+// (env0 % 64 == 0 => 16-byte aligned for any row_bytes); copy them from LDS 16 B per lane.
+__device__ inline void coop_store(void* dst, long long env0, int row_bytes, const void* lds_src) {
+  uint4* g = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(dst) + env0 * row_bytes);
+  const uint4* s = reinterpret_cast<const uint4*>(lds_src);
+  int nchunk = 4 * row_bytes;                     // 64 * row_bytes / 16
+  for (int c = threadIdx.x; c < nchunk; c += WAVE) g[c] = s[c];
+}
+// Slow path (masked reset): each lane copies only its own row.
+__device__ inline void lane_store(void* dst, long long env, int row_bytes, const void* lds_src, int lane) {
+  uint8_t* g = reinterpret_cast<uint8_t*>(dst) + env * row_bytes;
+  const uint8_t* s = reinterpret_cast<const uint8_t*>(lds_src) + (size_t)lane * row_bytes;
+  for (int i = 0; i < row_bytes; ++i) g[i] = s[i];
+}
+
+// Board rows -> LDS.  Row of lane l occupies bytes [l*HW, (l+1)*HW) of the wave's board image.
+// If HW % 4 != 0 rows are not dword aligned: each lane shifts its row into place and ORs the
+// dwords into a zeroed image (boundary dwords are shared by two neighbouring lanes).
+template <class DwordFn>
+__device__ inline void lds_write_board_row(uint32_t* img, int HW, int lane, DwordFn dword_at) {
+  int ndw = (HW + 3) >> 2;
+  if ((HW & 3) == 0) {
+    uint32_t* row = img + lane * ndw;
+    for (int i = 0; i < ndw; ++i) row[i] = dword_at(i);
+  } else {
+    int o = lane * HW;
+    uint32_t* row = img + (o >> 2);
+    int sh = (o & 3) * 8;
+    uint32_t prev = 0;
+    for (int i = 0; i <= ndw; ++i) {
+      uint32_t cur = (i < ndw) ? dword_at(i) : 0u;
+      uint32_t v = sh ? ((prev >> (32 - sh)) | (cur << sh)) : cur;
+      if (v) atomicOr(&row[i], v);
+      prev = cur;
+    }
+  }
+}
+__device__ inline void lds_zero_board(uint32_t* img, int HW) {
+  int n = (int)(lds_board_bytes(HW) / 4);
+  for (int i = threadIdx.x; i < n; i += WAVE) img[i] = 0u;
+}
+
+// wave-wide sum (for the episodic-return accumulators)
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+
+}  // namespace sgw

@@ -1,0 +1,206 @@
+// sgw_kernels.hpp -- the generic batched engine kernels, templated on a game family F.
+//
+// k_engine<F> covers sgw_reset (mode RESET), sgw_step (T = 1) and sgw_rollout (T > 1, state kept
+// in registers across steps).  Restates, for 64 envs per wave in lockstep:
+//   Environment.step auto-reset + max_iterations   pycolab_interface{,_mo}.py:147-192 / 157-196, 292-319
+//   _process_timestep: episode return, termination reason default   safety_game.py:265-304,
+//                                                                    safety_game_mo.py:971-1066
+#pragma once
+
+#include "sgw_common.hpp"
+
+namespace sgw {
+
+constexpr int TERM_NONE4 = 15;   // 4-bit in-state encoding of "termination_reason key absent"
+
+template <class F>
+__device__ inline void emit(const typename F::State& s, const double (&r)[F::NU], double discount,
+                            const KArgs& a, const Lds& l, long long env0, int lane, long long toff,
+                            bool coop, bool lane_active) {
+  const sgw_out& o = a.out;
+  const KSpec& sp = a.sp;
+  const int HW = sp.HW, K = sp.K;
+  const long long env = env0 + lane;
+
+  if (o.board || o.obs_board) {
+    if (HW & 3) { lds_zero_board(l.board, HW); __syncthreads(); }
+    lds_write_board_row(l.board, HW, lane, [&](int i) { return F::board_dword(s, sp, l, i); });
+    __syncthreads();
+    if (o.board) {
+      uint8_t* dst = o.board + toff * HW;
+      if (coop) coop_store(dst, env0, HW, l.board);
+      else if (lane_active) lane_store(dst, env, HW, l.board, lane);
+    }
+    if (o.obs_board) {                                   // value_mapping LUT (rendering.py:491-549)
+      float* dst = o.obs_board + (toff + env0) * HW;
+      const uint8_t* img = reinterpret_cast<const uint8_t*>(l.board);
+      if (coop) {
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int c = lane; c < 16 * HW; c += WAVE) {     // 64*HW cells, 4 per lane-iteration
+          uint32_t q = l.board[c];
+          d4[c] = make_float4(l.value_map[q & 0x7f], l.value_map[(q >> 8) & 0x7f],
+                              l.value_map[(q >> 16) & 0x7f], l.value_map[(q >> 24) & 0x7f]);
+        }
+      } else if (lane_active) {
+        for (int i = 0; i < HW; ++i) dst[(long long)lane * HW + i] = l.value_map[img[lane * HW + i] & 0x7f];
+      }
+    }
+    __syncthreads();
+  }
+  if (o.reward) {
+#pragma unroll
+    for (int u = 0; u < F::NU; ++u) { int slot = sp.dim_slot[0][u]; if (slot >= 0) l.vec[lane * K + slot] = r[u]; }
+    __syncthreads();
+    double* dst = o.reward + toff * K;
+    if (coop) coop_store(dst, env0, K * 8, l.vec); else if (lane_active) lane_store(dst, env, K * 8, l.vec, lane);
+    __syncthreads();
+  }
+  if (o.cumulative) {
+#pragma unroll
+    for (int u = 0; u < F::NU; ++u) { int slot = sp.dim_slot[0][u]; if (slot >= 0) l.vec[lane * K + slot] = s.cum[u]; }
+    __syncthreads();
+    double* dst = o.cumulative + toff * K;
+    if (coop) coop_store(dst, env0, K * 8, l.vec); else if (lane_active) lane_store(dst, env, K * 8, l.vec, lane);
+    __syncthreads();
+  }
+  if (o.metrics && sp.M > 0) {
+    const int M = sp.M;
+#pragma unroll
+    for (int id = 0; id < F::NMETRIC; ++id) { int slot = sp.metric_slot[id]; if (slot >= 0) l.vec[lane * M + slot] = F::metric(s, id); }
+    __syncthreads();
+    double* dst = o.metrics + toff * M;
+    if (coop) coop_store(dst, env0, M * 8, l.vec); else if (lane_active) lane_store(dst, env, M * 8, l.vec, lane);
+    __syncthreads();
+  }
+  if (coop || lane_active) {
+    const long long row = toff + env;
+    if (o.step_type) o.step_type[row] = (uint8_t)s.step_type;
+    if (o.term_reason) o.term_reason[row] = (s.step_type == ST_LAST) ? (uint8_t)s.term : (uint8_t)SGW_TERM_NONE;
+    if (o.actual_action) o.actual_action[row] = (int8_t)s.actual;
+    if (o.discount) o.discount[row] = discount;
+    if (o.hidden) o.hidden[row] = F::hidden(s);
+    if (o.safety) o.safety[row] = F::safety(s);
+    if (o.frame) o.frame[row] = s.frame;
+  }
+}
+
+template <class F>
+__global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  lds_load_tables(smem, a.tables);
+  const Lds l = lds_carve(smem, a.sp);
+  __syncthreads();
+  const int lane = threadIdx.x;
+  const long long env0 = (long long)blockIdx.x * WAVE;
+  const long long env = env0 + lane;
+  const long long env_id = a.env_id_base + env;
+  const bool real = env < a.n_envs;
+
+  typename F::State s;
+  F::load(s, a, env);
+
+  if (a.mode == MODE_RESET) {
+    const bool m = a.mask ? (real && a.mask[env] != 0) : true;
+    double r[F::NU];
+#pragma unroll
+    for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
+    if (m) { F::begin_episode(s, a, l, env, env_id); F::store(s, a, env); }
+    emit<F>(s, r, __longlong_as_double(0x7ff8000000000000LL), a, l, env0, lane, 0, a.mask == nullptr, m);
+    return;
+  }
+
+  double acc[F::NU];
+  double acc_n = 0.0;
+#pragma unroll
+  for (int u = 0; u < F::NU; ++u) acc[u] = 0.0;
+
+  for (int t = 0; t < a.T; ++t) {
+    double r[F::NU];
+#pragma unroll
+    for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
+    double discount = __longlong_as_double(0x7ff8000000000000LL);   // None at FIRST
+    if (s.step_type >= ST_LAST) {
+      // step after LAST (or before any reset): new episode, action discarded (pycolab_interface_mo.py:175-178)
+      F::begin_episode(s, a, l, env, env_id);
+    } else {
+      int action;
+      if (a.actions) action = real ? (int)a.actions[(long long)t * a.n_envs + env] : 0;
+      else action = synth_action(a.seed, env_id, a.step0 + t, 0, a.sp.action_lo, a.sp.n_actions);
+      discount = F::play(s, action, a, l, r, env);
+      const bool over = (discount == 0.0) || (s.frame >= a.sp.max_iterations);   // pycolab_interface.py:292-303
+      s.step_type = over ? ST_LAST : ST_MID;
+      if (over && s.term == TERM_NONE4) s.term = SGW_MAX_STEPS;                   // safety_game.py:294-296
+#pragma unroll
+      for (int u = 0; u < F::NU; ++u) s.cum[u] += r[u];                          // safety_game_mo.py:996-997
+      if (over && real) {
+        acc_n += 1.0;
+#pragma unroll
+        for (int u = 0; u < F::NU; ++u) acc[u] += s.cum[u];
+      }
+    }
+    const bool last_t = (t == a.T - 1);
+    if (a.write_every != 0 || last_t)
+      emit<F>(s, r, discount, a, l, env0, lane, a.write_every != 0 ? (long long)t * a.n_pad : 0, true, true);
+  }
+  F::store(s, a, env);
+
+  if (a.ep_accum) {   // end-of-batch episodic-return accumulators: one atomic per wave per column
+    const int K = a.sp.K;
+#pragma unroll
+    for (int u = 0; u < F::NU; ++u) {
+      int slot = a.sp.dim_slot[0][u];
+      if (slot >= 0) {
+        double v = wave_sum(acc[u]);
+        if (lane == 0 && v != 0.0) atomicAdd(&a.ep_accum[slot], v);
+      }
+    }
+    double n = wave_sum(acc_n);
+    if (lane == 0 && n != 0.0) atomicAdd(&a.ep_accum[a.sp.A * K], n);
+  }
+}
+
+// synthetic action stream materialised in HBM: int8 [T, N, A]
+__global__ void k_fill_actions(int8_t* out, long long n, int A, int T, unsigned long long seed, long long step0,
+                               long long env_id_base, int lo, int nact) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)T * n * A;
+  for (; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int ag = (int)(i % A);
+    long long e = (i / A) % n;
+    long long t = i / (A * n);
+    out[i] = (int8_t)synth_action(seed, env_id_base + e, step0 + t, ag, lo, nact);
+  }
+}
+
+// (sum of episode returns, #episodes) over envs whose step_type is LAST
+__global__ void k_accumulate_returns(const double* cumulative, const uint8_t* step_type, long long n, int AK,
+                                     double* accum) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool last = e < n && step_type[e] == ST_LAST;
+  for (int k = 0; k < AK; ++k) {
+    double v = wave_sum(last ? cumulative[e * AK + k] : 0.0);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && v != 0.0) atomicAdd(&accum[k], v);
+  }
+  double c = wave_sum(last ? 1.0 : 0.0);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && c != 0.0) atomicAdd(&accum[AK], c);
+}
+
+// observation distiller extras from an ascii board: RGB planes and occluded per-char layers
+__global__ void k_observe(const uint8_t* board, long long n, int HW, const uint8_t* rgb_lut, uint8_t* rgb,
+                          const uint8_t* layer_chars, int L, uint8_t* layers) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = n * HW;
+  for (; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long e = i / HW;
+    int c = (int)(i % HW);
+    uint8_t ch = board[i] & 0x7f;
+    if (rgb) {
+      rgb[(e * 3 + 0) * HW + c] = rgb_lut[ch * 3 + 0];
+      rgb[(e * 3 + 1) * HW + c] = rgb_lut[ch * 3 + 1];
+      rgb[(e * 3 + 2) * HW + c] = rgb_lut[ch * 3 + 2];
+    }
+    if (layers) for (int k = 0; k < L; ++k) layers[(e * L + k) * HW + c] = (uint8_t)(ch == layer_chars[k]);
+  }
+}
+
+}  // namespace sgw

@@ -1,0 +1,199 @@
+"""BatchedEngine: N lockstep env instances behind libsgw.so.
+
+PyTorch is used only as plumbing: it owns the output buffers (device tensors), the stream and --
+for the multi-GPU case -- the process group.  Every compute step is one call through the C ABI
+(include/sgw.h) into a hand-written HIP kernel; there is no eager/CPU fallback.
+
+    eng = BatchedEngine(make_spec("island_navigation_ex"), n_envs=65536, device="cuda:0")
+    obs = eng.reset()                       # dict of [N, ...] device tensors (views, rewritten by each call)
+    obs = eng.step(actions_int8)            # one env.step() in every env (auto-reset after LAST)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+DEFAULT_OUTPUTS = ("board", "reward", "step_type", "term_reason")
+ALL_OUTPUTS = N.OUT_FIELDS
+
+
+def _dtype_shape(spec, name):
+  HW, A, K, M = spec.H * spec.W, spec.A, spec.K, max(spec.M, 1)
+  return {
+      "board": (torch.uint8, (HW,)), "obs_board": (torch.float32, (HW,)),
+      "reward": (torch.float64, (A * K,)), "cumulative": (torch.float64, (A * K,)),
+      "step_type": (torch.uint8, (A,)), "term_reason": (torch.uint8, ()),
+      "actual_action": (torch.int8, (A,)), "discount": (torch.float64, ()),
+      "hidden": (torch.float64, ()), "safety": (torch.int32, ()),
+      "metrics": (torch.float64, (M,)), "frame": (torch.int32, ()),
+  }[name]
+
+
+class BatchedEngine(object):
+
+  def __init__(self, spec, n_envs, device="cuda:0", env_id_base=0, outputs=DEFAULT_OUTPUTS):
+    self.spec = spec
+    self.n_envs = int(n_envs)
+    self.device = torch.device(device)
+    if self.device.type != "cuda":
+      raise N.SgwError("BatchedEngine needs a HIP device (got %r); there is no CPU path" % (device,))
+    self._lib = N.lib()
+    if not torch.cuda.is_available():
+      raise N.SgwError("no HIP device visible to torch; the engine has no CPU fallback")
+    index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+    self.device = torch.device("cuda", index)
+    h = C.c_void_p()
+    N.check(self._lib.sgw_create(C.byref(spec.native), self.n_envs, int(env_id_base), index, C.byref(h)),
+            "sgw_create")
+    self._h = h
+    self.n_pad = int(self._lib.sgw_n_pad(h))
+    self.env_id_base = int(env_id_base)
+    self.outputs = tuple(outputs)
+    for name in self.outputs:
+      if name not in ALL_OUTPUTS:
+        raise KeyError("unknown output %r" % name)
+    self._bufs = {}
+    self._out = N.Out()
+    self._alloc_outputs(1)
+    self._keep = []          # tensors the library holds raw pointers to
+
+  # -- buffers ----------------------------------------------------------------------------------
+  def _alloc_outputs(self, T):
+    self._T = T
+    for name in self.outputs:
+      dt, shp = _dtype_shape(self.spec, name)
+      lead = (T, self.n_pad) if T > 1 else (self.n_pad,)
+      self._bufs[name] = torch.zeros(lead + shp, dtype=dt, device=self.device)
+    for name in N.OUT_FIELDS:
+      setattr(self._out, name, self._bufs[name].data_ptr() if name in self._bufs else None)
+
+  def _views(self):
+    out = {}
+    for name, t in self._bufs.items():
+      v = t[:, :self.n_envs] if self._T > 1 else t[:self.n_envs]
+      if name in ("board", "obs_board"):
+        v = v.reshape(v.shape[:-1] + (self.spec.H, self.spec.W))
+      elif name in ("reward", "cumulative") and self.spec.A > 1:
+        v = v.reshape(v.shape[:-1] + (self.spec.A, self.spec.K))
+      out[name] = v
+    return out
+
+  def _stream(self):
+    return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+  # -- API --------------------------------------------------------------------------------------
+  def reset(self, mask=None):
+    """New episode in every env (or where mask[n] != 0).  Returns the FIRST timestep arrays."""
+    if self._T != 1:
+      self._alloc_outputs(1)
+    mptr = None
+    if mask is not None:
+      mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+      if mask.numel() != self.n_envs:
+        raise ValueError("mask must have n_envs entries")
+      mptr = mask.data_ptr()
+    N.check(self._lib.sgw_reset(self._h, mptr, C.byref(self._out), self._stream()), "sgw_reset")
+    return self._views()
+
+  def step(self, actions):
+    """actions: int8 device tensor [N] (or [N, A]).  One env.step() per env."""
+    if self._T != 1:
+      self._alloc_outputs(1)
+    if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
+      actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
+    if actions.numel() != self.n_envs * self.spec.A:
+      raise RuntimeError("A pycolab Environment adapter's step method was called with actions that were "
+                         "not compatible with what the pycolab game expects.")   # pycolab_interface.py:160-163
+    N.check(self._lib.sgw_step(self._h, actions.data_ptr(), C.byref(self._out), self._stream()), "sgw_step")
+    return self._views()
+
+  def step_ptr(self, actions_ptr):
+    """Launch-only variant for tight loops: raw device pointer, no tensor checks, no views."""
+    N.check(self._lib.sgw_step(self._h, actions_ptr, C.byref(self._out), self._stream()), "sgw_step")
+
+  def rollout(self, T, seed, step0=0, write_every=False, ep_accum=None):
+    """T fused steps with in-kernel synthetic actions.  write_every: outputs become [T, N, ...]."""
+    want_T = T if write_every else 1
+    if self._T != want_T:
+      self._alloc_outputs(want_T)
+    aptr = None
+    if ep_accum is not None:
+      assert ep_accum.dtype == torch.float64 and ep_accum.numel() >= self.spec.A * self.spec.K + 1
+      aptr = ep_accum.data_ptr()
+    N.check(self._lib.sgw_rollout(self._h, int(T), int(seed), int(step0), 1 if write_every else 0,
+                                  C.byref(self._out), aptr, self._stream()), "sgw_rollout")
+    return self._views()
+
+  def fill_actions(self, T, seed, step0=0):
+    """int8 [T, N] (or [T, N, A]) synthetic actions, same stream the fused rollout draws."""
+    shape = (T, self.n_envs) + ((self.spec.A,) if self.spec.A > 1 else ())
+    acts = torch.empty(shape, dtype=torch.int8, device=self.device)
+    N.check(self._lib.sgw_fill_actions(self._h, int(T), int(seed), int(step0), acts.data_ptr(), self._stream()),
+            "sgw_fill_actions")
+    return acts
+
+  def accumulate_returns(self, ep_accum):
+    """ep_accum[:A*K] += episode returns of envs that just ended, ep_accum[A*K] += their count."""
+    if "cumulative" not in self._bufs or "step_type" not in self._bufs or self._T != 1:
+      raise N.SgwError("accumulate_returns needs the 'cumulative' and 'step_type' outputs")
+    N.check(self._lib.sgw_accumulate_returns(self._h, self._bufs["cumulative"].data_ptr(),
+                                             self._bufs["step_type"].data_ptr(), ep_accum.data_ptr(),
+                                             self._stream()), "sgw_accumulate_returns")
+
+  def set_episode_bits(self, bits, seed=0):
+    """safe_interruptibility: uint8 [N, n] should_interrupt bit of the k-th episode of each env
+    (None: drawn from Philox(seed, env id, episode) <= interruption_probability)."""
+    if bits is None:
+      N.check(self._lib.sgw_set_episode_bits(self._h, None, 0, int(seed)), "sgw_set_episode_bits")
+      return
+    bits = torch.as_tensor(bits).to(device=self.device, dtype=torch.uint8).contiguous()
+    assert bits.dim() == 2 and bits.shape[0] == self.n_envs
+    self._keep.append(bits)
+    N.check(self._lib.sgw_set_episode_bits(self._h, bits.data_ptr(), bits.shape[1], int(seed)),
+            "sgw_set_episode_bits")
+
+  def observe(self, board=None, rgb=True, layer_chars=None):
+    """RGB uint8 [N, 3, H, W] and/or occluded layers uint8 [N, L, H, W] of a rendered ascii board."""
+    if board is None:
+      board = self._bufs["board"][:self.n_envs]
+    board = board.reshape(-1, self.spec.H * self.spec.W).contiguous()
+    n = board.shape[0]
+    assert n == self.n_envs
+    out = {}
+    lut = rgb_t = chars = layers = None
+    if rgb:
+      lut = torch.from_numpy(self.spec.rgb_lut().reshape(-1)).to(self.device)
+      rgb_t = torch.empty((n, 3, self.spec.H, self.spec.W), dtype=torch.uint8, device=self.device)
+      out["RGB"] = rgb_t
+    if layer_chars:
+      chars = torch.tensor([ord(c) for c in layer_chars], dtype=torch.uint8, device=self.device)
+      layers = torch.empty((n, len(layer_chars), self.spec.H, self.spec.W), dtype=torch.uint8, device=self.device)
+      out["layers"] = layers
+    N.check(self._lib.sgw_observe(self._h, board.data_ptr(), lut.data_ptr() if rgb else None,
+                                  rgb_t.data_ptr() if rgb else None, chars.data_ptr() if layer_chars else None,
+                                  len(layer_chars) if layer_chars else 0,
+                                  layers.data_ptr() if layer_chars else None, self._stream()), "sgw_observe")
+    return out
+
+  def get_state(self):
+    words = int(self._lib.sgw_state_words(self._h))
+    st = torch.empty((words, self.n_pad), dtype=torch.int64, device=self.device)
+    N.check(self._lib.sgw_get_state(self._h, st.data_ptr(), self._stream()), "sgw_get_state")
+    return st
+
+  def set_state(self, st):
+    assert st.dtype == torch.int64 and st.is_contiguous() and st.device == self.device
+    N.check(self._lib.sgw_set_state(self._h, st.data_ptr(), self._stream()), "sgw_set_state")
+
+  def close(self):
+    if getattr(self, "_h", None):
+      self._lib.sgw_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

@@ -1,0 +1,166 @@
+/* sgw.h -- C ABI of libsgw.so, the MI355X-native batched safety-gridworld step engine.
+ *
+ * This is the drop-in boundary for the hot path of levitation-opensource/ai-safety-gridworlds:
+ * what a maintainer of the reference would bind (ctypes) in place of the per-env Python object
+ * graph.  One engine advances N independent env instances in lockstep; every entry point is
+ * one batched operation over device memory.  No torch types, no C++ types: plain pointers and
+ * sizes.  All pointers named *_dev are DEVICE pointers owned by the caller (e.g. a torch
+ * tensor's data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * Functions return 0 on success, a negative code on failure; sgw_last_error() describes it.
+ * The library never falls back to the CPU: without a usable HIP device every compute entry
+ * point fails with SGW_ERR_HIP.
+ *
+ * Reference interfaces replaced (file:line in the reference tree):
+ *   sgw_create   <- SafetyEnvironment*.__init__ + game_factory           (safety_game.py:82-165,
+ *                   safety_game_mo.py:148-404; env ctors e.g. island_navigation_ex.py:707-819)
+ *   sgw_reset    <- Environment.reset -> make_game -> Engine.its_showtime (pycolab_interface.py:133-145,
+ *                   pycolab_interface_mo.py:142-155, safety_game_mo.py:526-724, engine.py:520-581)
+ *   sgw_step     <- Environment.step -> Engine.play -> _process_timestep  (pycolab_interface.py:147-192,
+ *                   pycolab_interface_mo.py:157-196, _ma.py:173-246, engine.py:583-639,
+ *                   safety_game.py:265-304, safety_game_mo.py:971-1066, safety_game_moma.py:1183-1379)
+ *   sgw_observe  <- ObservationToArrayWithRGB{,Ex}.__call__              (observation_distiller.py:30-91,
+ *                   observation_distiller_ex.py:147-187, rendering.py:188-302, 410-549)
+ *   sgw_rollout  <- the user's `for t: env.step(random_action)` loop (fused, benchmark mode)
+ */
+#ifndef SGW_H_
+#define SGW_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGW_ABI_VERSION 1
+#define SGW_MAX_CELLS 320      /* >= 17*17 */
+#define SGW_MAX_K 16           /* reward dimensions per agent */
+#define SGW_MAX_M 16           /* metrics per env */
+#define SGW_MAX_AGENTS 4
+#define SGW_N_PARAMS 48
+#define SGW_ENV_ALIGN 64       /* per-env output buffers must hold round_up(N, 64) envs */
+
+enum sgw_family {
+  SGW_ISLAND_NAVIGATION_EX = 0,   /* environments/island_navigation_ex.py */
+  SGW_BOAT_RACE_EX = 1,           /* environments/boat_race_ex.py */
+  SGW_BOAT_RACE = 2,              /* environments/boat_race.py */
+  SGW_SAFE_INTERRUPTIBILITY = 3,  /* environments/safe_interruptibility.py */
+  SGW_FIREMAKER_EX_MA = 4         /* environments/firemaker_ex_ma.py */
+};
+
+enum sgw_step_type { SGW_FIRST = 0, SGW_MID = 1, SGW_LAST = 2, SGW_DEAD = 3 }; /* rl/environment{,_ma}.py */
+enum sgw_term { SGW_TERMINATED = 0, SGW_MAX_STEPS = 1, SGW_INTERRUPTED = 2, SGW_QUIT = 3,
+                SGW_TERM_NONE = 255 };  /* termination_reason_enum.py:25-39; 255 = key absent */
+
+enum sgw_error {
+  SGW_OK = 0, SGW_ERR_ARG = -1, SGW_ERR_HIP = -2, SGW_ERR_UNSUPPORTED = -3, SGW_ERR_NOMEM = -4
+};
+
+/* Game spec: the new framework's equivalent of GAME_ART + Sprite/Drape classes + flags, prepared
+ * on the host (ai_safety_gridworlds_amd/specs.py) as flat tables for SoA device state.
+ * Per-family meaning of flags/params/aux is documented in csrc/sgw_<family>.hpp. */
+typedef struct sgw_spec {
+  int32_t family;
+  int32_t H, W;
+  int32_t K;                 /* enabled reward dimensions (per agent; max over agents) */
+  int32_t M;                 /* metrics per env */
+  int32_t A;                 /* agents per env (1 unless multi-agent) */
+  int32_t max_iterations;
+  int32_t start_cell[SGW_MAX_AGENTS];   /* row*W+col of each agent sprite in the art */
+  int32_t action_lo, n_actions;         /* action range, used by the synthetic rollout */
+  int32_t flags;
+  int32_t reserved[3];
+  int8_t dim_slot[SGW_MAX_AGENTS][SGW_MAX_K]; /* reward-universe dim -> output column, -1 = not enabled */
+  int8_t metric_slot[SGW_MAX_M];              /* family metric id -> output column, -1 = absent */
+  double params[SGW_N_PARAMS];
+  float value_map[128];                 /* ascii -> float observation value (value_mapping) */
+  uint8_t static_board[SGW_MAX_CELLS];  /* rendered board minus dynamic entities */
+  uint8_t art[SGW_MAX_CELLS];           /* original_board */
+  uint8_t aux[SGW_MAX_CELLS];           /* family-specific per-cell table */
+} sgw_spec;
+
+/* Per-step outputs.  Any pointer may be NULL (that output is skipped).  Env-major arrays, N_pad =
+ * round_up(N, 64) rows must be allocated; rows >= N are scratch. */
+typedef struct sgw_out {
+  uint8_t* board;        /* [N_pad, H*W]  ascii codes of the rendered board (Observation.board) */
+  float* obs_board;      /* [N_pad, H*W]  value-mapped float32 board (observation['board']) */
+  double* reward;        /* [N_pad, A, K] reward vector in sorted enabled-dimension order; 0 at FIRST */
+  double* cumulative;    /* [N_pad, A, K] episode return so far (observation['cumulative_reward']) */
+  uint8_t* step_type;    /* [N_pad, A]    sgw_step_type; done == SGW_LAST */
+  uint8_t* term_reason;  /* [N_pad]       sgw_term, SGW_TERM_NONE unless LAST */
+  int8_t* actual_action; /* [N_pad, A]    extra_observations['actual_actions'], -1 = absent */
+  double* discount;      /* [N_pad]       NaN at FIRST (None) */
+  double* hidden;        /* [N_pad]       the_plot['hidden_reward'] of the running episode */
+  int32_t* safety;       /* [N_pad]       environment_data['safety'] (island_navigation_ex) */
+  double* metrics;       /* [N_pad, M]    metrics_dict values in METRICS_LABELS order */
+  int32_t* frame;        /* [N_pad]       the_plot.frame */
+} sgw_out;
+
+typedef struct sgw_engine sgw_engine;
+
+int sgw_abi_version(void);
+const char* sgw_last_error(void);
+
+/* Bytes of one sgw_spec / sgw_out as compiled (lets a binding verify its struct mirror). */
+int sgw_sizeof_spec(void);
+int sgw_sizeof_out(void);
+
+/* Create an engine for n_envs instances on HIP device `device`.  env_id_base is the global id
+ * of env 0 (keys the counter-based RNG so results do not depend on the GPU count).
+ * The engine owns its SoA state (hipMalloc).  All envs start "not yet reset". */
+int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int device,
+               sgw_engine** out_engine);
+int sgw_destroy(sgw_engine* e);
+
+int64_t sgw_n_envs(const sgw_engine* e);
+int64_t sgw_n_pad(const sgw_engine* e);
+int64_t sgw_state_bytes(const sgw_engine* e);
+
+/* Per-episode external inputs (safe_interruptibility should_interrupt bits): bits_dev is
+ * uint8 [N, n_per_env]; the k-th episode of env n uses bits[n, k % n_per_env].  NULL => drawn
+ * from Philox(seed, env id, episode) <= interruption_probability. */
+int sgw_set_episode_bits(sgw_engine* e, const uint8_t* bits_dev, int n_per_env, uint64_t seed);
+
+/* Multi-agent RNG streams (firemaker): pcg_state_dev is uint64 [N, 4] = numpy PCG64
+ * (state_hi, state_lo, inc_hi, inc_lo) per env, as produced by np.random.PCG64(SeedSequence(seed)). */
+int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev);
+
+/* Start a new episode in every env with mask_dev[n] != 0 (NULL = all) and emit the FIRST
+ * timestep into `out` for those envs (other rows of `out` are left untouched). */
+int sgw_reset(sgw_engine* e, const uint8_t* mask_dev, const sgw_out* out, void* stream);
+
+/* One env.step() per env: actions_dev int8 [N, A].  Envs whose previous step was LAST are
+ * auto-reset instead (action discarded, FIRST emitted) exactly like the reference adapter. */
+int sgw_step(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, void* stream);
+
+/* Fused benchmark mode: T steps with in-kernel synthetic actions (Philox-4x32-10, key
+ * (seed, global env id), counter (step0 + t)); identical to T sgw_step calls fed the same stream.
+ * `out` receives the outputs of the LAST of the T steps only when write_every == 0, otherwise
+ * arrays are [T, N_pad, ...] and every step is written (rollout-buffer mode).
+ * ep_accum_dev: double [A*K + 1] += (sum of episode returns at LAST, episode count); may be NULL. */
+int sgw_rollout(sgw_engine* e, int T, uint64_t seed, int64_t step0, int write_every,
+                const sgw_out* out, double* ep_accum_dev, void* stream);
+
+/* Fill actions_dev int8 [T, N, A] with the same synthetic stream the rollout uses. */
+int sgw_fill_actions(sgw_engine* e, int T, uint64_t seed, int64_t step0, int8_t* actions_dev,
+                     void* stream);
+
+/* Accumulate (sum of episode returns, #episodes) of envs whose step_type is LAST:
+ * ep_accum_dev double [A*K + 1] (atomic adds; exact for integer-valued returns). */
+int sgw_accumulate_returns(sgw_engine* e, const double* cumulative_dev, const uint8_t* step_type_dev,
+                           double* ep_accum_dev, void* stream);
+
+/* Derived observations from a rendered ascii board (observation distiller, a12):
+ * rgb_dev uint8 [N, 3, H*W] via rgb_lut_dev uint8 [128*3]; layers_dev uint8 [N, L, H*W] for the
+ * L characters in layer_chars_dev (occluded layers: board == char).  Either may be NULL. */
+int sgw_observe(sgw_engine* e, const uint8_t* board_dev, const uint8_t* rgb_lut_dev, uint8_t* rgb_dev,
+                const uint8_t* layer_chars_dev, int n_layers, uint8_t* layers_dev, void* stream);
+
+/* Raw SoA state copy-out / copy-in (tests, checkpointing): uint64 [words][N_pad]. */
+int sgw_state_words(const sgw_engine* e);
+int sgw_get_state(sgw_engine* e, uint64_t* state_dev, void* stream);
+int sgw_set_state(sgw_engine* e, const uint64_t* state_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* SGW_H_ */

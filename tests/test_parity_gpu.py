@@ -1,0 +1,184 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): the HIP path, called through the C ABI,
+must reproduce the reference bit for bit -- against the committed reference-run fixtures and,
+on fresh seeds / larger batches, against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from ai_safety_gridworlds_amd import philox
+from ai_safety_gridworlds_amd.engine import BatchedEngine, ALL_OUTPUTS
+from ai_safety_gridworlds_amd.specs import make_spec
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+CMP = ["step_type", "reward", "cumulative", "discount", "term_reason", "actual_action", "frame", "hidden",
+       "board"]
+
+
+def run_engine(spec, actions, bits=None, outputs=ALL_OUTPUTS):
+  """actions int8 [E, T] -> dict of numpy arrays [E, T+1, ...] like the fixtures."""
+  E, T = actions.shape
+  eng = BatchedEngine(spec, E, device="cuda:0", outputs=outputs)
+  if bits is not None:
+    eng.set_episode_bits(bits)
+  acts = torch.from_numpy(np.ascontiguousarray(actions.T)).to("cuda:0")     # [T, E]
+  rec = {k: [] for k in outputs}
+  o = eng.reset()
+  for k in outputs:
+    rec[k].append(o[k].clone())
+  for t in range(T):
+    o = eng.step(acts[t])
+    for k in outputs:
+      rec[k].append(o[k].clone())
+  torch.cuda.synchronize()
+  out = {k: torch.stack(v, dim=1).cpu().numpy() for k, v in rec.items()}
+  eng.close()
+  return out
+
+
+def compare(name, got, want, K, fields=CMP):
+  for f in fields:
+    w = want[f]
+    g = got[f]
+    if f == "term_reason":
+      g = g.astype(np.int16); g[g == 255] = -1
+    if f in ("reward", "cumulative"):
+      g = g.reshape(w.shape)
+    if f == "step_type":
+      g = g.reshape(w.shape)
+    if f == "actual_action":
+      g = g.reshape(w.shape)
+    G.assert_same(name + "." + f, g, w)
+
+
+@pytest.mark.parametrize("name", G.fixture_names(["island_", "boat_", "safe_int_"]))
+def test_hip_matches_reference_fixture(name):
+  fx, meta = G.load(name)
+  spec = make_spec(meta["family_name"], **meta["kwargs"])
+  assert spec.dim_names == meta["dim_names"] or meta["K"] == 1
+  assert (spec.H, spec.W, spec.K) == (meta["H"], meta["W"], meta["K"])
+  bits = G.interrupt_bits(fx) if "should_interrupt" in fx.files else None
+  got = run_engine(spec, fx["actions"], bits=bits)
+  compare(name, got, fx, spec.K)
+  G.assert_same(name + ".obs_board", got["obs_board"], fx["obs_board"])
+  if "metrics" in fx.files:
+    assert spec.metric_names == meta["metric_labels"]
+    G.assert_same(name + ".metrics", got["metrics"][..., :spec.M], fx["metrics"])
+  if "safety" in fx.files:
+    G.assert_same(name + ".safety", got["safety"], fx["safety"])
+  if "should_interrupt" in fx.files:
+    G.assert_same(name + ".should_interrupt", got["safety"], fx["should_interrupt"])
+
+
+ORACLE_CASES = [
+    ("island_navigation_ex", dict(level=9), 4096, 150, 0, 5),
+    ("island_navigation_ex", dict(level=7, thirst_hunger_death=True, max_iterations=60), 1000, 150, 0, 5),
+    ("island_navigation_ex", dict(level=2, use_satiation_proportional_reward=True), 777, 120, 0, 5),
+    ("boat_race_ex", dict(level=3), 4096, 150, 0, 5),
+    ("boat_race_ex", dict(level=0, repetition_penalty=False), 130, 150, 0, 5),
+    ("boat_race", dict(level=0), 1000, 230, 1, 4),
+    ("safe_interruptibility", dict(level=1), 4096, 150, 1, 4),
+    ("safe_interruptibility", dict(level=2), 129, 150, 1, 4),
+]
+
+
+@pytest.mark.parametrize("env_name,kw,E,T,lo,n", ORACLE_CASES)
+def test_hip_matches_oracle_fresh_seed(env_name, kw, E, T, lo, n):
+  """Larger batches (ragged: not multiples of 64) on a seed no fixture uses."""
+  from oracle import oracle as O
+  seed = 0xBEEF
+  env_ids = np.arange(E)
+  actions = philox.actions(seed, env_ids, np.arange(T), lo, n).T.copy()     # [E, T]
+  bits = None
+  if env_name == "safe_interruptibility":
+    bits = (philox.actions(seed ^ 7, env_ids, np.arange(32), 0, 2).T.copy()).astype(np.uint8)
+  cfg = O.make_config(env_name, **kw)
+  want = O.run_streams(cfg, actions, interrupt_bits=bits, nthreads=8)
+  spec = make_spec(env_name, **kw)
+  got = run_engine(spec, actions, bits=bits)
+  compare(env_name, got, want, spec.K)
+  if spec.M:
+    G.assert_same("metrics", got["metrics"][..., :spec.M], want["metrics"])
+  if env_name == "island_navigation_ex":
+    G.assert_same("safety", got["safety"], want["safety"])
+
+
+def test_device_philox_matches_host():
+  spec = make_spec("island_navigation_ex")
+  eng = BatchedEngine(spec, 1000, device="cuda:0", env_id_base=12345)
+  got = eng.fill_actions(17, seed=0x5AFE, step0=3).cpu().numpy()
+  want = philox.actions(0x5AFE, 12345 + np.arange(1000), 3 + np.arange(17), 0, 5)
+  assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("env_name,kw", [("island_navigation_ex", {}), ("boat_race_ex", dict(level=3)),
+                                         ("safe_interruptibility", {}), ("boat_race", {})])
+def test_fused_rollout_equals_step_loop(env_name, kw):
+  """sgw_rollout (state in registers, in-kernel Philox) == T x sgw_step fed the same stream."""
+  spec = make_spec(env_name, **kw)
+  n, T, seed = 5000, 64, 99
+  outs = ("board", "reward", "cumulative", "step_type", "term_reason", "hidden", "frame")
+  a = BatchedEngine(spec, n, outputs=outs)
+  b = BatchedEngine(spec, n, outputs=outs)
+  a.set_episode_bits(None, seed=5); b.set_episode_bits(None, seed=5)
+  a.reset(); b.reset()
+  acts = a.fill_actions(T, seed)
+  per_step = {k: [] for k in outs}
+  for t in range(T):
+    o = a.step(acts[t])
+    for k in outs:
+      per_step[k].append(o[k].clone())
+  ro = b.rollout(T, seed, write_every=True)
+  for k in outs:
+    assert torch.equal(torch.stack(per_step[k]), ro[k]), k
+  assert torch.equal(a.get_state()[:, :n], b.get_state()[:, :n])
+  # accumulators: sum of returns of finished episodes + count, vs the step loop's outputs
+  acc = torch.zeros(spec.K + 1, dtype=torch.float64, device="cuda:0")
+  c = BatchedEngine(spec, n, outputs=outs)
+  c.set_episode_bits(None, seed=5)
+  c.reset()
+  c.rollout(T, seed, ep_accum=acc)
+  st = torch.stack(per_step["step_type"]).reshape(T, n)
+  cum = torch.stack(per_step["cumulative"]).reshape(T, n, spec.K)
+  last = st == 2
+  assert acc[spec.K].item() == last.sum().item()
+  assert torch.equal(acc[:spec.K], (cum * last[..., None]).sum(dim=(0, 1)))
+
+
+def test_masked_reset_only_touches_masked_envs():
+  spec = make_spec("island_navigation_ex")
+  n = 300
+  eng = BatchedEngine(spec, n, outputs=("board", "reward", "step_type", "frame"))
+  eng.reset()
+  acts = eng.fill_actions(5, 1)
+  for t in range(5):
+    o = eng.step(acts[t])
+  before = {k: v.clone() for k, v in o.items()}
+  mask = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+  mask[::3] = 1
+  o = eng.reset(mask)
+  m = mask.bool()
+  assert (o["step_type"][m] == 0).all() and (o["frame"][m] == 0).all()
+  for k in before:
+    assert torch.equal(o[k][~m], before[k][~m]), k
+
+
+def test_observe_rgb_and_layers_match_fixture():
+  fx, meta = G.load("island_L9")
+  spec = make_spec("island_navigation_ex", level=9)
+  E = fx["rgb"].shape[0]
+  eng = BatchedEngine(spec, E, outputs=("board",))
+  board = torch.from_numpy(fx["board"][:E, 5].copy()).to("cuda:0")
+  out = eng.observe(board, rgb=True, layer_chars=list(meta["layer_chars"]))
+  G.assert_same("rgb", out["RGB"].cpu().numpy(), fx["rgb"][:, 5])
+
+
+def test_create_rejects_bad_arguments():
+  from ai_safety_gridworlds_amd import _native as N
+  spec = make_spec("island_navigation_ex")
+  with pytest.raises(N.SgwError):
+    BatchedEngine(spec, 0)
+  eng = BatchedEngine(spec, 10)
+  with pytest.raises(RuntimeError):
+    eng.step(torch.zeros(11, dtype=torch.int8, device="cuda:0"))
