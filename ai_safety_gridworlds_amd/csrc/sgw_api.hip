@@ -208,6 +208,37 @@ int sgw_step(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, void*
   return launch(e, a, (hipStream_t)stream);
 }
 
+static void offset_out(sgw_out& o, const sgw_spec& sp, long long n_pad, long long t) {
+  const long long HW = sp.H * sp.W, AK = sp.A * sp.K, A = sp.A, M = sp.M, r = t * n_pad;
+  if (o.board) o.board += r * HW;
+  if (o.obs_board) o.obs_board += r * HW;
+  if (o.reward) o.reward += r * AK;
+  if (o.cumulative) o.cumulative += r * AK;
+  if (o.step_type) o.step_type += r * A;
+  if (o.term_reason) o.term_reason += r;
+  if (o.actual_action) o.actual_action += r * A;
+  if (o.discount) o.discount += r;
+  if (o.hidden) o.hidden += r;
+  if (o.safety) o.safety += r;
+  if (o.metrics) o.metrics += r * M;
+  if (o.frame) o.frame += r;
+}
+
+int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out,
+               double* ep_accum_dev, void* stream) {
+  if (!e) return fail(SGW_ERR_ARG, "sgw_step_n: null engine");
+  if (!actions_dev || T < 1) return fail(SGW_ERR_ARG, "sgw_step_n: bad argument");
+  for (int t = 0; t < T; ++t) {
+    KArgs a; memset(&a, 0, sizeof(a));
+    a.mode = MODE_STEP; a.T = 1; a.ep_accum = ep_accum_dev;
+    a.actions = actions_dev + (long long)t * e->n_envs * e->spec.A;
+    if (out) { a.out = *out; if (write_every) offset_out(a.out, e->spec, e->n_pad, t); }
+    int rc = launch(e, a, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return SGW_OK;
+}
+
 int sgw_rollout(sgw_engine* e, int T, uint64_t seed, int64_t step0, int write_every, const sgw_out* out,
                 double* ep_accum_dev, void* stream) {
   if (!e) return fail(SGW_ERR_ARG, "sgw_rollout: null engine");

@@ -113,6 +113,20 @@ class BatchedEngine(object):
     """Launch-only variant for tight loops: raw device pointer, no tensor checks, no views."""
     N.check(self._lib.sgw_step(self._h, actions_ptr, C.byref(self._out), self._stream()), "sgw_step")
 
+  def step_n(self, actions, write_every=False, ep_accum=None):
+    """actions int8 [T, N(, A)] resident on the device: T step launches issued from C (no Python in
+    the loop).  Returns the last step's arrays, or [T, N, ...] arrays with write_every."""
+    T = int(actions.shape[0])
+    assert actions.dtype == torch.int8 and actions.is_contiguous() and actions.device == self.device
+    assert actions.numel() == T * self.n_envs * self.spec.A
+    want_T = T if write_every else 1
+    if self._T != want_T:
+      self._alloc_outputs(want_T)
+    aptr = ep_accum.data_ptr() if ep_accum is not None else None
+    N.check(self._lib.sgw_step_n(self._h, actions.data_ptr(), T, 1 if write_every else 0, C.byref(self._out),
+                                 aptr, self._stream()), "sgw_step_n")
+    return self._views()
+
   def rollout(self, T, seed, step0=0, write_every=False, ep_accum=None):
     """T fused steps with in-kernel synthetic actions.  write_every: outputs become [T, N, ...]."""
     want_T = T if write_every else 1

@@ -132,6 +132,12 @@ int sgw_reset(sgw_engine* e, const uint8_t* mask_dev, const sgw_out* out, void* 
  * auto-reset instead (action discarded, FIRST emitted) exactly like the reference adapter. */
 int sgw_step(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, void* stream);
 
+/* T consecutive sgw_step launches (one kernel launch per step, host loop in C): actions_dev int8
+ * [T, N, A].  write_every == 0: `out` is overwritten by each step; otherwise arrays are [T, N_pad, ...].
+ * ep_accum_dev as in sgw_rollout (may be NULL). */
+int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out,
+               double* ep_accum_dev, void* stream);
+
 /* Fused benchmark mode: T steps with in-kernel synthetic actions (Philox-4x32-10, key
  * (seed, global env id), counter (step0 + t)); identical to T sgw_step calls fed the same stream.
  * `out` receives the outputs of the LAST of the T steps only when write_every == 0, otherwise
