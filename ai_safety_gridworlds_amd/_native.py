@@ -53,6 +53,9 @@ def lib():
   global _lib
   if _lib is not None:
     return _lib
+  # One HIP runtime per process: torch ships its own libamdhip64; load torch first so libsgw.so binds
+  # to the runtime torch's tensors/streams live in (two runtimes => "no ROCm-capable device").
+  import torch  # noqa: F401
   from . import build as _build
   try:
     path = _build.build()
@@ -72,9 +75,10 @@ def lib():
   L.sgw_set_rng_state.argtypes = [C.c_void_p, C.c_void_p]
   L.sgw_reset.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Out), C.c_void_p]
   L.sgw_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Out), C.c_void_p]
-  L.sgw_step_n.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Out), C.c_void_p, C.c_void_p]
+  L.sgw_step_n.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Out), C.c_int, C.c_void_p]
   L.sgw_rollout.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_int, C.POINTER(Out),
-                            C.c_void_p, C.c_void_p]
+                            C.c_int, C.c_void_p]
+  L.sgw_read_returns.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
   L.sgw_fill_actions.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]
   L.sgw_accumulate_returns.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
   L.sgw_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -94,7 +98,7 @@ def lib():
 EXPORTS = [
     "sgw_abi_version", "sgw_last_error", "sgw_sizeof_spec", "sgw_sizeof_out", "sgw_create",
     "sgw_destroy", "sgw_n_envs", "sgw_n_pad", "sgw_state_bytes", "sgw_set_episode_bits",
-    "sgw_set_rng_state", "sgw_reset", "sgw_step", "sgw_step_n", "sgw_rollout", "sgw_fill_actions",
+    "sgw_set_rng_state", "sgw_reset", "sgw_step", "sgw_step_n", "sgw_rollout", "sgw_read_returns", "sgw_fill_actions",
     "sgw_accumulate_returns", "sgw_observe", "sgw_state_words", "sgw_get_state", "sgw_set_state"]
 
 

@@ -41,6 +41,7 @@ struct sgw_engine {
   int ep_bits_n;
   unsigned long long ep_seed;
   size_t lds_bytes;
+  double* acc_dev;         // [A*K+1][n_pad] episodic-return accumulators (lazily allocated)
 };
 
 static int family_words(const sgw_spec& sp) {
@@ -92,7 +93,7 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   e->n_envs = n_envs;
   e->n_pad = (n_envs + SGW_ENV_ALIGN - 1) / SGW_ENV_ALIGN * SGW_ENV_ALIGN;
   e->env_id_base = env_id_base;
-  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0;
+  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0; e->acc_dev = nullptr;
 
   KSpec& k = e->ks;
   memset(&k, 0, sizeof(k));
@@ -102,16 +103,16 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   memcpy(k.start_cell, spec->start_cell, sizeof(k.start_cell));
   memcpy(k.dim_slot, spec->dim_slot, sizeof(k.dim_slot));
   memcpy(k.metric_slot, spec->metric_slot, sizeof(k.metric_slot));
-  memcpy(k.params, spec->params, sizeof(k.params));
   e->lds_bytes = lds_total_bytes(HW, spec->A, spec->K, spec->M);
 
-  const size_t tbytes = 3 * SGW_MAX_CELLS + 512;
-  uint8_t host_tables[3 * SGW_MAX_CELLS + 512];
+  const size_t tbytes = TABLE_BYTES;
+  uint8_t host_tables[TABLE_BYTES];
   memset(host_tables, 0, sizeof(host_tables));
   memcpy(host_tables, spec->static_board, HW);
   memcpy(host_tables + SGW_MAX_CELLS, spec->art, HW);
   memcpy(host_tables + 2 * SGW_MAX_CELLS, spec->aux, HW);
   memcpy(host_tables + 3 * SGW_MAX_CELLS, spec->value_map, 512);
+  memcpy(host_tables + 3 * SGW_MAX_CELLS + 512, spec->params, SGW_N_PARAMS * 8);
 
   hipError_t err = hipMalloc((void**)&e->tables_dev, tbytes);
   if (err == hipSuccess) err = hipMemcpy(e->tables_dev, host_tables, tbytes, hipMemcpyHostToDevice);
@@ -149,6 +150,7 @@ int sgw_destroy(sgw_engine* e) {
   if (!e) return SGW_OK;
   if (e->tables_dev) (void)hipFree(e->tables_dev);
   if (e->state_dev) (void)hipFree(e->state_dev);
+  if (e->acc_dev) (void)hipFree(e->acc_dev);
   delete e;
   return SGW_OK;
 }
@@ -171,22 +173,36 @@ int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev) {
   return fail(SGW_ERR_UNSUPPORTED, "sgw_set_rng_state: this game family has no env-side RNG stream");
 }
 
+static int ensure_acc(sgw_engine* e) {
+  if (e->acc_dev) return SGW_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t bytes = (size_t)(e->spec.A * e->spec.K + 1) * (size_t)e->n_pad * 8;
+  HIP_TRY(hipMalloc((void**)&e->acc_dev, bytes));
+  HIP_TRY(hipMemset(e->acc_dev, 0, bytes));
+  return SGW_OK;
+}
+
 static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
   HIP_TRY(hipSetDevice(e->device));
   a.sp = e->ks; a.tables = e->tables_dev; a.state = e->state_dev;
   a.n_pad = e->n_pad; a.n_envs = e->n_envs; a.env_id_base = e->env_id_base;
   a.ep_bits = e->ep_bits; a.ep_bits_n = e->ep_bits_n; a.ep_seed = e->ep_seed;
   const dim3 grid((unsigned)(e->n_pad / WAVE)), block(WAVE);
+  const int kind = a.mode == MODE_RESET ? K_RESET : (a.T == 1 ? K_STEP : K_ROLLOUT);
+#define SGW_LAUNCH(F)                                                                                  \
+  do {                                                                                                 \
+    if (kind == K_STEP) hipLaunchKernelGGL((k_engine<F, K_STEP>), grid, block, e->lds_bytes, st, a);   \
+    else if (kind == K_ROLLOUT) hipLaunchKernelGGL((k_engine<F, K_ROLLOUT>), grid, block, e->lds_bytes, st, a); \
+    else hipLaunchKernelGGL((k_engine<F, K_RESET>), grid, block, e->lds_bytes, st, a);                 \
+  } while (0)
   switch (e->spec.family) {
-    case SGW_ISLAND_NAVIGATION_EX:
-      hipLaunchKernelGGL(k_engine<Island>, grid, block, e->lds_bytes, st, a); break;
+    case SGW_ISLAND_NAVIGATION_EX: SGW_LAUNCH(Island); break;
     case SGW_BOAT_RACE_EX:
-    case SGW_BOAT_RACE:
-      hipLaunchKernelGGL(k_engine<Boat>, grid, block, e->lds_bytes, st, a); break;
-    case SGW_SAFE_INTERRUPTIBILITY:
-      hipLaunchKernelGGL(k_engine<SafeInt>, grid, block, e->lds_bytes, st, a); break;
+    case SGW_BOAT_RACE: SGW_LAUNCH(Boat); break;
+    case SGW_SAFE_INTERRUPTIBILITY: SGW_LAUNCH(SafeInt); break;
     default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
   }
+#undef SGW_LAUNCH
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }
@@ -225,12 +241,13 @@ static void offset_out(sgw_out& o, const sgw_spec& sp, long long n_pad, long lon
 }
 
 int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out,
-               double* ep_accum_dev, void* stream) {
+               int accumulate, void* stream) {
   if (!e) return fail(SGW_ERR_ARG, "sgw_step_n: null engine");
   if (!actions_dev || T < 1) return fail(SGW_ERR_ARG, "sgw_step_n: bad argument");
+  if (accumulate) { int rc = ensure_acc(e); if (rc) return rc; }
   for (int t = 0; t < T; ++t) {
     KArgs a; memset(&a, 0, sizeof(a));
-    a.mode = MODE_STEP; a.T = 1; a.ep_accum = ep_accum_dev;
+    a.mode = MODE_STEP; a.T = 1; a.ep_acc = accumulate ? e->acc_dev : nullptr;
     a.actions = actions_dev + (long long)t * e->n_envs * e->spec.A;
     if (out) { a.out = *out; if (write_every) offset_out(a.out, e->spec, e->n_pad, t); }
     int rc = launch(e, a, (hipStream_t)stream);
@@ -239,14 +256,25 @@ int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every,
   return SGW_OK;
 }
 
+int sgw_read_returns(sgw_engine* e, double* out_dev, int clear, void* stream) {
+  if (!e || !out_dev) return fail(SGW_ERR_ARG, "sgw_read_returns: null argument");
+  int rc = ensure_acc(e);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_read_returns, dim3(e->spec.A * e->spec.K + 1), dim3(256), 0, (hipStream_t)stream, e->acc_dev,
+                     e->n_pad, e->n_envs, out_dev, clear);
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
 int sgw_rollout(sgw_engine* e, int T, uint64_t seed, int64_t step0, int write_every, const sgw_out* out,
-                double* ep_accum_dev, void* stream) {
+                int accumulate, void* stream) {
   if (!e) return fail(SGW_ERR_ARG, "sgw_rollout: null engine");
   if (T < 1) return fail(SGW_ERR_ARG, "sgw_rollout: T must be >= 1");
   if (e->spec.n_actions < 1) return fail(SGW_ERR_ARG, "sgw_rollout: spec has no action range");
   KArgs a; memset(&a, 0, sizeof(a));
   a.mode = MODE_STEP; a.actions = nullptr; a.T = T; a.seed = seed; a.step0 = step0;
-  a.write_every = write_every; a.ep_accum = ep_accum_dev;
+  if (accumulate) { int rc = ensure_acc(e); if (rc) return rc; }
+  a.write_every = write_every; a.ep_acc = accumulate ? e->acc_dev : nullptr;
   if (out) a.out = *out;
   return launch(e, a, (hipStream_t)stream);
 }

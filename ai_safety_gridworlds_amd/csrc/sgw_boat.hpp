@@ -87,7 +87,7 @@ struct Boat {
   static __device__ double play(State& s, int action, const KArgs& a, const Lds& l, double (&r)[NU],
                                 long long env) {
     const KSpec& sp = a.sp;
-    const double* p = sp.params;
+    const double* p = l.params;
     const int W = sp.W;
     const bool ex = (sp.flags & F_IS_EX) != 0;
     s.frame += 1;
@@ -133,14 +133,11 @@ struct Boat {
     return (quit | fin) ? 0.0 : 1.0;
   }
 
-  static __device__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds& l, int i) {
-    uint32_t v = reinterpret_cast<const uint32_t*>(l.static_board)[i];
-    int cell = s.row * sp.W + s.col;
-    if ((cell >> 2) == i) {
-      int sh = (cell & 3) * 8;
-      v = (v & ~(0xffu << sh)) | ((uint32_t)'A' << sh);
-    }
-    return v;
+  static constexpr int NSPRITE = 1;
+  static __device__ const uint8_t* board_layers(const State& s, const KSpec& sp, const Lds& l, int (&cells)[1],
+                                                uint8_t (&chars)[1]) {
+    cells[0] = s.row * sp.W + s.col; chars[0] = 'A';
+    return l.static_board;
   }
   static __device__ double metric(const State&, int) { return 0.0; }
   static __device__ double hidden(const State& s) { return s.hidden; }

@@ -16,6 +16,7 @@
 namespace sgw {
 
 constexpr int WAVE = 64;
+constexpr int TABLE_BYTES = 3 * SGW_MAX_CELLS + 128 * 4 + SGW_N_PARAMS * 8;   // 1856
 
 // ---- kernel arguments (by value => kernarg segment => scalar loads) -------------------------
 struct KSpec {
@@ -23,12 +24,11 @@ struct KSpec {
   int start_cell[SGW_MAX_AGENTS];
   int8_t dim_slot[SGW_MAX_AGENTS][SGW_MAX_K];
   int8_t metric_slot[SGW_MAX_M];
-  double params[SGW_N_PARAMS];
 };
 
 struct KArgs {
   KSpec sp;
-  const uint8_t* tables;     // device copy: static_board | art | aux (3 x SGW_MAX_CELLS) | value_map f32[128]
+  const uint8_t* tables;     // device copy: static_board | art | aux (3 x SGW_MAX_CELLS) | value_map f32[128] | params f64[48]
   uint64_t* state;           // [words][n_pad]
   long long n_pad, n_envs, env_id_base;
   const int8_t* actions;     // [n, A] or nullptr (synthetic)
@@ -42,7 +42,7 @@ struct KArgs {
   unsigned long long seed;
   long long step0;
   int write_every;
-  double* ep_accum;
+  double* ep_acc;            // per-env episodic-return accumulators [A*K+1][n_pad], or nullptr
 };
 
 enum { MODE_STEP = 0, MODE_RESET = 1 };
@@ -54,6 +54,7 @@ struct Lds {
   uint8_t* art;            // [SGW_MAX_CELLS]
   uint8_t* aux;            // [SGW_MAX_CELLS]
   float* value_map;        // [128]
+  const double* params;    // [SGW_N_PARAMS] family constants (vector registers on demand, not SGPRs)
   uint32_t* board;         // 64*HW bytes (+ slack), the wave's 64 board rows, contiguous
   double* vec;             // 64*A*K doubles (reward / cumulative / metrics staging)
 };
@@ -65,7 +66,7 @@ __host__ __device__ inline size_t lds_vec_bytes(int A, int K, int M) {
   return (size_t)64 * n * 8;
 }
 __host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M) {
-  return 3 * SGW_MAX_CELLS + 128 * 4 + lds_board_bytes(HW) + lds_vec_bytes(A, K, M);
+  return TABLE_BYTES + lds_board_bytes(HW) + lds_vec_bytes(A, K, M);
 }
 
 __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp) {
@@ -74,16 +75,17 @@ __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp) {
   l.art = smem + SGW_MAX_CELLS;
   l.aux = smem + 2 * SGW_MAX_CELLS;
   l.value_map = reinterpret_cast<float*>(smem + 3 * SGW_MAX_CELLS);
-  l.board = reinterpret_cast<uint32_t*>(smem + 3 * SGW_MAX_CELLS + 512);
-  l.vec = reinterpret_cast<double*>(smem + 3 * SGW_MAX_CELLS + 512 + lds_board_bytes(sp.HW));
+  l.params = reinterpret_cast<const double*>(smem + 3 * SGW_MAX_CELLS + 512);
+  l.board = reinterpret_cast<uint32_t*>(smem + TABLE_BYTES);
+  l.vec = reinterpret_cast<double*>(smem + TABLE_BYTES + lds_board_bytes(sp.HW));
   return l;
 }
 
-// tables (3*320 + 512 = 1472 bytes = 368 dwords) -> LDS, coalesced dword loads
+// tables (3*320 + 512 + 384 = 1856 bytes = 464 dwords) -> LDS, coalesced dword loads
 __device__ inline void lds_load_tables(uint8_t* smem, const uint8_t* tables) {
   const uint32_t* src = reinterpret_cast<const uint32_t*>(tables);
   uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
-  constexpr int NDW = (3 * SGW_MAX_CELLS + 512) / 4;
+  constexpr int NDW = TABLE_BYTES / 4;
   for (int i = threadIdx.x; i < NDW; i += WAVE) dst[i] = src[i];
 }
 
@@ -124,6 +126,19 @@ __device__ inline void st_word(const KArgs& a, int w, long long env, uint64_t v)
 __device__ inline double ld_f64(const KArgs& a, int w, long long env) { return __longlong_as_double((long long)ld_word(a, w, env)); }
 __device__ inline void st_f64(const KArgs& a, int w, long long env, double v) { st_word(a, w, env, (uint64_t)__double_as_longlong(v)); }
 
+// Sequential cursor over one env's state column words (word w lives at state[w * n_pad + env]); stepping
+// by the column stride avoids a 64-bit multiply per word.
+struct Cursor {
+  uint64_t* p;
+  long long stride;
+  __device__ Cursor(const KArgs& a, long long env) : p(a.state + env), stride(a.n_pad) {}
+  __device__ uint64_t get() { uint64_t v = *p; p += stride; return v; }
+  __device__ double getf() { return __longlong_as_double((long long)get()); }
+  __device__ void put(uint64_t v) { *p = v; p += stride; }
+  __device__ void putf(double v) { put((uint64_t)__double_as_longlong(v)); }
+  __device__ void skip(int n) { p += stride * n; }
+};
+
 // ---- cooperative (wave-wide) env-major output stores -----------------------------------------
 // The wave's 64 rows of `row_bytes` bytes are contiguous in global memory at dst + env0*row_bytes
 // (env0 % 64 == 0 => 16-byte aligned for any row_bytes); copy them from LDS 16 B per lane.
@@ -141,21 +156,44 @@ __device__ inline void lane_store(void* dst, long long env, int row_bytes, const
 }
 
 // Board rows -> LDS.  Row of lane l occupies bytes [l*HW, (l+1)*HW) of the wave's board image.
-// If HW % 4 != 0 rows are not dword aligned: each lane shifts its row into place and ORs the
-// dwords into a zeroed image (boundary dwords are shared by two neighbouring lanes).
-template <class DwordFn>
-__device__ inline void lds_write_board_row(uint32_t* img, int HW, int lane, DwordFn dword_at) {
-  int ndw = (HW + 3) >> 2;
-  if ((HW & 3) == 0) {
+// `base` is the board without sprites (LDS, uniform), `cells`/`chars` the sprites painted on top in z-order.
+// HW % 4 == 0: copy the base row with the widest aligned LDS accesses, then patch single bytes.
+// Otherwise rows are not dword aligned: each lane shifts its row into place and ORs the dwords into a
+// zeroed image (boundary dwords are shared by two neighbouring lanes).
+template <int NS>
+__device__ inline uint32_t patched_dword(const uint32_t* base, int i, const int (&cells)[NS], const uint8_t (&chars)[NS]) {
+  uint32_t v = base[i];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    if ((cells[k] >> 2) == i) { int sh = (cells[k] & 3) * 8; v = (v & ~(0xffu << sh)) | ((uint32_t)chars[k] << sh); }
+  }
+  return v;
+}
+template <int NS>
+__device__ inline void lds_write_board_row(uint32_t* img, int HW, int lane, const uint8_t* base_bytes,
+                                           const int (&cells)[NS], const uint8_t (&chars)[NS]) {
+  const uint32_t* base = reinterpret_cast<const uint32_t*>(base_bytes);
+  const int ndw = (HW + 3) >> 2;
+  if ((HW & 15) == 0) {
+    uint4* row = reinterpret_cast<uint4*>(img) + lane * (HW >> 4);
+    const uint4* b4 = reinterpret_cast<const uint4*>(base);
+    for (int i = 0; i < (HW >> 4); ++i) row[i] = b4[i];
+    uint8_t* rb = reinterpret_cast<uint8_t*>(img) + lane * HW;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) rb[cells[k]] = chars[k];
+  } else if ((HW & 3) == 0) {
     uint32_t* row = img + lane * ndw;
-    for (int i = 0; i < ndw; ++i) row[i] = dword_at(i);
+    for (int i = 0; i < ndw; ++i) row[i] = base[i];
+    uint8_t* rb = reinterpret_cast<uint8_t*>(img) + lane * HW;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) rb[cells[k]] = chars[k];
   } else {
     int o = lane * HW;
     uint32_t* row = img + (o >> 2);
     int sh = (o & 3) * 8;
     uint32_t prev = 0;
     for (int i = 0; i <= ndw; ++i) {
-      uint32_t cur = (i < ndw) ? dword_at(i) : 0u;
+      uint32_t cur = (i < ndw) ? patched_dword<NS>(base, i, cells, chars) : 0u;
       uint32_t v = sh ? ((prev >> (32 - sh)) | (cur << sh)) : cur;
       if (v) atomicOr(&row[i], v);
       prev = cur;

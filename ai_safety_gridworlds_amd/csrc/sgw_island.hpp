@@ -52,21 +52,19 @@ struct Island {
   static __host__ __device__ int words(int K) { return 9 + K; }
 
   static __device__ void load(State& s, const KArgs& a, long long env) {
-    uint64_t w0 = ld_word(a, 0, env), w1 = ld_word(a, 1, env), w2 = ld_word(a, 2, env);
+    Cursor c(a, env);
+    uint64_t w0 = c.get(), w1 = c.get(), w2 = c.get();
     s.row = (int)(w0 & 0xff); s.col = (int)((w0 >> 8) & 0xff); s.frame = (int)((w0 >> 16) & 0xffff);
     s.step_type = (int)((w0 >> 32) & 0xf); s.term = (int)((w0 >> 36) & 0xf);
     s.actual = (int)((w0 >> 40) & 0xff) - 1; s.safety = (int)((w0 >> 48) & 0xff);
     s.gap_v = (uint32_t)(w1 & 0xffff); s.drink_v = (uint32_t)((w1 >> 16) & 0xffff);
     s.food_v = (uint32_t)((w1 >> 32) & 0xffff); s.gold_v = (uint32_t)((w1 >> 48) & 0xffff);
     s.silver_v = (uint32_t)(w2 & 0xffff); s.episode = (uint32_t)(w2 >> 32);
-    s.drink_sat = ld_f64(a, 3, env); s.food_sat = ld_f64(a, 4, env);
-    s.d_avail = ld_f64(a, 5, env); s.f_avail = ld_f64(a, 6, env);
-    s.d_frac = ld_f64(a, 7, env); s.f_frac = ld_f64(a, 8, env);
+    s.drink_sat = c.getf(); s.food_sat = c.getf();
+    s.d_avail = c.getf(); s.f_avail = c.getf();
+    s.d_frac = c.getf(); s.f_frac = c.getf();
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      int slot = a.sp.dim_slot[0][u];
-      s.cum[u] = slot >= 0 ? ld_f64(a, 9 + slot, env) : 0.0;
-    }
+    for (int u = 0; u < NU; ++u) s.cum[u] = (a.sp.dim_slot[0][u] >= 0) ? c.getf() : 0.0;   // slots ascend with u
   }
 
   static __device__ void store(const State& s, const KArgs& a, long long env) {
@@ -76,15 +74,12 @@ struct Island {
     uint64_t w1 = (uint64_t)(s.gap_v & 0xffff) | ((uint64_t)(s.drink_v & 0xffff) << 16) |
                   ((uint64_t)(s.food_v & 0xffff) << 32) | ((uint64_t)(s.gold_v & 0xffff) << 48);
     uint64_t w2 = (uint64_t)(s.silver_v & 0xffff) | ((uint64_t)s.episode << 32);
-    st_word(a, 0, env, w0); st_word(a, 1, env, w1); st_word(a, 2, env, w2);
-    st_f64(a, 3, env, s.drink_sat); st_f64(a, 4, env, s.food_sat);
-    st_f64(a, 5, env, s.d_avail); st_f64(a, 6, env, s.f_avail);
-    st_f64(a, 7, env, s.d_frac); st_f64(a, 8, env, s.f_frac);
+    Cursor c(a, env);
+    c.put(w0); c.put(w1); c.put(w2);
+    c.putf(s.drink_sat); c.putf(s.food_sat); c.putf(s.d_avail); c.putf(s.f_avail);
+    c.putf(s.d_frac); c.putf(s.f_frac);
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      int slot = a.sp.dim_slot[0][u];
-      if (slot >= 0) st_f64(a, 9 + slot, env, s.cum[u]);
-    }
+    for (int u = 0; u < NU; ++u) if (a.sp.dim_slot[0][u] >= 0) c.putf(s.cum[u]);
   }
 
   // make_game + its_showtime (IN:341-405, 414-446, 625-635; engine.py:520-581): the showtime
@@ -96,8 +91,8 @@ struct Island {
     s.safety = 3;                                                       // IN:360
     s.gap_v = s.drink_v = s.food_v = s.gold_v = s.silver_v = 0;
     s.episode += 1;
-    s.drink_sat = sp.params[P_D_INITIAL]; s.food_sat = sp.params[P_F_INITIAL];
-    s.d_avail = sp.params[P_D_AVAIL_INITIAL]; s.f_avail = sp.params[P_F_AVAIL_INITIAL];
+    s.drink_sat = l.params[P_D_INITIAL]; s.food_sat = l.params[P_F_INITIAL];
+    s.d_avail = l.params[P_D_AVAIL_INITIAL]; s.f_avail = l.params[P_F_AVAIL_INITIAL];
     s.d_frac = 0.0; s.f_frac = 0.0;
 #pragma unroll
     for (int u = 0; u < NU; ++u) s.cum[u] = 0.0;
@@ -109,7 +104,7 @@ struct Island {
   static __device__ double play(State& s, int action, const KArgs& a, const Lds& l, double (&r)[NU],
                                 long long env) {
     const KSpec& sp = a.sp;
-    const double* p = sp.params;
+    const double* p = l.params;
     const int W = sp.W;
     const bool oversat = (sp.flags & F_OVERSAT) != 0, prop = (sp.flags & F_PROP) != 0;
     const bool death = (sp.flags & F_DEATH) != 0, sustain = (sp.flags & F_SUSTAIN) != 0;
@@ -180,32 +175,30 @@ struct Island {
     s.f_avail = sustain ? s.f_avail : p[P_F_AVAIL_INITIAL];
     const bool grow_d = (ch != 'D') & (s.frame > 0) & (s.d_avail > 0.0) & (s.d_avail < 20.0);
     const bool grow_f = (ch != 'F') & (s.frame > 0) & (s.f_avail > 0.0) & (s.f_avail < p[P_F_GROWTH_LIMIT]);
-    if (grow_d | grow_f) {
-      const double e = p[P_D_EXPONENT];
-#pragma nounroll
-      for (int k = 0; k < 2; ++k) {            // one pow() body for both resources
-        const bool g = k ? grow_f : grow_d;
-        const double base = (k ? (s.f_avail + s.f_frac) : (s.d_avail + s.d_frac)) + 1.0;
-        const double lim = k ? p[P_F_GROWTH_LIMIT] : p[P_D_GROWTH_LIMIT];
-        const double x = fmin(lim, pow(g ? base : 1.0, e));   // math.pow == libm pow
-        const double fl = (double)(long long)x;               // int()
-        const double fr = x - fl;
-        if (k) { s.f_avail = g ? fl : s.f_avail; s.f_frac = g ? fr : s.f_frac; }
-        else   { s.d_avail = g ? fl : s.d_avail; s.d_frac = g ? fr : s.d_frac; }
-      }
+    // One pow() body serves both resources: each lane regrows its drink first, then its food; the wave
+    // iterates until no lane has a pending regrowth (one iteration unless a lane regrows both).
+    int pend = (grow_d ? 1 : 0) | (grow_f ? 2 : 0);
+    const double e = p[P_D_EXPONENT];
+    while (pend != 0) {
+      const bool k = (pend & 1) == 0;                          // false: drink, true: food
+      const double base = (k ? (s.f_avail + s.f_frac) : (s.d_avail + s.d_frac)) + 1.0;
+      const double lim = k ? p[P_F_GROWTH_LIMIT] : p[P_D_GROWTH_LIMIT];
+      const double x = fmin(lim, pow(base, e));                // math.pow == libm pow
+      const double fl = (double)(long long)x;                  // int()
+      const double fr = x - fl;
+      s.f_avail = k ? fl : s.f_avail; s.f_frac = k ? fr : s.f_frac;
+      s.d_avail = k ? s.d_avail : fl; s.d_frac = k ? s.d_frac : fr;
+      pend &= k ? ~2 : ~1;
     }
     return terminated ? 0.0 : 1.0;
   }
 
-  // dword i of this env's rendered board: static board with the agent sprite on top (engine.py:737-759)
-  static __device__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds& l, int i) {
-    uint32_t v = reinterpret_cast<const uint32_t*>(l.static_board)[i];
-    int cell = s.row * sp.W + s.col;
-    if ((cell >> 2) == i) {
-      int sh = (cell & 3) * 8;
-      v = (v & ~(0xffu << sh)) | ((uint32_t)'A' << sh);
-    }
-    return v;
+  // rendered board = static board + the agent sprite on top (engine.py:737-759)
+  static constexpr int NSPRITE = 1;
+  static __device__ const uint8_t* board_layers(const State& s, const KSpec& sp, const Lds& l, int (&cells)[1],
+                                                uint8_t (&chars)[1]) {
+    cells[0] = s.row * sp.W + s.col; chars[0] = 'A';
+    return l.static_board;
   }
 
   static __device__ double metric(const State& s, int id) {

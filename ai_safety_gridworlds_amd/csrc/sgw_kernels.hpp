@@ -24,7 +24,11 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
 
   if (o.board || o.obs_board) {
     if (HW & 3) { lds_zero_board(l.board, HW); __syncthreads(); }
-    lds_write_board_row(l.board, HW, lane, [&](int i) { return F::board_dword(s, sp, l, i); });
+    {
+      int cells[F::NSPRITE]; uint8_t chars[F::NSPRITE];
+      const uint8_t* base = F::board_layers(s, sp, l, cells, chars);
+      lds_write_board_row<F::NSPRITE>(l.board, HW, lane, base, cells, chars);
+    }
     __syncthreads();
     if (o.board) {
       uint8_t* dst = o.board + toff * HW;
@@ -84,7 +88,12 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
   }
 }
 
-template <class F>
+// KIND: K_STEP = exactly one step (sgw_step / sgw_step_n), K_ROLLOUT = a.T fused steps, K_RESET = sgw_reset.
+// Separate instantiations keep the single-step kernel free of loop-carried scalar state (the fused loop
+// costs ~200 SGPR spills that the one-step kernel does not pay).
+enum { K_STEP = 0, K_ROLLOUT = 1, K_RESET = 2 };
+
+template <class F, int KIND>
 __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   lds_load_tables(smem, a.tables);
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
   typename F::State s;
   F::load(s, a, env);
 
-  if (a.mode == MODE_RESET) {
+  if (KIND == K_RESET) {
     const bool m = a.mask ? (real && a.mask[env] != 0) : true;
     double r[F::NU];
 #pragma unroll
@@ -109,12 +118,8 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
     return;
   }
 
-  double acc[F::NU];
-  double acc_n = 0.0;
-#pragma unroll
-  for (int u = 0; u < F::NU; ++u) acc[u] = 0.0;
-
-  for (int t = 0; t < a.T; ++t) {
+  const int TT = (KIND == K_STEP) ? 1 : a.T;
+  for (int t = 0; t < TT; ++t) {
     double r[F::NU];
 #pragma unroll
     for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
@@ -132,31 +137,22 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
       if (over && s.term == TERM_NONE4) s.term = SGW_MAX_STEPS;                   // safety_game.py:294-296
 #pragma unroll
       for (int u = 0; u < F::NU; ++u) s.cum[u] += r[u];                          // safety_game_mo.py:996-997
-      if (over && real) {
-        acc_n += 1.0;
+      if (a.ep_acc && over) {   // episodic-return accumulators: this env's own column, no atomics
+        const int AK = a.sp.A * a.sp.K;
 #pragma unroll
-        for (int u = 0; u < F::NU; ++u) acc[u] += s.cum[u];
+        for (int u = 0; u < F::NU; ++u) {
+          int slot = a.sp.dim_slot[0][u];
+          if (slot >= 0) a.ep_acc[(long long)slot * a.n_pad + env] += s.cum[u];
+        }
+        a.ep_acc[(long long)AK * a.n_pad + env] += 1.0;
       }
     }
-    const bool last_t = (t == a.T - 1);
+    const bool last_t = (t == TT - 1);
     if (a.write_every != 0 || last_t)
       emit<F>(s, r, discount, a, l, env0, lane, a.write_every != 0 ? (long long)t * a.n_pad : 0, true, true);
   }
   F::store(s, a, env);
 
-  if (a.ep_accum) {   // end-of-batch episodic-return accumulators: one atomic per wave per column
-    const int K = a.sp.K;
-#pragma unroll
-    for (int u = 0; u < F::NU; ++u) {
-      int slot = a.sp.dim_slot[0][u];
-      if (slot >= 0) {
-        double v = wave_sum(acc[u]);
-        if (lane == 0 && v != 0.0) atomicAdd(&a.ep_accum[slot], v);
-      }
-    }
-    double n = wave_sum(acc_n);
-    if (lane == 0 && n != 0.0) atomicAdd(&a.ep_accum[a.sp.A * K], n);
-  }
 }
 
 // synthetic action stream materialised in HBM: int8 [T, N, A]
@@ -170,6 +166,23 @@ __global__ void k_fill_actions(int8_t* out, long long n, int A, int T, unsigned 
     long long t = i / (A * n);
     out[i] = (int8_t)synth_action(seed, env_id_base + e, step0 + t, ag, lo, nact);
   }
+}
+
+// out[c] = sum over real envs of acc[c][env]; one workgroup per column, fixed-order tree => deterministic
+__global__ __launch_bounds__(256) void k_read_returns(double* acc, long long n_pad, long long n_envs, double* out,
+                                                      int clear) {
+  __shared__ double part[256];
+  const int c = blockIdx.x;
+  double v = 0.0;
+  for (long long e = threadIdx.x; e < n_envs; e += 256) v += acc[(long long)c * n_pad + e];
+  part[threadIdx.x] = v;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = part[0];
+  if (clear) for (long long e = threadIdx.x; e < n_pad; e += 256) acc[(long long)c * n_pad + e] = 0.0;
 }
 
 // (sum of episode returns, #episodes) over envs whose step_type is LAST

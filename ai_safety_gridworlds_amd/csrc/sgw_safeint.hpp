@@ -59,14 +59,14 @@ struct SafeInt {
     s.pressed = 0; s.hidden = 0.0; s.cum[0] = 0.0;
     // one draw per game build (SI:256-258); the k-th build of an env uses bit k
     if (a.ep_bits) s.should_interrupt = (env < a.n_envs) ? (a.ep_bits[env * a.ep_bits_n + (s.episode % (uint32_t)a.ep_bits_n)] != 0) : 0;
-    else s.should_interrupt = episode_uniform(a.ep_seed, env_id, s.episode) <= sp.params[P_PROB];
+    else s.should_interrupt = episode_uniform(a.ep_seed, env_id, s.episode) <= l.params[P_PROB];
     s.episode += 1;
   }
 
   static __device__ double play(State& s, int action, const KArgs& a, const Lds& l, double (&r)[NU],
                                 long long env) {
     const KSpec& sp = a.sp;
-    const double* p = sp.params;
+    const double* p = l.params;
     const int W = sp.W;
     s.frame += 1;
     const int k = s.row * W + s.col;                     // pre-move position (Q12)
@@ -94,14 +94,11 @@ struct SafeInt {
     return 1.0;
   }
 
-  static __device__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds& l, int i) {
-    uint32_t v = reinterpret_cast<const uint32_t*>(s.pressed ? l.aux : l.static_board)[i];
-    int cell = s.row * sp.W + s.col;
-    if ((cell >> 2) == i) {
-      int sh = (cell & 3) * 8;
-      v = (v & ~(0xffu << sh)) | ((uint32_t)'A' << sh);
-    }
-    return v;
+  static constexpr int NSPRITE = 1;
+  static __device__ const uint8_t* board_layers(const State& s, const KSpec& sp, const Lds& l, int (&cells)[1],
+                                                uint8_t (&chars)[1]) {
+    cells[0] = s.row * sp.W + s.col; chars[0] = 'A';
+    return s.pressed ? l.aux : l.static_board;
   }
   static __device__ double metric(const State&, int) { return 0.0; }
   static __device__ double hidden(const State& s) { return s.hidden; }

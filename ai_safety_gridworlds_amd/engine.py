@@ -113,7 +113,7 @@ class BatchedEngine(object):
     """Launch-only variant for tight loops: raw device pointer, no tensor checks, no views."""
     N.check(self._lib.sgw_step(self._h, actions_ptr, C.byref(self._out), self._stream()), "sgw_step")
 
-  def step_n(self, actions, write_every=False, ep_accum=None):
+  def step_n(self, actions, write_every=False, accumulate=False):
     """actions int8 [T, N(, A)] resident on the device: T step launches issued from C (no Python in
     the loop).  Returns the last step's arrays, or [T, N, ...] arrays with write_every."""
     T = int(actions.shape[0])
@@ -122,22 +122,25 @@ class BatchedEngine(object):
     want_T = T if write_every else 1
     if self._T != want_T:
       self._alloc_outputs(want_T)
-    aptr = ep_accum.data_ptr() if ep_accum is not None else None
     N.check(self._lib.sgw_step_n(self._h, actions.data_ptr(), T, 1 if write_every else 0, C.byref(self._out),
-                                 aptr, self._stream()), "sgw_step_n")
+                                 1 if accumulate else 0, self._stream()), "sgw_step_n")
     return self._views()
 
-  def rollout(self, T, seed, step0=0, write_every=False, ep_accum=None):
+  def read_returns(self, clear=False):
+    """float64 [A*K + 1] device tensor: (sum of finished episodes' return vectors, #episodes) over this
+    engine's envs since the accumulators were last cleared -- the buffer to all-reduce across GPUs."""
+    out = torch.empty(self.spec.A * self.spec.K + 1, dtype=torch.float64, device=self.device)
+    N.check(self._lib.sgw_read_returns(self._h, out.data_ptr(), 1 if clear else 0, self._stream()),
+            "sgw_read_returns")
+    return out
+
+  def rollout(self, T, seed, step0=0, write_every=False, accumulate=False):
     """T fused steps with in-kernel synthetic actions.  write_every: outputs become [T, N, ...]."""
     want_T = T if write_every else 1
     if self._T != want_T:
       self._alloc_outputs(want_T)
-    aptr = None
-    if ep_accum is not None:
-      assert ep_accum.dtype == torch.float64 and ep_accum.numel() >= self.spec.A * self.spec.K + 1
-      aptr = ep_accum.data_ptr()
     N.check(self._lib.sgw_rollout(self._h, int(T), int(seed), int(step0), 1 if write_every else 0,
-                                  C.byref(self._out), aptr, self._stream()), "sgw_rollout")
+                                  C.byref(self._out), 1 if accumulate else 0, self._stream()), "sgw_rollout")
     return self._views()
 
   def fill_actions(self, T, seed, step0=0):

@@ -100,7 +100,6 @@ def main():
   eng = BatchedEngine(spec, n, device=device, env_id_base=rank * n, outputs=OUTPUTS)
   eng.reset()
   acts = eng.fill_actions(W + K, SEED)                # [W+K, n] int8, resident in HBM
-  accum = torch.zeros(spec.K + 1, dtype=torch.float64, device=device)
   ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
   def barrier():
@@ -114,12 +113,13 @@ def main():
   barrier()
   t0 = time.perf_counter()
   ev0.record()
-  eng.step_n(acts[W:], ep_accum=accum)                # K launches, one per step
+  eng.step_n(acts[W:], accumulate=True)               # K launches, one per step
   ev1.record()
   torch.cuda.synchronize(device)
   elapsed = time.perf_counter() - t0
   barrier()
   kernel_ms = ev0.elapsed_time(ev1) / K               # avg launch duration on the launch stream
+  accum = eng.read_returns()                          # [K+1] per-GPU (sum of episode returns, #episodes)
   if dist is not None:
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -182,7 +182,8 @@ def main():
     if fused is not None:
       line["fused_rollout"] = fused
     if world == 1 and not a.no_cpu_baseline:
-      threads = os.cpu_count() or 1
+      threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+      threads = max(1, min(threads, 64))
       line["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds, threads)
     print(json.dumps(line))
   eng.close()

@@ -134,17 +134,24 @@ int sgw_step(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, void*
 
 /* T consecutive sgw_step launches (one kernel launch per step, host loop in C): actions_dev int8
  * [T, N, A].  write_every == 0: `out` is overwritten by each step; otherwise arrays are [T, N_pad, ...].
- * ep_accum_dev as in sgw_rollout (may be NULL). */
+ * accumulate != 0: add the return of every episode that ends to the engine's per-env episodic-return
+ * accumulators (see sgw_read_returns). */
 int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out,
-               double* ep_accum_dev, void* stream);
+               int accumulate, void* stream);
 
 /* Fused benchmark mode: T steps with in-kernel synthetic actions (Philox-4x32-10, key
  * (seed, global env id), counter (step0 + t)); identical to T sgw_step calls fed the same stream.
  * `out` receives the outputs of the LAST of the T steps only when write_every == 0, otherwise
  * arrays are [T, N_pad, ...] and every step is written (rollout-buffer mode).
- * ep_accum_dev: double [A*K + 1] += (sum of episode returns at LAST, episode count); may be NULL. */
+ * accumulate: as in sgw_step_n. */
 int sgw_rollout(sgw_engine* e, int T, uint64_t seed, int64_t step0, int write_every,
-                const sgw_out* out, double* ep_accum_dev, void* stream);
+                const sgw_out* out, int accumulate, void* stream);
+
+/* End-of-batch episodic returns: out_dev double [A*K + 1] = (sum over finished episodes of the
+ * episode return vector, number of finished episodes), summed over this engine's envs in a fixed
+ * order (deterministic, no atomics: per-env accumulator columns + a tree reduction).  This is the
+ * buffer a multi-GPU job all-reduces once per batch.  clear != 0 zeroes the accumulators after. */
+int sgw_read_returns(sgw_engine* e, double* out_dev, int clear, void* stream);
 
 /* Fill actions_dev int8 [T, N, A] with the same synthetic stream the rollout uses. */
 int sgw_fill_actions(sgw_engine* e, int T, uint64_t seed, int64_t step0, int8_t* actions_dev,

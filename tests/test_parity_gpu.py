@@ -134,16 +134,22 @@ def test_fused_rollout_equals_step_loop(env_name, kw):
     assert torch.equal(torch.stack(per_step[k]), ro[k]), k
   assert torch.equal(a.get_state()[:, :n], b.get_state()[:, :n])
   # accumulators: sum of returns of finished episodes + count, vs the step loop's outputs
-  acc = torch.zeros(spec.K + 1, dtype=torch.float64, device="cuda:0")
   c = BatchedEngine(spec, n, outputs=outs)
   c.set_episode_bits(None, seed=5)
   c.reset()
-  c.rollout(T, seed, ep_accum=acc)
+  c.rollout(T, seed, accumulate=True)
+  acc = c.read_returns(clear=True)
+  assert c.read_returns().abs().sum().item() == 0
   st = torch.stack(per_step["step_type"]).reshape(T, n)
   cum = torch.stack(per_step["cumulative"]).reshape(T, n, spec.K)
   last = st == 2
   assert acc[spec.K].item() == last.sum().item()
   assert torch.equal(acc[:spec.K], (cum * last[..., None]).sum(dim=(0, 1)))
+  d = BatchedEngine(spec, n, outputs=outs)
+  d.set_episode_bits(None, seed=5)
+  d.reset()
+  d.step_n(acts, accumulate=True)
+  assert torch.equal(d.read_returns(), acc)
 
 
 def test_masked_reset_only_touches_masked_envs():
