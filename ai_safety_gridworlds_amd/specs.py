@@ -281,7 +281,8 @@ def _island_spec(kwargs):
                   K=len(dim_names), dim_names=dim_names, M=len(metric_names), metric_names=metric_names, A=1,
                   action_lo=lo, n_actions=n, value_mapping=ISLAND_VALUES, bg_colours=ISLAND_BG,
                   actions=MO_ACTIONS, scalar=False, max_iterations=int(cfg["max_iterations"]), config=cfg,
-                  layer_chars=sorted(set(flat) | {' '}), what_lies_beneath=' ', agent_chars=['A'])
+                  # every drape exists even when its character is absent from the level (island_navigation_ex.py:387-393)
+                  layer_chars=sorted(set(flat) | set(' WDFGSA')), what_lies_beneath=' ', agent_chars=['A'])
 
 
 def _boat_ex_spec(kwargs):

@@ -32,6 +32,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+from ai_safety_gridworlds_amd import parallel                   # noqa: E402
 from ai_safety_gridworlds_amd.engine import BatchedEngine      # noqa: E402
 from ai_safety_gridworlds_amd.specs import make_spec            # noqa: E402
 
@@ -78,20 +79,12 @@ def main():
   ap.add_argument("--no-fused", action="store_true")
   a = ap.parse_args()
 
-  rank = int(os.environ.get("RANK", "0"))
-  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank, local_rank, world = parallel.world()
   if world != a.gpus:
     if world == 1 and a.gpus > 1:
       sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
     a.gpus = world
-  dist = None
-  if world > 1:
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+  dist = parallel.init("nccl") if world > 1 else None
   device = torch.device("cuda", local_rank)
   torch.cuda.set_device(device)
 
@@ -120,11 +113,8 @@ def main():
   barrier()
   kernel_ms = ev0.elapsed_time(ev1) / K               # avg launch duration on the launch stream
   accum = eng.read_returns()                          # [K+1] per-GPU (sum of episode returns, #episodes)
-  if dist is not None:
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = tmax.item()
-    dist.all_reduce(accum, op=dist.ReduceOp.SUM)      # the one collective: episodic returns, end of batch
+  elapsed = parallel.max_over_ranks(elapsed, device, dist)
+  parallel.allreduce_returns(accum, dist)             # the one collective: episodic returns, end of batch
   acc = accum.cpu().numpy()
 
   fused = None
@@ -142,10 +132,7 @@ def main():
     felapsed = time.perf_counter() - f0
     barrier()
     fms = ev0.elapsed_time(ev1)
-    if dist is not None:
-      tmax = torch.tensor([felapsed], dtype=torch.float64, device=device)
-      dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-      felapsed = tmax.item()
+    felapsed = parallel.max_over_ranks(felapsed, device, dist)
     fused = {"value": world * n * Tf / felapsed, "unit": "env-steps/s", "steps_per_launch": Tf,
              "ms_per_step": fms / Tf, "bytes_per_env_step": B_ALG_FUSED,
              "hbm_gbs": n * B_ALG_FUSED / (fms / Tf * 1e-3) / 1e9,

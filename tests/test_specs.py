@@ -1,0 +1,84 @@
+"""CPU tier: host logic (spec tables, Philox, sharding) against the reference-run fixtures."""
+import numpy as np
+import pytest
+
+from ai_safety_gridworlds_amd import philox, parallel
+from ai_safety_gridworlds_amd.specs import make_spec, environment_names
+from tests import golden_util as G
+
+
+def test_philox_known_answers():
+  # Random123 kat_vectors, philox4x32 10 rounds
+  got = philox.philox4x32_10(0, 0, 0, 0, 0, 0)
+  assert [int(x) for x in got] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+  f = 0xffffffff
+  got = philox.philox4x32_10(f, f, f, f, f, f)
+  assert [int(x) for x in got] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+  got = philox.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
+  assert [int(x) for x in got] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_action_stream_is_keyed_by_global_env_id():
+  full = philox.actions(7, np.arange(100), np.arange(9), 0, 5)
+  part = philox.actions(7, np.arange(40, 70), np.arange(9), 0, 5)
+  assert np.array_equal(full[:, 40:70], part)
+  assert full.min() >= 0 and full.max() <= 4 and len(np.unique(full)) == 5
+
+
+@pytest.mark.parametrize("name", G.fixture_names(["island_", "boat_", "safe_int_"]))
+def test_spec_tables_match_reference_fixture(name):
+  fx, meta = G.load(name)
+  spec = make_spec(meta["family_name"], **meta["kwargs"])
+  assert (spec.H, spec.W, spec.K) == (meta["H"], meta["W"], meta["K"])
+  if meta["K"] > 1:
+    assert spec.dim_names == meta["dim_names"]
+  assert spec.metric_names == meta["metric_labels"]
+  assert (spec.action_lo, spec.n_actions) == (meta["action_lo"], meta["n_actions"])
+  board = fx["board"]
+  # value_mapping LUT (observation['board']) and RGB LUT reproduce the reference's distiller output
+  vm = np.array([spec.native.value_map[i] for i in range(128)], np.float32)
+  assert np.array_equal(vm[board], fx["obs_board"])
+  lut = spec.rgb_lut()
+  n = fx["rgb"].shape[0]
+  assert np.array_equal(np.moveaxis(lut[board[:n]], -1, 2), fx["rgb"])
+  # reset board: static board + agent at its start cell
+  sb = np.array(list(spec.native.static_board[:spec.H * spec.W]), np.uint8).reshape(spec.H, spec.W).copy()
+  r, c = divmod(spec.native.start_cell[0], spec.W)
+  sb[r, c] = ord('A')
+  assert np.array_equal(sb, board[0, 0])
+  if "layers" in fx.files:    # occluded layers == (board == char) except the unoccluded extras
+    assert sorted(meta["layer_chars"]) == sorted(spec.layer_chars)
+
+
+def test_island_safety_table_matches_fixture():
+  fx, meta = G.load("island_L9")
+  spec = make_spec("island_navigation_ex", level=9)
+  board, safety, st = fx["board"], fx["safety"], fx["step_type"]
+  aux = np.array(list(spec.native.aux[:48]), np.int32)
+  pos = (board.reshape(board.shape[0], board.shape[1], -1) == ord('A')).argmax(-1)
+  mid = st != 0
+  assert np.array_equal(aux[pos][mid], safety[mid])
+  assert (safety[~mid] == 3).all()
+
+
+def test_spec_errors_mirror_the_reference():
+  with pytest.raises(NotImplementedError):           # factory.py:201-202
+    make_spec("no_such_environment")
+  with pytest.raises(ValueError, match="DRINK_DEFICIENCY_REWARD is not enabled"):   # mo_reward.py:196-198
+    make_spec("island_navigation_ex", level=0)
+  with pytest.raises(TypeError):
+    make_spec("island_navigation_ex", nonsense=1)
+  with pytest.raises(NotImplementedError):
+    make_spec("island_navigation_ex", MOVEMENT_REWARD={"SOME_OTHER_DIM": -1})
+  s = make_spec("island_navigation_ex", movement_reward="{'MOVEMENT_REWARD': -2.5}", GOLD_REWARD={"GOLD_REWARD": 0})
+  assert "GOLD_REWARD" not in s.dim_names and s.K == 9          # zero units drop out (mo_reward.py:131-135)
+  assert s.native.params[0] == -2.5
+  assert set(environment_names()) >= {"island_navigation_ex", "boat_race_ex", "boat_race", "safe_interruptibility"}
+
+
+def test_shard_ranges_partition_the_env_ids():
+  for n, w in [(65536, 8), (262144, 8), (10, 3), (7, 8)]:
+    spans = [parallel.shard_range(n, r, w) for r in range(w)]
+    assert spans[0][0] == 0 and spans[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
