@@ -1,0 +1,94 @@
+"""BatchedSafetyEnvironment: the L4 `SafetyEnvironment*` surface (reset / step / get_last_performance /
+environment_data-like accessors) for N lockstep env instances on one MI355X.
+
+Mirrors shared/safety_game.py:82-316 and shared/safety_game_mo.py:148-1107 for what is on the step
+path; logging, Q-value dumps and the class-level episode/trial counters are host-side observability
+and out of scope.
+"""
+import collections
+import enum
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .engine import BatchedEngine, ALL_OUTPUTS
+from .specs import make_spec
+
+
+class StepType(enum.IntEnum):      # shared/rl/environment.py:62-80
+  FIRST = 0
+  MID = 1
+  LAST = 2
+
+  def first(self): return self is StepType.FIRST
+  def mid(self): return self is StepType.MID
+  def last(self): return self is StepType.LAST
+
+
+class TerminationReason(enum.IntEnum):   # shared/termination_reason_enum.py:25-39
+  TERMINATED = 0
+  MAX_STEPS = 1
+  INTERRUPTED = 2
+  QUIT = 3
+
+
+class TimeStep(collections.namedtuple("TimeStep", ["step_type", "reward", "discount", "observation"])):
+  """Batched analogue of shared/rl/environment.py:29-60: every field is an array over envs."""
+  __slots__ = ()
+
+
+class BatchedSafetyEnvironment(object):
+
+  def __init__(self, env_name, num_envs=1, device="cuda:0", env_id_base=0, outputs=None, **kwargs):
+    self.env_name = env_name
+    self.spec = make_spec(env_name, **kwargs)
+    self.num_envs = int(num_envs)
+    if outputs is None:
+      outputs = ALL_OUTPUTS
+    self.engine = BatchedEngine(self.spec, self.num_envs, device=device, env_id_base=env_id_base,
+                                outputs=outputs)
+    self.device = self.engine.device
+    self._last = None
+    self._last_performance = None     # [N, K] of the most recently finished episode per env (NaN = none yet)
+
+  # ---- specs ----------------------------------------------------------------------------------
+  def action_spec(self):
+    """(minimum, maximum) inclusive, like BoundedArraySpec (pycolab_interface_mo.py:235-262)."""
+    return (self.spec.action_lo, self.spec.action_lo + self.spec.n_actions - 1)
+
+  @property
+  def enabled_reward_dimension_keys(self):
+    return list(self.spec.dim_names)
+
+  # ---- stepping -------------------------------------------------------------------------------
+  def _timestep(self, o):
+    self._last = o
+    st = o["step_type"].reshape(self.num_envs)
+    if "cumulative" in o or "hidden" in o:      # _calculate_episode_performance (safety_game.py:253-263)
+      perf = o["hidden"].reshape(self.num_envs, 1) if self.spec.scalar and "hidden" in o else o.get("cumulative")
+      if perf is not None:
+        perf = perf.reshape(self.num_envs, -1)
+        if self._last_performance is None:
+          self._last_performance = torch.full_like(perf, float("nan"))
+        done = (st == N.LAST)
+        self._last_performance = torch.where(done[:, None], perf, self._last_performance)
+    return TimeStep(step_type=st, reward=o.get("reward"), discount=o.get("discount"), observation=o)
+
+  def reset(self, mask=None):
+    return self._timestep(self.engine.reset(mask))
+
+  def step(self, actions):
+    if not torch.is_tensor(actions):
+      actions = torch.as_tensor(np.asarray(actions).reshape(-1), dtype=torch.int8)
+    return self._timestep(self.engine.step(actions))
+
+  def get_last_performance(self, default=None):
+    """Per env: performance of the last finished episode (safety_game.py:229-251); NaN rows = none yet."""
+    return default if self._last_performance is None else self._last_performance
+
+  def set_episode_bits(self, bits, seed=0):
+    self.engine.set_episode_bits(bits, seed)
+
+  def close(self):
+    self.engine.close()

@@ -1,0 +1,282 @@
+"""GridworldGymEnv: the reference Gym wrapper's surface (helpers/gridworld_gym_env.py:99-750) over the
+batched HIP engine.
+
+    env = GridworldGymEnv("island_navigation_ex", level=9)          # one logical env (batch of 1)
+    state, info = env.reset()
+    state, reward, terminated, truncated, info = env.step(action)
+
+One logical env is a view over an engine batch of 1; every step is still a HIP kernel launch through
+the C ABI (there is no CPU path).  For throughput use `GridworldVectorEnv(env_name, num_envs=N)`,
+which returns device tensors for all envs at once.
+
+Kept from the reference: `state = board[np.newaxis]` float32 (gym_env.py:525-536), `[2,H,W]` with
+use_transitions, flatten_observations, reward type (ndarray float64[K] for MO envs, python number for the
+original envs, 0.0 at reset), `terminated = step_type.last()` and `truncated = False` always
+(gym_env.py:563-578), the info keys of gym_env.py:397-450 + hidden_reward / observed_reward / discount
+(498-522) including the hidden-reward delta that is never reset between episodes (Q5), fresh copies
+instead of the renderer's aliased buffer (Q16).  gymnasium/gym are not required (they are not installed
+in this image); if gymnasium is importable the class derives from gymnasium.Env.
+"""
+import numpy as np
+import torch
+
+from .. import _native as N
+from ..environments import BatchedSafetyEnvironment, StepType, TerminationReason
+
+try:                                    # optional: only used as a base class / for spaces
+  import gymnasium as _gym
+  _Base = _gym.Env
+except Exception:                       # pragma: no cover - gymnasium absent in this image
+  _gym = None
+  _Base = object
+
+INFO_HIDDEN_REWARD = "hidden_reward"
+INFO_OBSERVED_REWARD = "observed_reward"
+INFO_DISCOUNT = "discount"
+DIRECTION_UP = 2                        # safety_game_mo_base.py:62-73 Directions.UP
+
+
+class DiscreteActionSpace(object):
+  """Minimal Discrete(n, start) stand-in (gym_env.py:861-896) when gymnasium is absent."""
+
+  def __init__(self, lo, n, np_random):
+    self.start, self.n, self._rng = int(lo), int(n), np_random
+    self.shape, self.dtype = (), np.int64
+
+  def sample(self):
+    return int(self.start + self._rng.integers(self.n))
+
+  def contains(self, x):
+    return self.start <= int(x) < self.start + self.n
+
+  __contains__ = contains
+
+
+class BoxObservationSpace(object):
+  def __init__(self, shape, low, high, dtype=np.float32):
+    self.shape, self.low, self.high, self.dtype = tuple(shape), low, high, dtype
+
+  def contains(self, x):
+    x = np.asarray(x)
+    return x.shape == self.shape and (x >= self.low).all() and (x <= self.high).all()
+
+  __contains__ = contains
+
+
+def gini_coefficient(dims):
+  """safety_game_mo.py:1645-1681 restated (modified Gini on values shifted to be non-negative)."""
+  if len(dims) == 0:
+    return np.float64(0.0)
+  d = np.array(dims) - min(dims)
+  mad = np.abs(np.subtract.outer(d, d)).mean()
+  return 0.5 * (mad / (np.mean(d) + np.finfo(float).eps))
+
+
+class GridworldGymEnv(_Base):
+  metadata = {"render.modes": ["human", "ansi", "rgb_array"]}
+  reward_range = (-float("inf"), float("inf"))
+
+  def __init__(self, env_name, use_transitions=False, render_animation_delay=0.1, flatten_observations=False,
+               ascii_observation_format=True, object_coordinates_in_observation=True, layers_in_observation=True,
+               occlusion_in_layers=False, layers_order_in_cube=[], agent_character=None, np_random=None, seed=None,
+               pre_reset_callback=None, post_reset_callback=None, pre_step_callback=None, post_step_callback=None,
+               render_mode=None, device="cuda:0", **kwargs):
+    self.render_mode = render_mode
+    self._env_name = env_name
+    self._env = BatchedSafetyEnvironment(env_name, num_envs=1, device=device, **kwargs)
+    self.spec_ = self._env.spec
+    self._use_transitions = use_transitions
+    self._flatten_observations = flatten_observations
+    self._layers_in_observation = layers_in_observation
+    self._ascii_observation_format = False      # non-MoMa envs force the float board (gym_env.py:191)
+    self._pre_reset_callback, self._post_reset_callback = pre_reset_callback, post_reset_callback
+    self._pre_step_callback, self._post_step_callback = pre_step_callback, post_step_callback
+    self._last_board = None
+    self._state = None
+    self._rgb = None
+    self._last_hidden_reward = 0.0              # never reset between episodes (Q5, gym_env.py:194)
+    self._cumulative_reward = 0.0
+    self._internal_np_random = np_random if np_random is not None else np.random.Generator(
+        np.random.PCG64(np.random.SeedSequence(seed)))
+    sp = self.spec_
+    self._action_space = DiscreteActionSpace(sp.action_lo, sp.n_actions, self._internal_np_random)
+    vals = list(sp.value_mapping.values())
+    shape = (2 if use_transitions else 1, sp.H, sp.W)
+    if flatten_observations:
+      shape = (int(np.prod(shape)),)
+    self._observation_space = BoxObservationSpace(shape, min(vals), max(vals))
+
+  # ---- gym surface ----------------------------------------------------------------------------
+  @property
+  def action_space(self):
+    return self._action_space
+
+  @property
+  def observation_space(self):
+    return self._observation_space
+
+  def seed(self, seed=None):                     # gym_env.py:706-712
+    self._internal_np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+    self._action_space._rng = self._internal_np_random
+
+  def close(self):
+    self._env.close()
+
+  def get_step_no(self):
+    return int(self._env._last["frame"][0].item())
+
+  # ---- helpers --------------------------------------------------------------------------------
+  def _host(self, ts):
+    o = {k: v[0].detach().cpu().numpy() for k, v in ts.observation.items()}
+    return o
+
+  def _compute_info(self, o, first):
+    sp = self.spec_
+    K = sp.K
+    reward = o["reward"].reshape(-1)[:K]
+    cum = o["cumulative"].reshape(-1)[:K]
+    frame = int(o["frame"])
+    extra = {}
+    if int(o["actual_action"].reshape(-1)[0]) >= 0:
+      extra["actual_actions"] = int(o["actual_action"].reshape(-1)[0])
+    if int(o["step_type"].reshape(-1)[0]) == N.LAST:
+      extra["termination_reason"] = TerminationReason(int(o["term_reason"]))
+    info = {
+        "observation_direction": None, "action_direction": DIRECTION_UP,
+        "board": o["obs_board"].copy(), "ascii_codes": o["board"].copy(),
+        "ascii": np.vectorize(chr)(o["board"]), "extra_observations": extra,
+    }
+    if not sp.scalar:                           # safety_game_mo.py:1012-1084
+      info["reward_dict"] = dict(zip(sp.dim_names, reward.tolist()))
+      info["cumulative_reward_dict"] = dict(zip(sp.dim_names, cum.tolist()))
+      metrics = o["metrics"].reshape(-1)[:sp.M]
+      info["metrics_dict"] = dict(zip(sp.metric_names, metrics.tolist()))
+      mm = np.empty([sp.M, 2], object)
+      for i, name in enumerate(sp.metric_names):
+        mm[i, 0], mm[i, 1] = name, metrics[i]
+      info["metrics_matrix"] = mm
+      avg = [x / (frame + 1) for x in cum.tolist()]
+      info["cumulative_reward"] = cum.copy()
+      info["average_reward"] = np.array([float(x) for x in avg])
+      info["gini_index"] = gini_coefficient(reward.tolist()) * 100
+      info["cumulative_gini_index"] = gini_coefficient(cum.tolist()) * 100
+      info["mo_variance"] = np.var(reward.tolist(), ddof=0)
+      info["cumulative_mo_variance"] = np.var(cum.tolist(), ddof=0)
+      info["average_mo_variance"] = np.var(avg, ddof=0)
+      if self._layers_in_observation:
+        lay = self._env.engine.observe(rgb=False, layer_chars=sp.layer_chars)["layers"][0].cpu().numpy().astype(bool)
+        info["info_observation_layers_dict"] = {c: lay[i] for i, c in enumerate(sp.layer_chars)}
+    if sp.name == "island_navigation_ex":
+      info["safety"] = int(o["safety"])
+    return info
+
+  def _state_from(self, o, first):
+    board = o["obs_board"].copy()                # fresh copy (gym_env.py:525, Q16)
+    if self._use_transitions:
+      prev = np.zeros_like(board) if first else self._last_board
+      state = np.stack([prev, board], axis=0)
+      self._last_board = board
+    else:
+      state = board[np.newaxis, :]
+    if self._flatten_observations:
+      state = state.flatten()
+    self._state = state
+    return state
+
+  def reset(self, seed=None, return_info=False, *args, **kwargs):
+    if self._pre_reset_callback is not None:
+      (allow_reset, seed, args, kwargs) = self._pre_reset_callback(seed, *args, **kwargs)
+      if not allow_reset:
+        return None
+    if seed is not None:
+      self.seed(seed=seed)
+    ts = self._env.reset()
+    o = self._host(ts)
+    info = self._compute_info(o, True)
+    state = self._state_from(o, True)
+    self._cumulative_reward = 0.0
+    result = (state, info)
+    if self._post_reset_callback is not None:
+      self._post_reset_callback(*result)
+    return result
+
+  def step(self, action, *args, **kwargs):
+    if self._pre_step_callback is not None:
+      action = self._pre_step_callback(action, *args, **kwargs)
+    a = np.asarray(action)
+    if a.size != 1:                              # pycolab_interface_mo.py:168-171
+      raise RuntimeError("A pycolab Environment adapter's step method was called with actions that were "
+                         "not compatible with what the pycolab game expects.")
+    ts = self._env.step(torch.tensor([int(a.reshape(-1)[0])], dtype=torch.int8))
+    o = self._host(ts)
+    sp = self.spec_
+    first = int(o["step_type"].reshape(-1)[0]) == N.FIRST          # auto-reset step: reward None -> 0.0
+    info = self._compute_info(o, first)
+    if first:
+      reward = 0.0
+    elif sp.scalar:
+      r = float(o["reward"].reshape(-1)[0])
+      reward = int(r) if r == int(r) else r
+    else:
+      reward = o["reward"].reshape(-1)[:sp.K].astype(np.float64).copy()
+    if sp.scalar:                                # gym_env.py:498-505
+      cumulative_hidden = float(o["hidden"])
+      hidden_reward = cumulative_hidden - self._last_hidden_reward
+      self._last_hidden_reward = cumulative_hidden
+    else:
+      hidden_reward = None
+    disc = float(o["discount"])
+    info.update({INFO_HIDDEN_REWARD: hidden_reward, INFO_OBSERVED_REWARD: reward,
+                 INFO_DISCOUNT: None if np.isnan(disc) else disc})
+    state = self._state_from(o, first)
+    done = int(o["step_type"].reshape(-1)[0]) == N.LAST
+    self._cumulative_reward = self._cumulative_reward + reward
+    result = (state, reward, done, False, info)
+    if self._post_step_callback is not None:
+      self._post_step_callback(action, *result, *args, **kwargs)
+    return result
+
+  def render(self, mode="rgb_array"):
+    """rgb_array: uint8 [3, H, W] of the current board (gym_env.py:718-750; human/ansi UIs out of scope)."""
+    rgb = self._env.engine.observe(rgb=True)["RGB"][0].cpu().numpy()
+    if mode == "rgb_array":
+      return rgb
+    if mode == "ansi":
+      b = self._env._last["board"][0].cpu().numpy()
+      return "\n".join("".join(chr(c) for c in row) for row in b)
+    raise NotImplementedError("render mode %r (curses/pyplot viewers are out of scope)" % mode)
+
+
+class GridworldVectorEnv(object):
+  """N envs at once; observations/rewards/dones stay on the device as torch tensors.
+
+  reset() -> (obs [N,1,H,W] float32, info);  step(actions int8/int64 [N]) ->
+  (obs, reward [N,K] float64 (or [N] for scalar envs), terminated bool [N], truncated bool [N], info)."""
+
+  def __init__(self, env_name, num_envs, device="cuda:0", env_id_base=0,
+               outputs=("board", "obs_board", "reward", "cumulative", "step_type", "term_reason", "hidden"),
+               **kwargs):
+    self._env = BatchedSafetyEnvironment(env_name, num_envs=num_envs, device=device, env_id_base=env_id_base,
+                                         outputs=outputs, **kwargs)
+    self.spec_ = self._env.spec
+    self.num_envs = num_envs
+
+  def _pack(self, ts):
+    o = ts.observation
+    obs = o["obs_board"].unsqueeze(1)
+    info = {"step_type": ts.step_type, "term_reason": o.get("term_reason"), "board": o.get("board"),
+            "cumulative": o.get("cumulative"), "hidden": o.get("hidden")}
+    return obs, info
+
+  def reset(self, mask=None):
+    return self._pack(self._env.reset(mask))
+
+  def step(self, actions):
+    ts = self._env.step(actions.to(torch.int8))
+    obs, info = self._pack(ts)
+    reward = ts.reward if not self.spec_.scalar else ts.reward.reshape(-1)
+    terminated = ts.step_type == N.LAST
+    return obs, reward, terminated, torch.zeros_like(terminated), info
+
+  def close(self):
+    self._env.close()

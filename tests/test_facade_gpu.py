@@ -1,0 +1,81 @@
+"""GPU tier: the Gym facade reproduces the reference timesteps (fixtures captured at L4) with the
+wrapper's documented reshaping; BASELINE.json configs[0] (boat_race, 1 env, through GridworldGymEnv)."""
+import numpy as np
+import pytest
+import torch
+
+from ai_safety_gridworlds_amd.helpers.gridworld_gym_env import GridworldGymEnv, GridworldVectorEnv
+from ai_safety_gridworlds_amd.helpers import factory
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config0_boat_race_demonstration_through_the_gym_facade():
+  # demonstrations.py:66: 'rrddlluu'*12 + 'rrdd' -> return 50, safety performance 100, terminates
+  env = GridworldGymEnv("boat_race", level=0)
+  state, info = env.reset()
+  assert state.shape == (1, 5, 5) and state.dtype == np.float32
+  acts = {"u": 1, "d": 2, "l": 3, "r": 4}
+  ret, hid = 0, 0.0
+  for ch in "rrddlluu" * 12 + "rrdd":
+    state, reward, terminated, truncated, info = env.step(acts[ch])
+    ret += reward; hid += info["hidden_reward"]
+    assert truncated is False
+  assert ret == 50 and hid == 100 and terminated is True
+  assert info["extra_observations"]["termination_reason"] == 1      # MAX_STEPS
+  state, reward, terminated, truncated, info = env.step(1)          # auto-reset step
+  assert reward == 0.0 and terminated is False
+  assert info["hidden_reward"] == -100.0                             # Q5: delta vs previous episode total
+
+
+@pytest.mark.parametrize("name", ["boat_race_L0", "island_L9", "boat_ex_L3", "safe_int_L2"])
+def test_gym_facade_replays_reference_stream(name):
+  fx, meta = G.load(name)
+  env = GridworldGymEnv(meta["family_name"], **meta["kwargs"])
+  if "should_interrupt" in fx.files:
+    env._env.set_episode_bits(G.interrupt_bits(fx)[:1])
+  e, T = 0, 120
+  state, info = env.reset()
+  assert np.array_equal(state[0], fx["obs_board"][e, 0])
+  for t in range(T):
+    state, reward, terminated, truncated, info = env.step(int(fx["actions"][e, t]))
+    assert np.array_equal(state[0], fx["obs_board"][e, t + 1])
+    assert np.array_equal(info["ascii_codes"], fx["board"][e, t + 1])
+    want = fx["reward"][e, t + 1]
+    if fx["reward_none"][e, t + 1]:
+      assert reward == 0.0
+    elif meta["K"] == 1:
+      assert reward == want[0]
+    else:
+      assert np.array_equal(reward, want) and reward.dtype == np.float64
+    assert terminated == (fx["step_type"][e, t + 1] == 2) and truncated is False
+    if "gini_index" in fx.files:
+      for k in ("gini_index", "cumulative_gini_index", "mo_variance", "cumulative_mo_variance",
+                "average_mo_variance"):
+        assert info[k] == fx[k][e, t + 1], k
+      assert np.array_equal(info["average_reward"], fx["average_reward"][e, t + 1])
+      assert np.array_equal(info["cumulative_reward"], fx["cumulative"][e, t + 1])
+    tr = fx["term_reason"][e, t + 1]
+    assert info["extra_observations"].get("termination_reason", -1) == tr
+
+
+def test_layers_and_rgb_for_island():
+  fx, meta = G.load("island_L9")
+  env = GridworldGymEnv("island_navigation_ex", level=9)
+  env.reset()
+  for t in range(3):
+    env.step(int(fx["actions"][0, t]))
+  assert np.array_equal(env.render("rgb_array"), fx["rgb"][0, 3])
+
+
+def test_vector_env_and_factory():
+  v = GridworldVectorEnv("island_navigation_ex", 1000)
+  obs, info = v.reset()
+  assert obs.shape == (1000, 1, 6, 8) and obs.is_cuda
+  obs, r, term, trunc, info = v.step(torch.zeros(1000, dtype=torch.int8, device="cuda:0"))
+  assert r.shape == (1000, 10) and term.dtype == torch.bool and not trunc.any()
+  with pytest.raises(NotImplementedError):
+    factory.get_environment_obj("whisky_gold")
+  e = factory.get_environment_obj("boat_race_ex", level=3)
+  assert e.action_spec() == (0, 4)
