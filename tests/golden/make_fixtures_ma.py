@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Golden fixtures for firemaker_ex_ma, produced by RUNNING the reference (build container only).
+
+    python tests/golden/make_fixtures_ma.py
+
+Same rules as make_fixtures.py (data only, test-only stand-ins for absl / gymnasium seeding).
+Additionally this env needs the two patches SURVEY.md §8c documents, because at this snapshot the
+reference cannot construct it:
+  (1) SafetyEnvironmentMoMa.reset leaves `_last_reward` None and FireDrape adds a (zero) reward during
+      its_showtime -> `None + ma_reward` raises.  Patch: treat None as the default reward in
+      EnvironmentMa._update_for_game_step (what EnvironmentMa.reset itself does, pycolab_interface_ma.py:164).
+  (2) FireDrape calls NP_RANDOM.rand() (legacy-gym RandomNumberGenerator); the stand-in Generator
+      subclass provides rand == random.
+amount_agents=3 (workers '1','2' + supervisor 'S') is the reference's maximum (firemaker_ex_ma.py:113-118).
+Each stream: a fresh env seeded `seed`, reset, T rounds of {agent: {"step": a}} actions (Philox, per agent).
+"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+SEED = 0x5AFE
+
+CONFIGS = {
+    # name: (kwargs, E, T)
+    "firemaker_L0": (dict(amount_agents=3), 24, 160),
+    "firemaker_L0_maxit60": (dict(amount_agents=3, max_iterations=60), 16, 120),
+    "firemaker_L0_hot": (dict(amount_agents=3, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.05, max_iterations=240), 12, 200),
+    # randomize_agent_actions_order=False cannot be configured through the reference constructor: it passes the
+    # flag explicitly AND leaves it in **kwargs (firemaker_ex_ma.py:816-847) -> TypeError "multiple values".
+}
+
+
+def main():
+  sys.dont_write_bytecode = True
+  sys.path.insert(0, "/root/reference")
+  sys.path.insert(0, os.path.join(HERE, "standins"))
+  sys.path.insert(0, REPO)
+  import numpy as np
+  from ai_safety_gridworlds_amd import philox
+  from ai_safety_gridworlds.environments.shared.rl import pycolab_interface_ma
+  from ai_safety_gridworlds.environments.shared import safety_game_moma
+
+  _orig = pycolab_interface_ma.EnvironmentMa._update_for_game_step
+  def _patched(self, observations, reward, discount):      # documented patch (1)
+    if self._last_reward is None:
+      self._last_reward = self._default_reward
+    return _orig(self, observations, reward, discount)
+  pycolab_interface_ma.EnvironmentMa._update_for_game_step = _patched
+  from ai_safety_gridworlds.environments import firemaker_ex_ma as m
+
+  only = sys.argv[1:] or list(CONFIGS)
+  for name in only:
+    kw, E, T = CONFIGS[name]
+    A, K, S = 3, 3, T + 1
+    agents = ['1', '2', 'S']
+    acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(A)], axis=-1)  # [T,E,A]
+    rec = dict(
+        actions=np.transpose(acts, (1, 0, 2)).copy(),          # [E, T, A]
+        seeds=np.zeros(E, np.int64), rng_init=np.zeros((E, 4), np.uint64),
+        step_type=np.zeros((E, S, A), np.uint8), reward=np.zeros((E, S, A, K)), reward_none=np.zeros((E, S), bool),
+        cumulative=np.zeros((E, S, A, K)), discount=np.full((E, S), np.nan), term_reason=np.full((E, S, A), -1, np.int8),
+        frame=np.zeros((E, S), np.int32), board=np.zeros((E, S, 17, 17), np.uint8), metrics=np.zeros((E, S, 16)),
+        pos=np.zeros((E, S, A, 2), np.int32), rng=np.zeros((E, S, 4), np.uint64), rng_has_uint32=np.zeros((E, S), np.uint8),
+        rng_uinteger=np.zeros((E, S), np.uint32), view_worker=np.zeros((E, S, 2, 5, 5), np.uint8),
+        view_supervisor=np.zeros((E, S, 33, 33), np.uint8), obs_board=np.zeros((E, S, 17, 17), np.float32))
+    t0 = time.time()
+    labels = None
+    for e in range(E):
+      seed = 1000 + e
+      env = m.FiremakerExMa(seed=seed, **kw)
+      rng = env.environment_data['np_random']
+      st = rng.bit_generator.state
+      assert st['has_uint32'] == 0
+      rec["seeds"][e] = seed
+      rec["rng_init"][e] = [st['state']['state'] >> 64, st['state']['state'] & (2**64 - 1),
+                            st['state']['inc'] >> 64, st['state']['inc'] & (2**64 - 1)]
+
+      def record(t, ts):
+        rng = env.environment_data['np_random']
+        st = rng.bit_generator.state
+        rec["rng"][e, t] = [st['state']['state'] >> 64, st['state']['state'] & (2**64 - 1),
+                            st['state']['inc'] >> 64, st['state']['inc'] & (2**64 - 1)]
+        rec["rng_has_uint32"][e, t] = st['has_uint32']; rec["rng_uinteger"][e, t] = st['uinteger']
+        for ai, ch in enumerate(agents):
+          rec["step_type"][e, t, ai] = int(ts.step_type[ch])
+          if ts.reward is not None and ts.reward.get(ch) is not None:
+            r = np.asarray(ts.reward[ch], dtype=np.float64)
+            rec["reward"][e, t, ai, :len(r)] = r
+          c = np.asarray(ts.observation["cumulative_reward"][ch], dtype=np.float64)
+          rec["cumulative"][e, t, ai, :len(c)] = c
+          sp = env.environment_data['agent_sprite'][ch]
+          rec["pos"][e, t, ai] = [sp.position.row, sp.position.col]
+          tr = ts.observation["extra_observations"].get("termination_reason")
+          if tr is not None:
+            v = tr[ch]
+            v = v[ch] if isinstance(v, dict) else v        # the reference nests the whole dict per agent
+            rec["term_reason"][e, t, ai] = int(v)
+        rec["reward_none"][e, t] = ts.reward is None
+        if ts.discount is not None:
+          rec["discount"][e, t] = ts.discount
+        rec["frame"][e, t] = env.current_game.the_plot.frame
+        rec["board"][e, t] = env.current_game._board.board
+        rec["obs_board"][e, t] = ts.observation["board"]
+        md = ts.observation["metrics_dict"]
+        rec["metrics"][e, t] = [float(md[k]) for k in labels]
+        board = env.current_game._board.board
+        for ai, ch in enumerate(agents):
+          sp = env.environment_data['agent_sprite'][ch]
+          view = safety_game_moma.get_agent_perspective(sp, board, ord('#'))
+          if ai < 2:
+            rec["view_worker"][e, t, ai] = view
+          else:
+            rec["view_supervisor"][e, t] = view
+
+      ts = env.reset()
+      if labels is None:
+        labels = list(env.environment_data["metrics_labels"])
+      record(0, ts)
+      for t in range(T):
+        a = acts[t, e]
+        ts = env.step({'1': {'step': int(a[0])}, '2': {'step': int(a[1])}, 'S': {'step': int(a[2])}})
+        record(t + 1, ts)
+    dt = time.time() - t0
+    meta = dict(name=name, family="firemaker_ex_ma", kwargs=repr(sorted(kw.items())), E=E, T=T, seed=SEED,
+                metric_labels="|".join(labels), reference_rounds_per_s=E * T / dt)
+    rec.update({"meta_" + k: np.array(v) for k, v in meta.items()})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print("%-24s E=%d T=%d  %.0f ref rounds/s  fires(max cells)=%d  episodes=%d" % (
+        name, E, T, E * T / dt, int((rec["board"] == ord('F')).sum(axis=(2, 3)).max()),
+        int((rec["step_type"][:, :, 0] == 2).sum())))
+
+
+if __name__ == "__main__":
+  main()

@@ -23,8 +23,8 @@ def load(name):
   meta = {k[5:]: fx[k].item() for k in fx.files if k.startswith("meta_")}
   meta["family_name"] = FAMILY_NAMES.get(meta["family"], meta["family"])
   meta["kwargs"] = dict(ast.literal_eval(meta["kwargs"]))
-  meta["dim_names"] = [s for s in meta["dim_names"].split("|") if s]
-  meta["metric_labels"] = [s for s in meta["metric_labels"].split("|") if s]
+  meta["dim_names"] = [s for s in meta.get("dim_names", "").split("|") if s]
+  meta["metric_labels"] = [s for s in meta.get("metric_labels", "").split("|") if s]
   return fx, meta
 
 
