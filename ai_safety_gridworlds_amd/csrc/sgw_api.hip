@@ -9,6 +9,7 @@
 
 #include "../../include/sgw.h"
 #include "sgw_boat.hpp"
+#include "sgw_firemaker.hpp"
 #include "sgw_island.hpp"
 #include "sgw_kernels.hpp"
 #include "sgw_safeint.hpp"
@@ -42,6 +43,7 @@ struct sgw_engine {
   unsigned long long ep_seed;
   size_t lds_bytes;
   double* acc_dev;         // [A*K+1][n_pad] episodic-return accumulators (lazily allocated)
+  int rng_set;
 };
 
 static int family_words(const sgw_spec& sp) {
@@ -50,6 +52,7 @@ static int family_words(const sgw_spec& sp) {
     case SGW_BOAT_RACE_EX:
     case SGW_BOAT_RACE: return Boat::words(sp.K, sp.H * sp.W);
     case SGW_SAFE_INTERRUPTIBILITY: return SafeInt::words();
+    case SGW_FIREMAKER_EX_MA: return Firemaker::words();
     default: return -1;
   }
 }
@@ -93,7 +96,7 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   e->n_envs = n_envs;
   e->n_pad = (n_envs + SGW_ENV_ALIGN - 1) / SGW_ENV_ALIGN * SGW_ENV_ALIGN;
   e->env_id_base = env_id_base;
-  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0; e->acc_dev = nullptr;
+  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0; e->acc_dev = nullptr; e->rng_set = 0;
 
   KSpec& k = e->ks;
   memset(&k, 0, sizeof(k));
@@ -168,9 +171,16 @@ int sgw_set_episode_bits(sgw_engine* e, const uint8_t* bits_dev, int n_per_env, 
 }
 
 int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev) {
-  (void)pcg_state_dev;
-  if (!e) return fail(SGW_ERR_ARG, "sgw_set_rng_state: null engine");
-  return fail(SGW_ERR_UNSUPPORTED, "sgw_set_rng_state: this game family has no env-side RNG stream");
+  if (!e || !pcg_state_dev) return fail(SGW_ERR_ARG, "sgw_set_rng_state: null argument");
+  if (e->spec.family != SGW_FIREMAKER_EX_MA)
+    return fail(SGW_ERR_UNSUPPORTED, "sgw_set_rng_state: this game family has no env-side RNG stream");
+  HIP_TRY(hipSetDevice(e->device));
+  hipLaunchKernelGGL(k_set_rng, dim3((unsigned)((e->n_envs + 255) / 256)), dim3(256), 0, 0, e->state_dev, e->n_pad,
+                     e->n_envs, pcg_state_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(0));
+  e->rng_set = 1;
+  return SGW_OK;
 }
 
 static int ensure_acc(sgw_engine* e) {
@@ -183,6 +193,8 @@ static int ensure_acc(sgw_engine* e) {
 }
 
 static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
+  if (e->spec.family == SGW_FIREMAKER_EX_MA && !e->rng_set)
+    return fail(SGW_ERR_ARG, "firemaker_ex_ma: call sgw_set_rng_state first (the env draws from a per-env numpy PCG64 stream)");
   HIP_TRY(hipSetDevice(e->device));
   a.sp = e->ks; a.tables = e->tables_dev; a.state = e->state_dev;
   a.n_pad = e->n_pad; a.n_envs = e->n_envs; a.env_id_base = e->env_id_base;
@@ -200,6 +212,7 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
     case SGW_BOAT_RACE_EX:
     case SGW_BOAT_RACE: SGW_LAUNCH(Boat); break;
     case SGW_SAFE_INTERRUPTIBILITY: SGW_LAUNCH(SafeInt); break;
+    case SGW_FIREMAKER_EX_MA: SGW_LAUNCH(Firemaker); break;
     default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
   }
 #undef SGW_LAUNCH
@@ -312,6 +325,38 @@ int sgw_observe(sgw_engine* e, const uint8_t* board_dev, const uint8_t* rgb_lut_
   int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(k_observe, dim3(blocks), dim3(256), 0, (hipStream_t)stream, board_dev, e->n_envs, e->ks.HW,
                      rgb_lut_dev, rgb_dev, layer_chars_dev, n_layers, layers_dev);
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
+static ViewSpec make_viewspec(const sgw_engine* e) {
+  ViewSpec v; memset(&v, 0, sizeof(v));
+  v.A = e->spec.A; v.H = e->spec.H; v.W = e->spec.W;
+  int off = 0;
+  for (int a = 0; a < e->spec.A; ++a) {
+    const int32_t* rad = e->spec.view_radius[a];
+    if (rad[0] < 0) { v.off[a] = off; continue; }
+    v.off[a] = off; v.up[a] = rad[0]; v.left[a] = rad[2];
+    v.vh[a] = rad[0] + rad[1] + 1; v.vw[a] = rad[2] + rad[3] + 1;
+    off += v.vh[a] * v.vw[a];
+  }
+  v.total = off;
+  return v;
+}
+
+int sgw_view_bytes(const sgw_engine* e) { return e ? make_viewspec(e).total : 0; }
+
+int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agent_pos_dev, uint8_t outside_chr,
+                    uint8_t* views_dev, void* stream) {
+  if (!e || !board_dev || !agent_pos_dev || !views_dev) return fail(SGW_ERR_ARG, "sgw_agent_views: null argument");
+  ViewSpec v = make_viewspec(e);
+  if (v.total <= 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_agent_views: the spec defines no agent views");
+  for (int a = 0; a < v.A; ++a) if (v.vw[a] <= 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_agent_views: every agent needs a view");
+  HIP_TRY(hipSetDevice(e->device));
+  long long total = e->n_envs * v.total;
+  int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(k_agent_views, dim3(blocks), dim3(256), 0, (hipStream_t)stream, board_dev, agent_pos_dev,
+                     e->n_envs, v, outside_chr, views_dev);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }

@@ -200,6 +200,26 @@ __device__ inline void lds_write_board_row(uint32_t* img, int HW, int lane, cons
     }
   }
 }
+// Boards with per-cell dynamic content (fire): the family supplies each dword of its row.
+template <class DwordFn>
+__device__ inline void lds_write_board_row_fn(uint32_t* img, int HW, int lane, DwordFn dword_at) {
+  const int ndw = (HW + 3) >> 2;
+  if ((HW & 3) == 0) {
+    uint32_t* row = img + lane * ndw;
+    for (int i = 0; i < ndw; ++i) row[i] = dword_at(i);
+  } else {
+    int o = lane * HW;
+    uint32_t* row = img + (o >> 2);
+    int sh = (o & 3) * 8;
+    uint32_t prev = 0;
+    for (int i = 0; i <= ndw; ++i) {
+      uint32_t cur = (i < ndw) ? dword_at(i) : 0u;
+      uint32_t v = sh ? ((prev >> (32 - sh)) | (cur << sh)) : cur;
+      if (v) atomicOr(&row[i], v);
+      prev = cur;
+    }
+  }
+}
 __device__ inline void lds_zero_board(uint32_t* img, int HW) {
   int n = (int)(lds_board_bytes(HW) / 4);
   for (int i = threadIdx.x; i < n; i += WAVE) img[i] = 0u;

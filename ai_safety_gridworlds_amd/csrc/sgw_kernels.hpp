@@ -19,12 +19,14 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
                             bool coop, bool lane_active) {
   const sgw_out& o = a.out;
   const KSpec& sp = a.sp;
-  const int HW = sp.HW, K = sp.K;
+  const int HW = sp.HW, K = sp.A * sp.K;   // reward rows hold all agents' vectors: [A][K]
   const long long env = env0 + lane;
 
   if (o.board || o.obs_board) {
     if (HW & 3) { lds_zero_board(l.board, HW); __syncthreads(); }
-    {
+    if constexpr (F::CUSTOM_BOARD) {
+      lds_write_board_row_fn(l.board, HW, lane, [&](int i) { return F::board_dword(s, sp, l, i); });
+    } else {
       int cells[F::NSPRITE]; uint8_t chars[F::NSPRITE];
       const uint8_t* base = F::board_layers(s, sp, l, cells, chars);
       lds_write_board_row<F::NSPRITE>(l.board, HW, lane, base, cells, chars);
@@ -78,9 +80,22 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
   }
   if (coop || lane_active) {
     const long long row = toff + env;
-    if (o.step_type) o.step_type[row] = (uint8_t)s.step_type;
+    if (o.step_type) {
+#pragma unroll
+      for (int ag = 0; ag < F::NA; ++ag) o.step_type[row * F::NA + ag] = (uint8_t)s.step_type;
+    }
     if (o.term_reason) o.term_reason[row] = (s.step_type == ST_LAST) ? (uint8_t)s.term : (uint8_t)SGW_TERM_NONE;
-    if (o.actual_action) o.actual_action[row] = (int8_t)s.actual;
+    if (o.actual_action) {
+#pragma unroll
+      for (int ag = 0; ag < F::NA; ++ag) o.actual_action[row * F::NA + ag] = (int8_t)F::actual(s, ag);
+    }
+    if (o.agent_pos) {
+#pragma unroll
+      for (int ag = 0; ag < F::NA; ++ag) {
+        int pr, pc; F::agent_pos(s, ag, pr, pc);
+        o.agent_pos[(row * F::NA + ag) * 2] = (uint8_t)pr; o.agent_pos[(row * F::NA + ag) * 2 + 1] = (uint8_t)pc;
+      }
+    }
     if (o.discount) o.discount[row] = discount;
     if (o.hidden) o.hidden[row] = F::hidden(s);
     if (o.safety) o.safety[row] = F::safety(s);
@@ -126,11 +141,15 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
     double discount = __longlong_as_double(0x7ff8000000000000LL);   // None at FIRST
     if (s.step_type >= ST_LAST) {
       // step after LAST (or before any reset): new episode, action discarded (pycolab_interface_mo.py:175-178)
+      F::pre_autoreset(s, a);
       F::begin_episode(s, a, l, env, env_id);
     } else {
-      int action;
-      if (a.actions) action = real ? (int)a.actions[(long long)t * a.n_envs + env] : 0;
-      else action = synth_action(a.seed, env_id, a.step0 + t, 0, a.sp.action_lo, a.sp.n_actions);
+      int action[F::NA];
+#pragma unroll
+      for (int ag = 0; ag < F::NA; ++ag) {
+        if (a.actions) action[ag] = real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0;
+        else action[ag] = synth_action(a.seed, env_id, a.step0 + t, ag, a.sp.action_lo, a.sp.n_actions);
+      }
       discount = F::play(s, action, a, l, r, env);
       const bool over = (discount == 0.0) || (s.frame >= a.sp.max_iterations);   // pycolab_interface.py:292-303
       s.step_type = over ? ST_LAST : ST_MID;
@@ -196,6 +215,33 @@ __global__ void k_accumulate_returns(const double* cumulative, const uint8_t* st
   }
   double c = wave_sum(last ? 1.0 : 0.0);
   if ((threadIdx.x & (WAVE - 1)) == 0 && c != 0.0) atomicAdd(&accum[AK], c);
+}
+
+// numpy PCG64 streams into the firemaker state (words 3..6), buffered-uint32 flag (word 0 bit 27) cleared
+__global__ void k_set_rng(uint64_t* state, long long n_pad, long long n, const uint64_t* pcg) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  for (int k = 0; k < 4; ++k) state[(3 + k) * n_pad + e] = pcg[e * 4 + k];
+  state[0 * n_pad + e] &= ~(1ull << 27);
+  state[2 * n_pad + e] &= ~0xffffffffull;
+}
+
+// agent-centric windows of the rendered board (safety_game_moma.py:1996-2101), one thread per output byte
+struct ViewSpec { int A, H, W, total; int off[SGW_MAX_AGENTS], up[SGW_MAX_AGENTS], left[SGW_MAX_AGENTS], vh[SGW_MAX_AGENTS], vw[SGW_MAX_AGENTS]; };
+__global__ void k_agent_views(const uint8_t* board, const uint8_t* pos, long long n, ViewSpec v, uint8_t outside,
+                              uint8_t* views) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = n * v.total;
+  for (; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i / v.total;
+    int b = (int)(i % v.total), ag = 0;
+#pragma unroll
+    for (int k = 1; k < SGW_MAX_AGENTS; ++k) if (k < v.A && b >= v.off[k]) ag = k;
+    b -= v.off[ag];
+    const int vr = b / v.vw[ag], vc = b % v.vw[ag];
+    const int r = (int)pos[(e * v.A + ag) * 2] - v.up[ag] + vr, c = (int)pos[(e * v.A + ag) * 2 + 1] - v.left[ag] + vc;
+    views[i] = (r < 0 || r >= v.H || c < 0 || c >= v.W) ? outside : board[e * (v.H * v.W) + r * v.W + c];
+  }
 }
 
 // observation distiller extras from an ascii board: RGB planes and occluded per-char layers

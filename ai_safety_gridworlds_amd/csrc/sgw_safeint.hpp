@@ -63,8 +63,9 @@ struct SafeInt {
     s.episode += 1;
   }
 
-  static __device__ double play(State& s, int action, const KArgs& a, const Lds& l, double (&r)[NU],
+  static __device__ double play(State& s, const int (&actions)[1], const KArgs& a, const Lds& l, double (&r)[NU],
                                 long long env) {
+    const int action = actions[0];
     const KSpec& sp = a.sp;
     const double* p = l.params;
     const int W = sp.W;
@@ -95,6 +96,12 @@ struct SafeInt {
   }
 
   static constexpr int NSPRITE = 1;
+  static constexpr int NA = 1;
+  static constexpr bool CUSTOM_BOARD = false;
+  static __device__ void pre_autoreset(State&, const KArgs&) {}
+  static __device__ uint32_t board_dword(const State&, const KSpec&, const Lds&, int) { return 0; }
+  static __device__ int actual(const State& s, int) { return s.actual; }
+  static __device__ void agent_pos(const State& s, int, int& r, int& c) { r = s.row; c = s.col; }
   static __device__ const uint8_t* board_layers(const State& s, const KSpec& sp, const Lds& l, int (&cells)[1],
                                                 uint8_t (&chars)[1]) {
     cells[0] = s.row * sp.W + s.col; chars[0] = 'A';

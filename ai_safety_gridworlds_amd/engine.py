@@ -27,7 +27,7 @@ def _dtype_shape(spec, name):
       "step_type": (torch.uint8, (A,)), "term_reason": (torch.uint8, ()),
       "actual_action": (torch.int8, (A,)), "discount": (torch.float64, ()),
       "hidden": (torch.float64, ()), "safety": (torch.int32, ()),
-      "metrics": (torch.float64, (M,)), "frame": (torch.int32, ()),
+      "metrics": (torch.float64, (M,)), "frame": (torch.int32, ()), "agent_pos": (torch.uint8, (A * 2,)),
   }[name]
 
 
@@ -77,6 +77,8 @@ class BatchedEngine(object):
         v = v.reshape(v.shape[:-1] + (self.spec.H, self.spec.W))
       elif name in ("reward", "cumulative") and self.spec.A > 1:
         v = v.reshape(v.shape[:-1] + (self.spec.A, self.spec.K))
+      elif name == "agent_pos":
+        v = v.reshape(v.shape[:-1] + (self.spec.A, 2))
       out[name] = v
     return out
 
@@ -170,6 +172,37 @@ class BatchedEngine(object):
     self._keep.append(bits)
     N.check(self._lib.sgw_set_episode_bits(self._h, bits.data_ptr(), bits.shape[1], int(seed)),
             "sgw_set_episode_bits")
+
+  def set_rng_seeds(self, seeds):
+    """firemaker_ex_ma: per-env numpy streams Generator(PCG64(SeedSequence(seed))) -- what
+    gymnasium.utils.seeding.np_random(seed) builds (safety_game_mo.py:283-291).  seeds: int array [N]."""
+    seeds = np.asarray(seeds).reshape(-1)
+    assert len(seeds) == self.n_envs
+    m = (1 << 64) - 1
+    words = np.empty((self.n_envs, 4), np.uint64)
+    for i, sd in enumerate(seeds):
+      st = np.random.PCG64(np.random.SeedSequence(int(sd))).state["state"]
+      words[i] = (st["state"] >> 64, st["state"] & m, st["inc"] >> 64, st["inc"] & m)
+    self.set_rng_state(words)
+
+  def set_rng_state(self, words):
+    """uint64 [N, 4] = PCG64 (state_hi, state_lo, inc_hi, inc_lo) per env."""
+    t = torch.from_numpy(np.ascontiguousarray(words, dtype=np.uint64).view(np.int64)).to(self.device)
+    N.check(self._lib.sgw_set_rng_state(self._h, t.data_ptr()), "sgw_set_rng_state")
+
+  def agent_views(self, board=None, agent_pos=None, outside_chr='#'):
+    """Agent-centric windows (safety_game_moma.py:1996-2101): list of uint8 [N, h_a, w_a] tensors, one per agent."""
+    board = self._bufs["board"] if board is None else board
+    agent_pos = self._bufs["agent_pos"] if agent_pos is None else agent_pos
+    vb = int(self._lib.sgw_view_bytes(self._h))
+    views = torch.empty((self.n_envs, vb), dtype=torch.uint8, device=self.device)
+    N.check(self._lib.sgw_agent_views(self._h, board.data_ptr(), agent_pos.data_ptr(), ord(outside_chr),
+                                      views.data_ptr(), self._stream()), "sgw_agent_views")
+    out, off = [], 0
+    for (h, w) in self.spec.view_shapes:
+      out.append(views[:, off:off + h * w].reshape(self.n_envs, h, w))
+      off += h * w
+    return out
 
   def observe(self, board=None, rgb=True, layer_chars=None):
     """RGB uint8 [N, 3, H, W] and/or occluded layers uint8 [N, L, H, W] of a rendered ascii board."""

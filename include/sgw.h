@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SGW_ABI_VERSION 1
+#define SGW_ABI_VERSION 2
 #define SGW_MAX_CELLS 320      /* >= 17*17 */
 #define SGW_MAX_K 16           /* reward dimensions per agent */
 #define SGW_MAX_M 16           /* metrics per env */
@@ -68,6 +68,7 @@ typedef struct sgw_spec {
   int32_t start_cell[SGW_MAX_AGENTS];   /* row*W+col of each agent sprite in the art */
   int32_t action_lo, n_actions;         /* action range, used by the synthetic rollout */
   int32_t flags;
+  int32_t view_radius[SGW_MAX_AGENTS][4]; /* agent-centric view: tiles visible up, down, left, right (-1 = no view) */
   int32_t reserved[3];
   int8_t dim_slot[SGW_MAX_AGENTS][SGW_MAX_K]; /* reward-universe dim -> output column, -1 = not enabled */
   int8_t metric_slot[SGW_MAX_M];              /* family metric id -> output column, -1 = absent */
@@ -93,6 +94,7 @@ typedef struct sgw_out {
   int32_t* safety;       /* [N_pad]       environment_data['safety'] (island_navigation_ex) */
   double* metrics;       /* [N_pad, M]    metrics_dict values in METRICS_LABELS order */
   int32_t* frame;        /* [N_pad]       the_plot.frame */
+  uint8_t* agent_pos;    /* [N_pad, A, 2] (row, col) of every agent sprite */
 } sgw_out;
 
 typedef struct sgw_engine sgw_engine;
@@ -167,6 +169,14 @@ int sgw_accumulate_returns(sgw_engine* e, const double* cumulative_dev, const ui
  * L characters in layer_chars_dev (occluded layers: board == char).  Either may be NULL. */
 int sgw_observe(sgw_engine* e, const uint8_t* board_dev, const uint8_t* rgb_lut_dev, uint8_t* rgb_dev,
                 const uint8_t* layer_chars_dev, int n_layers, uint8_t* layers_dev, void* stream);
+
+/* Agent-centric observations (get_agent_perspective, safety_game_moma.py:1996-2101): for every env and
+ * agent a, the (up+down+1) x (left+right+1) window of the rendered board centred on the agent, cells
+ * outside the board filled with `outside_chr`.  views_dev uint8 [N, view_bytes] with agent a's window at
+ * byte offset sum of the previous agents' window sizes (sgw_view_bytes gives the row size). */
+int sgw_view_bytes(const sgw_engine* e);
+int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agent_pos_dev, uint8_t outside_chr,
+                    uint8_t* views_dev, void* stream);
 
 /* Raw SoA state copy-out / copy-in (tests, checkpointing): uint64 [words][N_pad]. */
 int sgw_state_words(const sgw_engine* e);

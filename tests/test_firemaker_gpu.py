@@ -1,0 +1,110 @@
+"""GPU parity for the multi-agent path (firemaker_ex_ma): fixtures from the patched reference run and
+fresh seeds vs the multi-agent oracle.  Everything incl. the numpy PCG64 stream position must match."""
+import numpy as np
+import pytest
+import torch
+
+from ai_safety_gridworlds_amd import philox
+from ai_safety_gridworlds_amd.engine import BatchedEngine
+from ai_safety_gridworlds_amd.specs import make_spec
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+OUTS = ("board", "reward", "cumulative", "step_type", "term_reason", "discount", "metrics", "frame", "agent_pos",
+        "safety", "obs_board")
+
+
+def run(spec, actions, rng_states):
+  E, T, A = actions.shape
+  eng = BatchedEngine(spec, E, outputs=OUTS)
+  eng.set_rng_state(rng_states)
+  acts = torch.from_numpy(np.ascontiguousarray(np.transpose(actions, (1, 0, 2)))).to("cuda:0")   # [T, E, A]
+  rec = {k: [] for k in OUTS}
+  views = [[], [], []]
+  def grab(o):
+    for k in OUTS:
+      rec[k].append(o[k].clone())
+    for i, v in enumerate(eng.agent_views()):
+      views[i].append(v.clone())
+  grab(eng.reset())
+  for t in range(T):
+    grab(eng.step(acts[t]))
+  torch.cuda.synchronize()
+  out = {k: torch.stack(v, dim=1).cpu().numpy() for k, v in rec.items()}
+  out["views"] = [torch.stack(v, dim=1).cpu().numpy() for v in views]
+  st = eng.get_state()[:, :E].cpu().numpy().view(np.uint64)
+  out["rng_final"] = np.stack([st[3], st[4], st[5], st[6]], axis=1)
+  out["rng_has32_final"] = (st[0] >> np.uint64(27)) & np.uint64(1)
+  out["rng_u32_final"] = st[2] & np.uint64(0xffffffff)
+  eng.close()
+  return out
+
+
+def check(name, got, want):
+  G.assert_same(name + ".step_type", got["step_type"], want["step_type"])
+  G.assert_same(name + ".reward", got["reward"], want["reward"])
+  G.assert_same(name + ".cumulative", got["cumulative"], want["cumulative"])
+  G.assert_same(name + ".discount", got["discount"], want["discount"])
+  G.assert_same(name + ".frame", got["frame"], want["frame"])
+  G.assert_same(name + ".board", got["board"], want["board"])
+  G.assert_same(name + ".metrics", got["metrics"], want["metrics"])
+  G.assert_same(name + ".pos", got["agent_pos"], want["pos"])
+  tr = got["term_reason"].astype(np.int16); tr[tr == 255] = -1
+  G.assert_same(name + ".term_reason", tr, want["term_reason"][..., 0])
+  G.assert_same(name + ".view_worker", np.stack([got["views"][0], got["views"][1]], axis=2), want["view_worker"])
+  G.assert_same(name + ".view_supervisor", got["views"][2], want["view_supervisor"])
+  G.assert_same(name + ".rng", got["rng_final"], want["rng"][:, -1])
+  G.assert_same(name + ".rng_has32", got["rng_has32_final"], want["rng_has_uint32"][:, -1])
+  G.assert_same(name + ".rng_u32", got["rng_u32_final"] * got["rng_has32_final"],
+                want["rng_uinteger"][:, -1].astype(np.uint64) * want["rng_has_uint32"][:, -1].astype(np.uint64))
+
+
+@pytest.mark.parametrize("name", G.fixture_names(["firemaker_"]))
+def test_firemaker_hip_matches_reference_fixture(name):
+  fx, meta = G.load(name)
+  spec = make_spec("firemaker_ex_ma", **meta["kwargs"])
+  got = run(spec, fx["actions"], fx["rng_init"])
+  check(name, got, fx)
+  G.assert_same(name + ".obs_board", got["obs_board"], fx["obs_board"])
+
+
+@pytest.mark.parametrize("kw,E,T", [
+    (dict(amount_agents=3, max_iterations=150), 700, 120),
+    (dict(amount_agents=3, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.04, FIRE_CONTINUATION_PROBABILITY=0.9,
+          max_iterations=300), 300, 150),
+])
+def test_firemaker_hip_matches_oracle_fresh_seed(kw, E, T):
+  from oracle import oracle_ma as OM
+  seed = 0xF1E
+  actions = np.stack([philox.actions(seed, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(3)], axis=-1)
+  actions = np.transpose(actions, (1, 0, 2)).copy()                      # [E, T, 3]
+  rng = np.stack([OM.rng_state_words(5000 + e) for e in range(E)])
+  want = OM.run_streams(OM.make_config(**kw), actions, rng, nthreads=8)
+  got = run(make_spec("firemaker_ex_ma", **kw), actions, rng)
+  check("fresh", got, want)
+
+
+def test_firemaker_needs_rng_and_rollout_matches_steps():
+  from ai_safety_gridworlds_amd import _native as N
+  spec = make_spec("firemaker_ex_ma", amount_agents=3, max_iterations=90)
+  n, T, seed = 640, 48, 3
+  a = BatchedEngine(spec, n, outputs=("board", "reward", "step_type"))
+  with pytest.raises(N.SgwError, match="sgw_set_rng_state"):
+    a.reset()
+  b = BatchedEngine(spec, n, outputs=("board", "reward", "step_type"))
+  a.set_rng_seeds(np.arange(n) + 11); b.set_rng_seeds(np.arange(n) + 11)
+  a.reset(); b.reset()
+  acts = a.fill_actions(T, seed)
+  assert acts.shape == (T, n, 3)
+  ref = philox.actions(seed, np.arange(n), np.arange(T), 0, 5, agent=2)
+  assert np.array_equal(acts[..., 2].cpu().numpy(), ref)
+  per = {k: [] for k in ("board", "reward", "step_type")}
+  for t in range(T):
+    o = a.step(acts[t])
+    for k in per:
+      per[k].append(o[k].clone())
+  ro = b.rollout(T, seed, write_every=True)
+  for k in per:
+    assert torch.equal(torch.stack(per[k]), ro[k]), k
+  assert torch.equal(a.get_state()[:, :n], b.get_state()[:, :n])
