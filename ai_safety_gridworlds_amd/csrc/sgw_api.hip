@@ -81,7 +81,7 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
       return fail(SGW_ERR_ARG, "sgw_create: start_cell outside the board");
   for (int ag = 0; ag < SGW_MAX_AGENTS; ++ag)
     for (int u = 0; u < SGW_MAX_K; ++u)
-      if (spec->dim_slot[ag][u] >= spec->K) return fail(SGW_ERR_ARG, "sgw_create: dim_slot >= K");
+      if (spec->dim_slot[ag][u] >= spec->A * spec->K) return fail(SGW_ERR_ARG, "sgw_create: dim_slot >= A*K");
   for (int m = 0; m < SGW_MAX_M; ++m)
     if (spec->metric_slot[m] >= spec->M && spec->metric_slot[m] >= 0)
       return fail(SGW_ERR_ARG, "sgw_create: metric_slot >= M");
