@@ -79,3 +79,41 @@ def test_vector_env_and_factory():
     factory.get_environment_obj("whisky_gold")
   e = factory.get_environment_obj("boat_race_ex", level=3)
   assert e.action_spec() == (0, 4)
+
+
+def test_config3_firemaker_through_the_zoo_parallel_facade():
+  """BASELINE.json configs[3] surface: firemaker_ex_ma via the Zoo parallel API (3 agents = the reference's
+  maximum), replaying a reference fixture stream: agent-centric ascii views, per-agent reward vectors, dones."""
+  from ai_safety_gridworlds_amd.helpers.gridworld_zoo_parallel_env import GridworldZooParallelEnv
+  fx, meta = G.load("firemaker_L0_maxit60")
+  e = 2
+  env = GridworldZooParallelEnv("firemaker_ex_ma", seed=int(fx["seeds"][e]), **meta["kwargs"])
+  assert env.possible_agents == ["agent_1", "agent_2", "agent_S"]
+  obs, infos = env.reset()
+  assert obs["agent_1"].shape == (1, 5, 5) and obs["agent_S"].shape == (1, 33, 33) and obs["agent_1"].dtype.kind == "U"
+  names = env.possible_agents
+  for t in range(80):
+    a = fx["actions"][e, t]
+    obs, rewards, terms, truncs, infos = env.step({"agent_1": int(a[0]), "agent_2": {"step": int(a[1])}, "agent_S": int(a[2])})
+    st = fx["step_type"][e, t + 1]
+    if st[0] == 0:       # auto-reset round: FIRST for everybody, rewards 0.0
+      assert all(rewards[n] == 0.0 for n in names)
+    else:
+      assert np.array_equal(rewards["agent_1"], fx["reward"][e, t + 1, 0, :2])
+      assert np.array_equal(rewards["agent_S"], fx["reward"][e, t + 1, 2, :3])
+    want = np.vectorize(chr)(fx["view_worker"][e, t + 1, 1])
+    assert np.array_equal(obs["agent_2"][0], want)
+    assert np.array_equal(obs["agent_S"][0], np.vectorize(chr)(fx["view_supervisor"][e, t + 1]))
+    assert np.array_equal(env.state[0], np.vectorize(chr)(fx["board"][e, t + 1]))
+    assert terms["agent_1"] == (st[0] in (2, 3)) and truncs["agent_1"] is False
+    if terms["agent_1"]:
+      assert env.agents == []
+
+
+def test_zoo_facade_single_agent_env():
+  from ai_safety_gridworlds_amd.helpers.gridworld_zoo_parallel_env import GridworldZooParallelEnv
+  env = GridworldZooParallelEnv("island_navigation_ex")
+  obs, infos = env.reset()
+  assert list(obs) == ["agent_0"] and obs["agent_0"].shape == (1, 6, 8) and obs["agent_0"].dtype == np.float32
+  obs, r, term, trunc, infos = env.step({"agent_0": 3})
+  assert r["agent_0"].shape == (10,) and term["agent_0"] is False
