@@ -64,7 +64,7 @@ class BatchedSafetyEnvironment(object):
   # ---- stepping -------------------------------------------------------------------------------
   def _timestep(self, o):
     self._last = o
-    st = o["step_type"].reshape(self.num_envs)
+    st = o["step_type"].reshape(self.num_envs, -1)[:, 0]      # all agents of an env share the step type
     if "cumulative" in o or "hidden" in o:      # _calculate_episode_performance (safety_game.py:253-263)
       perf = o["hidden"].reshape(self.num_envs, 1) if self.spec.scalar and "hidden" in o else o.get("cumulative")
       if perf is not None:
