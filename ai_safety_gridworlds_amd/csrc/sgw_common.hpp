@@ -16,7 +16,7 @@
 namespace sgw {
 
 constexpr int WAVE = 64;
-constexpr int TABLE_BYTES = 3 * SGW_MAX_CELLS + 128 * 4 + SGW_N_PARAMS * 8;   // 1856
+constexpr int TABLE_BYTES = 2048;   // 3*320 level tables + 512 value map + 384 params = 1856, padded to 2 x 16 B per lane
 
 // ---- kernel arguments (by value => kernarg segment => scalar loads) -------------------------
 struct KSpec {
@@ -56,14 +56,14 @@ struct Lds {
   float* value_map;        // [128]
   const double* params;    // [SGW_N_PARAMS] family constants (vector registers on demand, not SGPRs)
   uint32_t* board;         // 64*HW bytes (+ slack), the wave's 64 board rows, contiguous
-  double* vec;             // 64*A*K doubles (reward / cumulative / metrics staging)
+  double* vec_r;           // 64*A*K doubles: reward rows
+  double* vec_c;           // 64*A*K doubles: cumulative rows
+  double* vec_m;           // 64*M doubles: metrics rows
 };
 
 __host__ __device__ inline size_t lds_board_bytes(int HW) { return ((size_t)64 * HW + 15) / 16 * 16 + 16; }
 __host__ __device__ inline size_t lds_vec_bytes(int A, int K, int M) {
-  int n = A * K > M ? A * K : M;
-  if (n < 1) n = 1;
-  return (size_t)64 * n * 8;
+  return (size_t)64 * 8 * (2 * (A * K > 0 ? A * K : 1) + (M > 0 ? M : 1));   // reward + cumulative + metrics staging
 }
 __host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M) {
   return TABLE_BYTES + lds_board_bytes(HW) + lds_vec_bytes(A, K, M);
@@ -77,16 +77,27 @@ __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp) {
   l.value_map = reinterpret_cast<float*>(smem + 3 * SGW_MAX_CELLS);
   l.params = reinterpret_cast<const double*>(smem + 3 * SGW_MAX_CELLS + 512);
   l.board = reinterpret_cast<uint32_t*>(smem + TABLE_BYTES);
-  l.vec = reinterpret_cast<double*>(smem + TABLE_BYTES + lds_board_bytes(sp.HW));
+  l.vec_r = reinterpret_cast<double*>(smem + TABLE_BYTES + lds_board_bytes(sp.HW));
+  l.vec_c = l.vec_r + 64 * (sp.A * sp.K > 0 ? sp.A * sp.K : 1);
+  l.vec_m = l.vec_c + 64 * (sp.A * sp.K > 0 ? sp.A * sp.K : 1);
   return l;
 }
 
-// tables (3*320 + 512 + 384 = 1856 bytes = 464 dwords) -> LDS, coalesced dword loads
+// tables (2048 bytes) -> LDS: exactly two 16-byte loads per lane, both in flight before the single wait
 __device__ inline void lds_load_tables(uint8_t* smem, const uint8_t* tables) {
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(tables);
-  uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
-  constexpr int NDW = TABLE_BYTES / 4;
-  for (int i = threadIdx.x; i < NDW; i += WAVE) dst[i] = src[i];
+  const uint4* src = reinterpret_cast<const uint4*>(tables);
+  uint4* dst = reinterpret_cast<uint4*>(smem);
+  const uint4 t0 = src[threadIdx.x], t1 = src[threadIdx.x + WAVE];
+  dst[threadIdx.x] = t0; dst[threadIdx.x + WAVE] = t1;
+}
+
+// One wavefront per workgroup: lanes exchange data through LDS in program order (the LDS pipeline executes
+// a wave's ds_* instructions in issue order), so a cross-lane LDS hand-off needs only a COMPILER fence --
+// no s_barrier and, unlike __syncthreads(), no s_waitcnt vmcnt(0) that would stall on in-flight global stores.
+__device__ inline void lds_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ---- Philox-4x32-10 (same stream as ai_safety_gridworlds_amd/philox.py) ---------------------

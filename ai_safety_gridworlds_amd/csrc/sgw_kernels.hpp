@@ -19,11 +19,14 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
                             bool coop, bool lane_active) {
   const sgw_out& o = a.out;
   const KSpec& sp = a.sp;
-  const int HW = sp.HW, K = sp.A * sp.K;   // reward rows hold all agents' vectors: [A][K]
+  const int HW = sp.HW, K = sp.A * sp.K, M = sp.M;   // reward rows hold all agents' vectors: [A][K]
   const long long env = env0 + lane;
+  const bool want_board = o.board || o.obs_board;
 
-  if (o.board || o.obs_board) {
-    if (HW & 3) { lds_zero_board(l.board, HW); __syncthreads(); }
+  // ---- phase 1: every lane writes its rows into the (disjoint) LDS staging regions
+  lds_wave_sync();                                        // previous step's cooperative reads are done (program order)
+  if (want_board && (HW & 3)) { lds_zero_board(l.board, HW); lds_wave_sync(); }
+  if (want_board) {
     if constexpr (F::CUSTOM_BOARD) {
       lds_write_board_row_fn(l.board, HW, lane, [&](int i) { return F::board_dword(s, sp, l, i); });
     } else {
@@ -31,52 +34,52 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
       const uint8_t* base = F::board_layers(s, sp, l, cells, chars);
       lds_write_board_row<F::NSPRITE>(l.board, HW, lane, base, cells, chars);
     }
-    __syncthreads();
-    if (o.board) {
-      uint8_t* dst = o.board + toff * HW;
-      if (coop) coop_store(dst, env0, HW, l.board);
-      else if (lane_active) lane_store(dst, env, HW, l.board, lane);
-    }
-    if (o.obs_board) {                                   // value_mapping LUT (rendering.py:491-549)
-      float* dst = o.obs_board + (toff + env0) * HW;
-      const uint8_t* img = reinterpret_cast<const uint8_t*>(l.board);
-      if (coop) {
-        float4* d4 = reinterpret_cast<float4*>(dst);
-        for (int c = lane; c < 16 * HW; c += WAVE) {     // 64*HW cells, 4 per lane-iteration
-          uint32_t q = l.board[c];
-          d4[c] = make_float4(l.value_map[q & 0x7f], l.value_map[(q >> 8) & 0x7f],
-                              l.value_map[(q >> 16) & 0x7f], l.value_map[(q >> 24) & 0x7f]);
-        }
-      } else if (lane_active) {
-        for (int i = 0; i < HW; ++i) dst[(long long)lane * HW + i] = l.value_map[img[lane * HW + i] & 0x7f];
-      }
-    }
-    __syncthreads();
   }
   if (o.reward) {
 #pragma unroll
-    for (int u = 0; u < F::NU; ++u) { int slot = sp.dim_slot[0][u]; if (slot >= 0) l.vec[lane * K + slot] = r[u]; }
-    __syncthreads();
-    double* dst = o.reward + toff * K;
-    if (coop) coop_store(dst, env0, K * 8, l.vec); else if (lane_active) lane_store(dst, env, K * 8, l.vec, lane);
-    __syncthreads();
+    for (int u = 0; u < F::NU; ++u) { int slot = sp.dim_slot[0][u]; if (slot >= 0) l.vec_r[lane * K + slot] = r[u]; }
   }
   if (o.cumulative) {
 #pragma unroll
-    for (int u = 0; u < F::NU; ++u) { int slot = sp.dim_slot[0][u]; if (slot >= 0) l.vec[lane * K + slot] = s.cum[u]; }
-    __syncthreads();
-    double* dst = o.cumulative + toff * K;
-    if (coop) coop_store(dst, env0, K * 8, l.vec); else if (lane_active) lane_store(dst, env, K * 8, l.vec, lane);
-    __syncthreads();
+    for (int u = 0; u < F::NU; ++u) { int slot = sp.dim_slot[0][u]; if (slot >= 0) l.vec_c[lane * K + slot] = s.cum[u]; }
   }
-  if (o.metrics && sp.M > 0) {
-    const int M = sp.M;
+  if (o.metrics && M > 0) {
 #pragma unroll
-    for (int id = 0; id < F::NMETRIC; ++id) { int slot = sp.metric_slot[id]; if (slot >= 0) l.vec[lane * M + slot] = F::metric(s, id); }
-    __syncthreads();
+    for (int id = 0; id < F::NMETRIC; ++id) { int slot = sp.metric_slot[id]; if (slot >= 0) l.vec_m[lane * M + slot] = F::metric(s, id); }
+  }
+  lds_wave_sync();
+
+  // ---- phase 2: the wave streams its 64 contiguous rows out, 16 B per lane per instruction; no waits in between
+  if (o.board) {
+    uint8_t* dst = o.board + toff * HW;
+    if (coop) coop_store(dst, env0, HW, l.board);
+    else if (lane_active) lane_store(dst, env, HW, l.board, lane);
+  }
+  if (o.obs_board) {                                     // value_mapping LUT (rendering.py:491-549)
+    float* dst = o.obs_board + (toff + env0) * HW;
+    const uint8_t* img = reinterpret_cast<const uint8_t*>(l.board);
+    if (coop) {
+      float4* d4 = reinterpret_cast<float4*>(dst);
+      for (int c = lane; c < 16 * HW; c += WAVE) {       // 64*HW cells, 4 per lane-iteration
+        uint32_t q = l.board[c];
+        d4[c] = make_float4(l.value_map[q & 0x7f], l.value_map[(q >> 8) & 0x7f],
+                            l.value_map[(q >> 16) & 0x7f], l.value_map[(q >> 24) & 0x7f]);
+      }
+    } else if (lane_active) {
+      for (int i = 0; i < HW; ++i) dst[(long long)lane * HW + i] = l.value_map[img[lane * HW + i] & 0x7f];
+    }
+  }
+  if (o.reward) {
+    double* dst = o.reward + toff * K;
+    if (coop) coop_store(dst, env0, K * 8, l.vec_r); else if (lane_active) lane_store(dst, env, K * 8, l.vec_r, lane);
+  }
+  if (o.cumulative) {
+    double* dst = o.cumulative + toff * K;
+    if (coop) coop_store(dst, env0, K * 8, l.vec_c); else if (lane_active) lane_store(dst, env, K * 8, l.vec_c, lane);
+  }
+  if (o.metrics && M > 0) {
     double* dst = o.metrics + toff * M;
-    if (coop) coop_store(dst, env0, M * 8, l.vec); else if (lane_active) lane_store(dst, env, M * 8, l.vec, lane);
-    __syncthreads();
+    if (coop) coop_store(dst, env0, M * 8, l.vec_m); else if (lane_active) lane_store(dst, env, M * 8, l.vec_m, lane);
   }
   if (coop || lane_active) {
     const long long row = toff + env;
@@ -111,17 +114,18 @@ enum { K_STEP = 0, K_ROLLOUT = 1, K_RESET = 2 };
 template <class F, int KIND>
 __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  lds_load_tables(smem, a.tables);
-  const Lds l = lds_carve(smem, a.sp);
-  __syncthreads();
   const int lane = threadIdx.x;
   const long long env0 = (long long)blockIdx.x * WAVE;
   const long long env = env0 + lane;
   const long long env_id = a.env_id_base + env;
   const bool real = env < a.n_envs;
 
+  // issue the level-table loads and the env's state-column loads back to back: one HBM/L2 round trip, not two
+  lds_load_tables(smem, a.tables);
+  const Lds l = lds_carve(smem, a.sp);
   typename F::State s;
   F::load(s, a, env);
+  __syncthreads();
 
   if (KIND == K_RESET) {
     const bool m = a.mask ? (real && a.mask[env] != 0) : true;
@@ -156,14 +160,19 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
       if (over && s.term == TERM_NONE4) s.term = SGW_MAX_STEPS;                   // safety_game.py:294-296
 #pragma unroll
       for (int u = 0; u < F::NU; ++u) s.cum[u] += r[u];                          // safety_game_mo.py:996-997
-      if (a.ep_acc && over) {   // episodic-return accumulators: this env's own column, no atomics
-        const int AK = a.sp.A * a.sp.K;
+      if (a.ep_acc && over) {   // episodic-return accumulators: this env's own column, no atomics.
+        // All loads are issued before the first store (one memory round trip, not one per column).
+        double* col = a.ep_acc + env;
+        double old[F::NU + 1];
+        {
+          const double* q = col;
 #pragma unroll
-        for (int u = 0; u < F::NU; ++u) {
-          int slot = a.sp.dim_slot[0][u];
-          if (slot >= 0) a.ep_acc[(long long)slot * a.n_pad + env] += s.cum[u];
+          for (int u = 0; u < F::NU; ++u) if (a.sp.dim_slot[0][u] >= 0) { old[u] = *q; q += a.n_pad; }
+          old[F::NU] = *q;
         }
-        a.ep_acc[(long long)AK * a.n_pad + env] += 1.0;
+#pragma unroll
+        for (int u = 0; u < F::NU; ++u) if (a.sp.dim_slot[0][u] >= 0) { *col = old[u] + s.cum[u]; col += a.n_pad; }
+        *col = old[F::NU] + 1.0;
       }
     }
     const bool last_t = (t == TT - 1);

@@ -40,9 +40,7 @@ SEED = 0x5AFE
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # algorithmic bytes per env-step, island_navigation_ex L9 (step-per-launch mode):
 # action 1 + state 80 read + 80 write + board 48 + reward 80 + done 1 + term 1 + safety/hidden 8
-B_ALG_STEP = 299
-B_ALG_FUSED = 139                # fused rollout: the two state terms drop out
-OUTPUTS = ("board", "reward", "step_type", "term_reason", "safety", "frame")
+# (per-workload figures live in WORKLOADS below; fused rollout: the two state terms drop out)
 
 
 def cpu_baseline(n_envs, seconds, threads):
@@ -68,12 +66,48 @@ def cpu_baseline(n_envs, seconds, threads):
           "single_thread_value": rate1}
 
 
+# SURVEY.md §8(d) algorithmic bytes per env-step: (step-per-launch, fused rollout)
+WORKLOADS = {
+    "island_navigation_ex": dict(kwargs={}, envs=65536, b_step=299, b_fused=139,
+                                 outputs=("board", "reward", "step_type", "term_reason", "safety", "frame")),
+    "boat_race_ex": dict(kwargs=dict(level=3), envs=65536, b_step=318, b_fused=108,
+                         outputs=("board", "reward", "step_type", "term_reason", "frame")),
+    "safe_interruptibility": dict(kwargs=dict(level=1), envs=65536, b_step=107, b_fused=75,
+                                  outputs=("board", "reward", "step_type", "term_reason", "hidden")),
+    "boat_race": dict(kwargs=dict(level=0), envs=65536, b_step=76, b_fused=44,
+                      outputs=("board", "reward", "step_type", "term_reason", "hidden")),
+    # one env-step = one ROUND (3 agents act); agent-centric views are produced by a separate kernel and are
+    # not part of this loop: 1815 B/round of SURVEY minus the 1139 view bytes
+    "firemaker_ex_ma": dict(kwargs=dict(amount_agents=3), envs=16384, b_step=676, b_fused=354,
+                            outputs=("board", "reward", "step_type", "term_reason", "agent_pos")),
+}
+MIXED = ("island_navigation_ex", "boat_race_ex", "safe_interruptibility")    # BASELINE.json configs[4]
+
+
+def mixed_parts(rank, world, per_gpu):
+  """Mixed suite: the global id range [0, per_gpu*world) is cut into three contiguous family ranges, ranks own
+  contiguous 1/world slices -> list of (family, n_envs, global id base)."""
+  total = per_gpu * world
+  bounds = [0]
+  for i in range(3):
+    lo, hi = parallel.shard_range(total, i, 3)
+    bounds.append(hi)
+  lo, hi = rank * per_gpu, (rank + 1) * per_gpu
+  parts = []
+  for i, fam in enumerate(MIXED):
+    a, b = max(lo, bounds[i]), min(hi, bounds[i + 1])
+    if b > a:
+      parts.append((fam, b - a, a))
+  return parts
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=2000)
   ap.add_argument("--warmup", type=int, default=200)
-  ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+  ap.add_argument("--workload", default="island_navigation_ex", choices=sorted(WORKLOADS) + ["mixed"])
+  ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's BASELINE size)")
   ap.add_argument("--cpu-seconds", type=float, default=12.0)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-fused", action="store_true")
@@ -88,11 +122,25 @@ def main():
   device = torch.device("cuda", local_rank)
   torch.cuda.set_device(device)
 
-  K, W, n = a.steps, a.warmup, a.envs
-  spec = make_spec("island_navigation_ex")            # level 9, default flags
-  eng = BatchedEngine(spec, n, device=device, env_id_base=rank * n, outputs=OUTPUTS)
-  eng.reset()
-  acts = eng.fill_actions(W + K, SEED)                # [W+K, n] int8, resident in HBM
+  K, W = a.steps, a.warmup
+  if a.workload == "mixed":
+    n = a.envs or 32768
+    parts = mixed_parts(rank, world, n)
+  else:
+    n = a.envs or WORKLOADS[a.workload]["envs"]
+    parts = [(a.workload, n, rank * n)]
+  engines = []
+  for fam, cnt, base in parts:
+    wl = WORKLOADS[fam]
+    spec = make_spec(fam, **wl["kwargs"])
+    eng = BatchedEngine(spec, cnt, device=device, env_id_base=base, outputs=wl["outputs"])
+    if fam == "firemaker_ex_ma":
+      eng.set_rng_seeds(base + np.arange(cnt))
+    if fam == "safe_interruptibility":
+      eng.set_episode_bits(None, seed=SEED)
+    eng.reset()
+    engines.append(dict(fam=fam, spec=spec, eng=eng, n=cnt, wl=wl, acts=eng.fill_actions(W + K, SEED),
+                        stream=torch.cuda.Stream(device) if len(parts) > 1 else torch.cuda.current_stream(device)))
   ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
   def barrier():
@@ -101,27 +149,43 @@ def main():
       dist.barrier()
     torch.cuda.synchronize(device)
 
+  def run(lo, hi, accumulate):
+    for e in engines:                                   # one stream per family (mixed suite); K launches each
+      with torch.cuda.stream(e["stream"]):
+        e["eng"].step_n(e["acts"][lo:hi], accumulate=accumulate)
+
   if W > 0:
-    eng.step_n(acts[:W])
+    run(0, W, False)
   barrier()
   t0 = time.perf_counter()
-  ev0.record()
-  eng.step_n(acts[W:], accumulate=True)               # K launches, one per step
-  ev1.record()
+  ev0.record(engines[0]["stream"])
+  run(W, W + K, True)
+  ev1.record(engines[0]["stream"])
   torch.cuda.synchronize(device)
   elapsed = time.perf_counter() - t0
   barrier()
-  kernel_ms = ev0.elapsed_time(ev1) / K               # avg launch duration on the launch stream
-  accum = eng.read_returns()                          # [K+1] per-GPU (sum of episode returns, #episodes)
+  kernel_ms = ev0.elapsed_time(ev1) / K                # avg launch duration of the first family's kernel
   elapsed = parallel.max_over_ranks(elapsed, device, dist)
-  parallel.allreduce_returns(accum, dist)             # the one collective: episodic returns, end of batch
-  acc = accum.cpu().numpy()
+  returns = {}
+  for fam in (MIXED if a.workload == "mixed" else (a.workload,)):
+    spec = make_spec(fam, **WORKLOADS[fam]["kwargs"])
+    acc = torch.zeros(spec.A * spec.K + 1, dtype=torch.float64, device=device)
+    for e in engines:
+      if e["fam"] == fam:
+        acc += e["eng"].read_returns()
+    parallel.allreduce_returns(acc, dist)              # the one collective: episodic returns, end of batch
+    returns[fam] = (spec, acc.cpu().numpy())
 
   fused = None
-  if not a.no_fused:
-    eng2 = BatchedEngine(spec, n, device=device, env_id_base=rank * n, outputs=OUTPUTS)
+  if not a.no_fused and a.workload != "mixed":
+    e = engines[0]
+    eng2 = BatchedEngine(e["spec"], e["n"], device=device, env_id_base=rank * e["n"], outputs=e["wl"]["outputs"])
+    if e["fam"] == "firemaker_ex_ma":
+      eng2.set_rng_seeds(rank * e["n"] + np.arange(e["n"]))
+    if e["fam"] == "safe_interruptibility":
+      eng2.set_episode_bits(None, seed=SEED)
     eng2.reset()
-    Tf = min(K, 512)
+    Tf = min(K, 512 if e["fam"] != "firemaker_ex_ma" else 128)
     eng2.rollout(min(W, 64) or 1, SEED, step0=0, write_every=True)
     barrier()
     f0 = time.perf_counter()
@@ -133,47 +197,55 @@ def main():
     barrier()
     fms = ev0.elapsed_time(ev1)
     felapsed = parallel.max_over_ranks(felapsed, device, dist)
-    fused = {"value": world * n * Tf / felapsed, "unit": "env-steps/s", "steps_per_launch": Tf,
-             "ms_per_step": fms / Tf, "bytes_per_env_step": B_ALG_FUSED,
-             "hbm_gbs": n * B_ALG_FUSED / (fms / Tf * 1e-3) / 1e9,
-             "note": "ONE launch advances every env Tf steps (state in registers, in-kernel Philox "
-                     "actions), board/reward/step_type/term_reason/safety/frame written every step"}
+    fused = {"value": world * e["n"] * Tf / felapsed, "unit": "env-steps/s", "steps_per_launch": Tf,
+             "ms_per_step": fms / Tf, "bytes_per_env_step": e["wl"]["b_fused"],
+             "hbm_gbs": e["n"] * e["wl"]["b_fused"] / (fms / Tf * 1e-3) / 1e9,
+             "note": "ONE launch advances every env Tf steps (state in registers, in-kernel Philox actions), "
+                     "all listed outputs written every step"}
     eng2.close()
 
   if rank == 0:
-    achieved = n * B_ALG_STEP / (kernel_ms * 1e-3) / 1e9
+    n_rank = sum(e["n"] for e in engines)
+    alg_bytes = sum(e["n"] * e["wl"]["b_step"] for e in engines)      # algorithmic bytes of one bench step on this rank
+    e0 = engines[0]
+    achieved = e0["n"] * e0["wl"]["b_step"] / (kernel_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and a.workload == "island_navigation_ex":
       try:
         traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
       except Exception:
         traffic = None
+    desc = {"island_navigation_ex": "island_navigation_ex level 9 default flags", "boat_race_ex": "boat_race_ex level 3",
+            "safe_interruptibility": "safe_interruptibility level 1", "boat_race": "boat_race level 0",
+            "firemaker_ex_ma": "firemaker_ex_ma level 0, 3 agents (one env-step = one round)",
+            "mixed": "mixed suite island_navigation_ex + boat_race_ex + safe_interruptibility on 3 streams"}[a.workload]
     line = {
         "metric": "env-steps/sec (whole node), 65 536 batched envs per GPU",
-        "value": world * n * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "value": world * n_rank * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "island_navigation_ex level 9 default flags, %d envs/GPU, one sgw_step launch "
-                               "per step, uniform Philox actions resident in HBM" % n,
-                   "envs_per_gpu": n, "reward_dims": spec.K, "board": "%dx%d" % (spec.H, spec.W),
-                   "outputs": list(OUTPUTS), "sharding": "env-id ranges, dp%d" % world},
+        "config": {"workload": "%s, %d envs/GPU, one sgw_step launch per family per step, uniform Philox actions "
+                               "resident in HBM" % (desc, n_rank),
+                   "envs_per_gpu": n_rank, "outputs": list(e0["wl"]["outputs"]), "sharding": "env-id ranges, dp%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "sgw::k_engine<sgw::Island>", "avg_launch_us": kernel_ms * 1e3,
-                     "algorithmic_bytes_per_env_step": B_ALG_STEP, "env_steps_per_launch": n},
-        "episodes_finished": float(acc[spec.K]),
-        "mean_episode_return": (acc[:spec.K] / max(acc[spec.K], 1.0)).tolist(),
-        "reward_dim_names": spec.dim_names,
+                     "kernel": "sgw::k_engine<%s, K_STEP>" % e0["fam"], "avg_launch_us": kernel_ms * 1e3,
+                     "algorithmic_bytes_per_env_step": e0["wl"]["b_step"], "env_steps_per_launch": e0["n"],
+                     "whole_step_algorithmic_gbs": alg_bytes / (elapsed / K) / 1e9},
+        "returns": {fam: {"episodes_finished": float(acc[-1]),
+                          "mean_episode_return": (acc[:-1] / max(acc[-1], 1.0)).tolist()}
+                    for fam, (spec, acc) in returns.items()},
     }
     if fused is not None:
       line["fused_rollout"] = fused
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and a.workload == "island_navigation_ex":
       threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
       threads = max(1, min(threads, 64))
       line["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds, threads)
     print(json.dumps(line))
-  eng.close()
+  for e in engines:
+    e["eng"].close()
   if dist is not None:
     dist.destroy_process_group()
 

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/<tag>/ (tools/collect_profiles.sh) into profiles/: kernel stats CSV copy, PMC table,
+r01_traffic.json (HBM bytes per launch of the step kernel, corrected as MI355X_MICROARCH.md §HBM prescribes)."""
+import csv, glob, json, os, shutil, statistics, sys
+
+tag, rnd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r01")
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+KERNEL = "Island"
+
+def counters(d):
+  f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+  acc = {}
+  if not f:
+    return acc
+  for r in csv.DictReader(open(f[0])):
+    if KERNEL in r["Kernel_Name"] and "Li0E" in r["Kernel_Name"] or (KERNEL in r["Kernel_Name"] and "K_STEP" in r["Kernel_Name"]) or (KERNEL in r["Kernel_Name"] and ", 0>" in r["Kernel_Name"]):
+      acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+  return {k: statistics.median(v[len(v) // 5:]) for k, v in acc.items()}
+
+pm = {}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+  pm.update(counters(d))
+stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+if stats:
+  shutil.copy(stats[0], os.path.join("profiles", "%s_%s_kernel_stats.csv" % (rnd, tag)))
+shutil.copy(os.path.join(src, "bench.json"), os.path.join("profiles", "%s_%s_bench.json" % (rnd, tag)))
+out = {"tag": tag, "kernel": "sgw::k_engine<sgw::Island, K_STEP> (65536 envs, 1024 waves)", "pmc_median_per_launch": pm}
+if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+  # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads exactly half of a wide coalesced streaming read
+  # (MI355X_MICROARCH.md §HBM) -> doubled.  Our state loads are 8 B/lane (uncalibrated width): both figures are kept.
+  out["fetch_kib_raw"] = pm["FETCH_SIZE"]; out["write_kib"] = pm["WRITE_SIZE"]
+  out["hbm_bytes_per_launch"] = (2 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024
+  out["hbm_bytes_per_launch_uncorrected"] = (pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024
+  out["algorithmic_bytes_per_launch"] = 299 * 65536
+json.dump(out, open(os.path.join("profiles", "%s_%s_pmc.json" % (rnd, tag)), "w"), indent=1)
+if "hbm_bytes_per_launch" in out:
+  json.dump({"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": "%s_%s_pmc.json" % (rnd, tag)},
+            open(os.path.join("profiles", "%s_traffic.json" % rnd), "w"))
+print(json.dumps(out, indent=1))
