@@ -156,8 +156,13 @@ struct Cursor {
 __device__ inline void coop_store(void* dst, long long env0, int row_bytes, const void* lds_src) {
   uint4* g = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(dst) + env0 * row_bytes);
   const uint4* s = reinterpret_cast<const uint4*>(lds_src);
-  int nchunk = 4 * row_bytes;                     // 64 * row_bytes / 16
-  for (int c = threadIdx.x; c < nchunk; c += WAVE) g[c] = s[c];
+  const int nchunk = 4 * row_bytes;               // 64 * row_bytes / 16
+  int c = threadIdx.x;
+  for (; c + 3 * WAVE < nchunk; c += 4 * WAVE) {  // 4 LDS reads in flight, then 4 stores: one LDS wait per batch
+    const uint4 v0 = s[c], v1 = s[c + WAVE], v2 = s[c + 2 * WAVE], v3 = s[c + 3 * WAVE];
+    g[c] = v0; g[c + WAVE] = v1; g[c + 2 * WAVE] = v2; g[c + 3 * WAVE] = v3;
+  }
+  for (; c < nchunk; c += WAVE) g[c] = s[c];
 }
 // Slow path (masked reset): each lane copies only its own row.
 __device__ inline void lane_store(void* dst, long long env, int row_bytes, const void* lds_src, int lane) {

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
 #pragma unroll
     for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
     double discount = __longlong_as_double(0x7ff8000000000000LL);   // None at FIRST
+    bool acc_now = false;
+    double acc_old[F::NU + 1];
     if (s.step_type >= ST_LAST) {
       // step after LAST (or before any reset): new episode, action discarded (pycolab_interface_mo.py:175-178)
       F::pre_autoreset(s, a);
@@ -160,24 +162,24 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
       if (over && s.term == TERM_NONE4) s.term = SGW_MAX_STEPS;                   // safety_game.py:294-296
 #pragma unroll
       for (int u = 0; u < F::NU; ++u) s.cum[u] += r[u];                          // safety_game_mo.py:996-997
-      if (a.ep_acc && over) {   // episodic-return accumulators: this env's own column, no atomics.
-        // All loads are issued before the first store (one memory round trip, not one per column).
-        double* col = a.ep_acc + env;
-        double old[F::NU + 1];
-        {
-          const double* q = col;
+      acc_now = a.ep_acc && over;
+      if (acc_now) {   // episodic-return accumulators: this env's own column, no atomics.  The loads are issued
+        // here, all before the first store, and consumed AFTER the output phase: their round trip hides behind it.
+        const double* q = a.ep_acc + env;
 #pragma unroll
-          for (int u = 0; u < F::NU; ++u) if (a.sp.dim_slot[0][u] >= 0) { old[u] = *q; q += a.n_pad; }
-          old[F::NU] = *q;
-        }
-#pragma unroll
-        for (int u = 0; u < F::NU; ++u) if (a.sp.dim_slot[0][u] >= 0) { *col = old[u] + s.cum[u]; col += a.n_pad; }
-        *col = old[F::NU] + 1.0;
+        for (int u = 0; u < F::NU; ++u) if (a.sp.dim_slot[0][u] >= 0) { acc_old[u] = *q; q += a.n_pad; }
+        acc_old[F::NU] = *q;
       }
     }
     const bool last_t = (t == TT - 1);
     if (a.write_every != 0 || last_t)
       emit<F>(s, r, discount, a, l, env0, lane, a.write_every != 0 ? (long long)t * a.n_pad : 0, true, true);
+    if (acc_now) {
+      double* col = a.ep_acc + env;
+#pragma unroll
+      for (int u = 0; u < F::NU; ++u) if (a.sp.dim_slot[0][u] >= 0) { *col = acc_old[u] + s.cum[u]; col += a.n_pad; }
+      *col = acc_old[F::NU] + 1.0;
+    }
   }
   F::store(s, a, env);
 
