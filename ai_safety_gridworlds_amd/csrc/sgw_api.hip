@@ -42,7 +42,7 @@ struct sgw_engine {
   int ep_bits_n;
   unsigned long long ep_seed;
   size_t lds_bytes;
-  double* acc_dev;         // [A*K+1][n_pad] episodic-return accumulators (lazily allocated)
+  double* acc_dev;         // [n_pad/64][A*K+1] per-wave episodic-return accumulators (lazily allocated)
   int rng_set;
 };
 
@@ -186,7 +186,7 @@ int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev) {
 static int ensure_acc(sgw_engine* e) {
   if (e->acc_dev) return SGW_OK;
   HIP_TRY(hipSetDevice(e->device));
-  const size_t bytes = (size_t)(e->spec.A * e->spec.K + 1) * (size_t)e->n_pad * 8;
+  const size_t bytes = (size_t)(e->spec.A * e->spec.K + 1) * (size_t)(e->n_pad / WAVE) * 8;   // [waves][A*K+1]
   HIP_TRY(hipMalloc((void**)&e->acc_dev, bytes));
   HIP_TRY(hipMemset(e->acc_dev, 0, bytes));
   return SGW_OK;
@@ -274,7 +274,7 @@ int sgw_read_returns(sgw_engine* e, double* out_dev, int clear, void* stream) {
   int rc = ensure_acc(e);
   if (rc) return rc;
   hipLaunchKernelGGL(k_read_returns, dim3(e->spec.A * e->spec.K + 1), dim3(256), 0, (hipStream_t)stream, e->acc_dev,
-                     e->n_pad, e->n_envs, out_dev, clear);
+                     e->n_pad / WAVE, e->spec.A * e->spec.K + 1, out_dev, clear);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }

@@ -42,7 +42,7 @@ struct KArgs {
   unsigned long long seed;
   long long step0;
   int write_every;
-  double* ep_acc;            // per-env episodic-return accumulators [A*K+1][n_pad], or nullptr
+  double* ep_acc;            // per-wave episodic-return accumulators [n_pad/64][A*K+1], or nullptr
 };
 
 enum { MODE_STEP = 0, MODE_RESET = 1 };
@@ -59,11 +59,12 @@ struct Lds {
   double* vec_r;           // 64*A*K doubles: reward rows
   double* vec_c;           // 64*A*K doubles: cumulative rows
   double* vec_m;           // 64*M doubles: metrics rows
+  double* vec_a;           // 64*(A*K+1) doubles: finished-episode returns staged for the per-wave sum
 };
 
 __host__ __device__ inline size_t lds_board_bytes(int HW) { return ((size_t)64 * HW + 15) / 16 * 16 + 16; }
 __host__ __device__ inline size_t lds_vec_bytes(int A, int K, int M) {
-  return (size_t)64 * 8 * (2 * (A * K > 0 ? A * K : 1) + (M > 0 ? M : 1));   // reward + cumulative + metrics staging
+  return (size_t)64 * 8 * (3 * (A * K > 0 ? A * K : 1) + 1 + (M > 0 ? M : 1));   // reward + cumulative + returns + metrics staging
 }
 __host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M) {
   return TABLE_BYTES + lds_board_bytes(HW) + lds_vec_bytes(A, K, M);
@@ -80,6 +81,7 @@ __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp) {
   l.vec_r = reinterpret_cast<double*>(smem + TABLE_BYTES + lds_board_bytes(sp.HW));
   l.vec_c = l.vec_r + 64 * (sp.A * sp.K > 0 ? sp.A * sp.K : 1);
   l.vec_m = l.vec_c + 64 * (sp.A * sp.K > 0 ? sp.A * sp.K : 1);
+  l.vec_a = l.vec_m + 64 * (sp.M > 0 ? sp.M : 1);
   return l;
 }
 

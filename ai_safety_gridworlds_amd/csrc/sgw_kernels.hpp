@@ -143,8 +143,7 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
 #pragma unroll
     for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
     double discount = __longlong_as_double(0x7ff8000000000000LL);   // None at FIRST
-    bool acc_now = false;
-    double acc_old[F::NU + 1];
+    bool over_now = false;
     if (s.step_type >= ST_LAST) {
       // step after LAST (or before any reset): new episode, action discarded (pycolab_interface_mo.py:175-178)
       F::pre_autoreset(s, a);
@@ -162,23 +161,42 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
       if (over && s.term == TERM_NONE4) s.term = SGW_MAX_STEPS;                   // safety_game.py:294-296
 #pragma unroll
       for (int u = 0; u < F::NU; ++u) s.cum[u] += r[u];                          // safety_game_mo.py:996-997
-      acc_now = a.ep_acc && over;
-      if (acc_now) {   // episodic-return accumulators: this env's own column, no atomics.  The loads are issued
-        // here, all before the first store, and consumed AFTER the output phase: their round trip hides behind it.
-        const double* q = a.ep_acc + env;
+      over_now = over;
+    }
+    // Episodic-return accumulators (end-of-batch all-reduce buffer).  Lanes whose episode just ended stage their
+    // return vector in LDS; lanes 0..A*K then each sum one column over the wave in a FIXED order (deterministic,
+    // no atomics) and add it to this wave's row.  Traffic: one 8-byte RMW per column per WAVE, not per env.
+    const int C = a.sp.A * a.sp.K + 1;
+    bool acc_any = false;
+    double acc_old = 0.0;
+    if (a.ep_acc) {
+      acc_any = __ballot(over_now && real) != 0ull;          // wave-uniform
+      if (acc_any) {
+        if (lane < C) acc_old = a.ep_acc[(long long)blockIdx.x * C + lane];   // consumed after the output phase
 #pragma unroll
-        for (int u = 0; u < F::NU; ++u) if (a.sp.dim_slot[0][u] >= 0) { acc_old[u] = *q; q += a.n_pad; }
-        acc_old[F::NU] = *q;
+        for (int u = 0; u < F::NU; ++u) { int slot = a.sp.dim_slot[0][u]; if (slot >= 0) l.vec_a[lane * C + slot] = over_now ? s.cum[u] : 0.0; }
+        l.vec_a[lane * C + C - 1] = over_now ? 1.0 : 0.0;    // made visible by the output phase's LDS fence
       }
     }
     const bool last_t = (t == TT - 1);
     if (a.write_every != 0 || last_t)
       emit<F>(s, r, discount, a, l, env0, lane, a.write_every != 0 ? (long long)t * a.n_pad : 0, true, true);
-    if (acc_now) {
-      double* col = a.ep_acc + env;
+    if (acc_any) {
+      lds_wave_sync();
+      // lane = part*16 + column: 4 partial sums of 16 rows each (reads batched), combined in a fixed tree
+      const int col = lane & 15, part = lane >> 4;
+      double v[16];
 #pragma unroll
-      for (int u = 0; u < F::NU; ++u) if (a.sp.dim_slot[0][u] >= 0) { *col = acc_old[u] + s.cum[u]; col += a.n_pad; }
-      *col = acc_old[F::NU] + 1.0;
+      for (int j = 0; j < 16; ++j) {
+        const int row = part * 16 + j;
+        v[j] = (col < C && env0 + row < a.n_envs) ? l.vec_a[row * C + col] : 0.0;
+      }
+      double p = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) p += v[j];
+      p += __shfl_xor(p, 16, WAVE);
+      p += __shfl_xor(p, 32, WAVE);
+      if (lane < C) a.ep_acc[(long long)blockIdx.x * C + lane] = acc_old + p;
     }
   }
   F::store(s, a, env);
@@ -198,13 +216,12 @@ __global__ void k_fill_actions(int8_t* out, long long n, int A, int T, unsigned 
   }
 }
 
-// out[c] = sum over real envs of acc[c][env]; one workgroup per column, fixed-order tree => deterministic
-__global__ __launch_bounds__(256) void k_read_returns(double* acc, long long n_pad, long long n_envs, double* out,
-                                                      int clear) {
+// out[c] = sum over waves of acc[wave][c]; one workgroup per column, fixed-order tree => deterministic
+__global__ __launch_bounds__(256) void k_read_returns(double* acc, long long n_waves, int C, double* out, int clear) {
   __shared__ double part[256];
   const int c = blockIdx.x;
   double v = 0.0;
-  for (long long e = threadIdx.x; e < n_envs; e += 256) v += acc[(long long)c * n_pad + e];
+  for (long long w = threadIdx.x; w < n_waves; w += 256) v += acc[w * C + c];
   part[threadIdx.x] = v;
   __syncthreads();
   for (int s2 = 128; s2 > 0; s2 >>= 1) {
@@ -212,7 +229,7 @@ __global__ __launch_bounds__(256) void k_read_returns(double* acc, long long n_p
     __syncthreads();
   }
   if (threadIdx.x == 0) out[c] = part[0];
-  if (clear) for (long long e = threadIdx.x; e < n_pad; e += 256) acc[(long long)c * n_pad + e] = 0.0;
+  if (clear) for (long long w = threadIdx.x; w < n_waves; w += 256) acc[w * C + c] = 0.0;
 }
 
 // (sum of episode returns, #episodes) over envs whose step_type is LAST

@@ -151,7 +151,7 @@ int sgw_rollout(sgw_engine* e, int T, uint64_t seed, int64_t step0, int write_ev
 
 /* End-of-batch episodic returns: out_dev double [A*K + 1] = (sum over finished episodes of the
  * episode return vector, number of finished episodes), summed over this engine's envs in a fixed
- * order (deterministic, no atomics: per-env accumulator columns + a tree reduction).  This is the
+ * order (deterministic, no atomics: per-wave accumulator rows summed in lane order + a tree reduction).  This is the
  * buffer a multi-GPU job all-reduces once per batch.  clear != 0 zeroes the accumulators after. */
 int sgw_read_returns(sgw_engine* e, double* out_dev, int clear, void* stream);
 
