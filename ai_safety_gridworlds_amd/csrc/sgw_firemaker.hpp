@@ -35,7 +35,9 @@
 
 namespace sgw {
 
-struct M5 { uint64_t w[5]; };
+// 320-bit mask as five NAMED words (an array member invites the compiler to turn the select chains below back into
+// indexed loads from a stack copy = scratch traffic in the innermost loops)
+struct M5 { uint64_t a, b, c, d, e; };
 
 struct Firemaker {
   static constexpr int NA = 3;
@@ -71,8 +73,7 @@ struct Firemaker {
     for (int ag = 0; ag < 3; ++ag) { s.row[ag] = (int)((w1 >> (16 * ag)) & 0xff); s.col[ag] = (int)((w1 >> (16 * ag + 8)) & 0xff); }
     s.rng_u32 = (uint32_t)w2; s.episode = (uint32_t)(w2 >> 32);
     s.rs_hi = c.get(); s.rs_lo = c.get(); s.ri_hi = c.get(); s.ri_lo = c.get();
-#pragma unroll
-    for (int i = 0; i < 5; ++i) s.fire.w[i] = c.get();
+    s.fire.a = c.get(); s.fire.b = c.get(); s.fire.c = c.get(); s.fire.d = c.get(); s.fire.e = c.get();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       uint64_t v = c.get();
@@ -93,8 +94,7 @@ struct Firemaker {
     for (int ag = 0; ag < 3; ++ag) w1 |= ((uint64_t)(s.row[ag] & 0xff) << (16 * ag)) | ((uint64_t)(s.col[ag] & 0xff) << (16 * ag + 8));
     c.put(w0); c.put(w1); c.put((uint64_t)s.rng_u32 | ((uint64_t)s.episode << 32));
     c.put(s.rs_hi); c.put(s.rs_lo); c.put(s.ri_hi); c.put(s.ri_lo);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) c.put(s.fire.w[i]);
+    c.put(s.fire.a); c.put(s.fire.b); c.put(s.fire.c); c.put(s.fire.d); c.put(s.fire.e);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       uint64_t v = 0;
@@ -114,8 +114,7 @@ struct Firemaker {
 #pragma unroll
     for (int ag = 0; ag < 3; ++ag) { s.row[ag] = sp.start_cell[ag] / W; s.col[ag] = sp.start_cell[ag] % W; }
     s.episode += 1;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) s.fire.w[i] = 0;
+    s.fire.a = s.fire.b = s.fire.c = s.fire.d = s.fire.e = 0;
 #pragma unroll
     for (int i = 0; i < 15; ++i) s.visits[i] = 0;
 #pragma unroll
@@ -156,38 +155,51 @@ struct Firemaker {
   // ---- 289-bit masks -----------------------------------------------------------------------------
   static __device__ M5 shl(const M5& m, int n) {                   // towards higher bit index, 0 < n < 64
     M5 r;
-    r.w[0] = m.w[0] << n;
-#pragma unroll
-    for (int i = 1; i < 5; ++i) r.w[i] = (m.w[i] << n) | (m.w[i - 1] >> (64 - n));
+    r.a = m.a << n;
+    r.b = (m.b << n) | (m.a >> (64 - n)); r.c = (m.c << n) | (m.b >> (64 - n));
+    r.d = (m.d << n) | (m.c >> (64 - n)); r.e = (m.e << n) | (m.d >> (64 - n));
     return r;
   }
   static __device__ M5 shr(const M5& m, int n) {
     M5 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r.w[i] = (m.w[i] >> n) | (m.w[i + 1] << (64 - n));
-    r.w[4] = m.w[4] >> n;
+    r.a = (m.a >> n) | (m.b << (64 - n)); r.b = (m.b >> n) | (m.c << (64 - n));
+    r.c = (m.c >> n) | (m.d << (64 - n)); r.d = (m.d >> n) | (m.e << (64 - n));
+    r.e = m.e >> n;
     return r;
   }
-  static __device__ M5 or5(const M5& a, const M5& b) { M5 r;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) r.w[i] = a.w[i] | b.w[i];
-    return r; }
-  static __device__ uint64_t word_of(const M5& m, int wi) {         // dynamic word select, no scratch
-    uint64_t v = m.w[0];
-    v = wi == 1 ? m.w[1] : v; v = wi == 2 ? m.w[2] : v; v = wi == 3 ? m.w[3] : v; v = wi == 4 ? m.w[4] : v;
-    return v;
+  static __device__ M5 or5(const M5& x, const M5& y) { M5 r; r.a = x.a | y.a; r.b = x.b | y.b; r.c = x.c | y.c; r.d = x.d | y.d; r.e = x.e | y.e; return r; }
+  // dynamic word select by MASKING, not by `cond ? m.b : v` chains: LLVM turns a select between two loaded struct
+  // fields into one load through a select of ADDRESSES, which pins the masks (and the whole env state) in scratch.
+  static __device__ uint64_t word_of(const M5& m, int wi) {
+    return (m.a & (0ull - (uint64_t)(wi == 0))) | (m.b & (0ull - (uint64_t)(wi == 1))) | (m.c & (0ull - (uint64_t)(wi == 2))) |
+           (m.d & (0ull - (uint64_t)(wi == 3))) | (m.e & (0ull - (uint64_t)(wi == 4)));
+  }
+  static __device__ void or_word(M5& m, int wi, uint64_t bits) {
+    m.a |= wi == 0 ? bits : 0ull; m.b |= wi == 1 ? bits : 0ull; m.c |= wi == 2 ? bits : 0ull;
+    m.d |= wi == 3 ? bits : 0ull; m.e |= wi == 4 ? bits : 0ull;
+  }
+  static __device__ void clear_word(M5& m, int wi, uint64_t bits) {
+    m.a &= wi == 0 ? ~bits : ~0ull; m.b &= wi == 1 ? ~bits : ~0ull; m.c &= wi == 2 ? ~bits : ~0ull;
+    m.d &= wi == 3 ? ~bits : ~0ull; m.e &= wi == 4 ? ~bits : ~0ull;
   }
   static __device__ void set_bit(M5& m, int k, bool on) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i) { uint64_t b = (i == (k >> 6)) ? (1ull << (k & 63)) : 0ull; m.w[i] = on ? (m.w[i] | b) : (m.w[i] & ~b); }
+    const uint64_t bit = 1ull << (k & 63);
+    if (on) or_word(m, k >> 6, bit); else clear_word(m, k >> 6, bit);
   }
   static __device__ bool get_bit(const M5& m, int k) { return (word_of(m, k >> 6) >> (k & 63)) & 1; }
+  // The pre-spread fire mask is constant while the candidates are scanned: park it in LDS ([word][lane], six
+  // words, the last zero) so that the per-row window extraction is two ds_read_b64 instead of two mask-selects.
+  static __device__ void park_mask(const Lds& l, const M5& m) {
+    uint64_t* q = reinterpret_cast<uint64_t*>(l.vec_m) + threadIdx.x;
+    q[0] = m.a; q[64] = m.b; q[128] = m.c; q[192] = m.d; q[256] = m.e; q[320] = 0ull;
+  }
   // 5 consecutive bits starting at bit b (b may be negative at the top-left corner: those bits are walls)
-  static __device__ uint32_t bits5(const M5& m, int b) {
-    if (b < 0) return (uint32_t)(m.w[0] << (-b)) & 31u;
+  static __device__ uint32_t bits5(const Lds& l, int b) {
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(l.vec_m) + threadIdx.x;
+    if (b < 0) return (uint32_t)(q[0] << (-b)) & 31u;
     const int wi = b >> 6, sh = b & 63;
-    uint64_t lo = word_of(m, wi) >> sh;
-    uint64_t hi = (sh > 59 && wi < 4) ? (word_of(m, wi + 1) << (64 - sh)) : 0ull;
+    const uint64_t lo = q[wi * 64] >> sh;
+    const uint64_t hi = sh ? (q[wi * 64 + 64] << (64 - sh)) : 0ull;
     return (uint32_t)(lo | hi) & 31u;
   }
   static __device__ uint64_t pword(const Lds& l, int i) { return (uint64_t)__double_as_longlong(l.params[i]); }
@@ -206,8 +218,10 @@ struct Firemaker {
     M5 hz = or5(or5(src, or5(shl(src, 1), shl(src, 2))), or5(shr(src, 1), shr(src, 2)));
     M5 dil = or5(or5(hz, or5(shl(hz, 17), shl(hz, 34))), or5(shr(hz, 17), shr(hz, 34)));
     M5 cand;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) cand.w[i] = dil.w[i] & ~old.w[i] & pword(l, P_ALLOWED0 + i);
+    cand.a = dil.a & ~old.a & pword(l, P_ALLOWED0 + 0); cand.b = dil.b & ~old.b & pword(l, P_ALLOWED0 + 1);
+    cand.c = dil.c & ~old.c & pword(l, P_ALLOWED0 + 2); cand.d = dil.d & ~old.d & pword(l, P_ALLOWED0 + 3);
+    cand.e = dil.e & ~old.e & pword(l, P_ALLOWED0 + 4);
+    park_mask(l, old);
     const uint32_t valid = (uint32_t)p[P_VALID];
     const int w1c = s.row[0] * W + s.col[0], w2c = s.row[1] * W + s.col[1];
     const bool w1src = ws_active && (s.at_ws & 1), w2src = ws_active && (s.at_ws & 2);
@@ -224,7 +238,7 @@ struct Firemaker {
         for (int dr = -2; dr <= 2; ++dr) {                     // fire sources in row-major order (FM:565-609)
           const int sr = tr + dr;
           if (sr < 0 || sr >= H) continue;
-          uint32_t row5 = bits5(old, sr * W + tc - 2);
+          uint32_t row5 = bits5(l, sr * W + tc - 2);
           const int adr = dr < 0 ? -dr : dr;
           while (row5) {
             const int j = __builtin_ctz(row5);
@@ -244,8 +258,7 @@ struct Firemaker {
         }
         if (cum > 0.0 && random01(s) < cum) lit |= 1ull << b;   // FM:612-615
       }
-#pragma unroll
-      for (int i = 0; i < 5; ++i) s.fire.w[i] |= (i == wi) ? lit : 0ull;
+      or_word(s.fire, wi, lit);
     }
     const double cont = p[P_CONTINUE];
 #pragma nounroll
@@ -257,12 +270,11 @@ struct Firemaker {
         ow &= ow - 1;
         if (!(random01(s) < cont)) out |= 1ull << b;
       }
-#pragma unroll
-      for (int i = 0; i < 5; ++i) s.fire.w[i] &= (i == wi) ? ~out : ~0ull;
+      clear_word(s.fire, wi, out);
     }
-    int n = 0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) n += __builtin_popcountll(s.fire.w[i] & ~pword(l, P_TERR0 + i));
+    const int n = __builtin_popcountll(s.fire.a & ~pword(l, P_TERR0 + 0)) + __builtin_popcountll(s.fire.b & ~pword(l, P_TERR0 + 1)) +
+                  __builtin_popcountll(s.fire.c & ~pword(l, P_TERR0 + 2)) + __builtin_popcountll(s.fire.d & ~pword(l, P_TERR0 + 3)) +
+                  __builtin_popcountll(s.fire.e & ~pword(l, P_TERR0 + 4));
     s.n_ext = n;                                                // FM:624-629
     r[2 * 3 + 1] += (double)n * p[P_SUP_EXT_FIRE];
   }
@@ -288,7 +300,9 @@ struct Firemaker {
     for (int b = 0; b < 3; ++b) { s.row[b] = (b == ag) ? fr : s.row[b]; s.col[b] = (b == ag) ? fc : s.col[b]; }
     // update_reward FM:429-463
     const bool sup = (ag == 2);
-    r[ag * 3 + 0] += (action != 0) ? (sup ? p[P_SUP_MOVE] : p[P_AGENT_MOVE]) : 0.0;
+    const double mv = (action != 0) ? (sup ? p[P_SUP_MOVE] : p[P_AGENT_MOVE]) : 0.0;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) r[b * 3 + 0] += (b == ag) ? mv : 0.0;       // static register indices only
     const int k = fr * W + fc;
     const uint8_t cls = l.aux[k];
     const bool on_fire = get_bit(s.fire, k);
