@@ -329,6 +329,19 @@ int sgw_observe(sgw_engine* e, const uint8_t* board_dev, const uint8_t* rgb_lut_
   return SGW_OK;
 }
 
+int sgw_observe_layers(sgw_engine* e, const uint8_t* board_dev, const uint8_t* layer_chars_dev,
+                       const uint8_t* layer_static_dev, int n_layers, int gap_index, uint8_t* layers_dev, void* stream) {
+  if (!e || !board_dev || !layer_chars_dev || !layer_static_dev || !layers_dev || n_layers < 1 || gap_index >= n_layers)
+    return fail(SGW_ERR_ARG, "sgw_observe_layers: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  long long total = e->n_envs * e->ks.HW;
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(k_observe_layers, dim3(blocks), dim3(256), 0, (hipStream_t)stream, board_dev, e->n_envs, e->ks.HW,
+                     layer_chars_dev, layer_static_dev, n_layers, gap_index, layers_dev);
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
 static ViewSpec make_viewspec(const sgw_engine* e) {
   ViewSpec v; memset(&v, 0, sizeof(v));
   v.A = e->spec.A; v.H = e->spec.H; v.W = e->spec.W;

@@ -254,6 +254,25 @@ __global__ void k_set_rng(uint64_t* state, long long n_pad, long long n, const u
   state[2 * n_pad + e] &= ~0xffffffffull;
 }
 
+// unoccluded layers + gap correction (rendering.py:188-302, observation_distiller_ex.py:164-178); thread per cell
+__global__ void k_observe_layers(const uint8_t* board, long long n, int HW, const uint8_t* chars, const uint8_t* stat,
+                                 int L, int gap, uint8_t* layers) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = n * HW;
+  for (; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i / HW;
+    const int c = (int)(i % HW);
+    const uint8_t ch = board[i] & 0x7f;
+    bool any_other = false;
+    for (int k = 0; k < L; ++k) {
+      const uint8_t st = stat[k * HW + c];
+      const bool on = st == 2 ? (ch == chars[k]) : (st != 0);
+      if (k != gap) { any_other |= on; layers[(e * L + k) * HW + c] = (uint8_t)on; }
+    }
+    if (gap >= 0) layers[(e * L + gap) * HW + c] = (uint8_t)((stat[gap * HW + c] != 0) && !any_other);
+  }
+}
+
 // agent-centric windows of the rendered board (safety_game_moma.py:1996-2101), one thread per output byte
 struct ViewSpec { int A, H, W, total; int off[SGW_MAX_AGENTS], up[SGW_MAX_AGENTS], left[SGW_MAX_AGENTS], vh[SGW_MAX_AGENTS], vw[SGW_MAX_AGENTS]; };
 __global__ void k_agent_views(const uint8_t* board, const uint8_t* pos, long long n, ViewSpec v, uint8_t outside,

@@ -227,6 +227,25 @@ class BatchedEngine(object):
                                   layers.data_ptr() if layer_chars else None, self._stream()), "sgw_observe")
     return out
 
+  def observe_layers(self, board=None):
+    """Unoccluded per-character layers with the gap correction: uint8 [N, L, H, W], L = len(spec.layer_chars)
+    (what the MO/MA envs put in observation['layers']: rendering.py:188-302, observation_distiller_ex.py:164-178)."""
+    sp = self.spec
+    if board is None:
+      board = self._bufs["board"][:self.n_envs]
+    board = board.reshape(-1, sp.H * sp.W).contiguous()
+    if not hasattr(self, "_layer_tables"):
+      chars = torch.tensor([ord(c) for c in sp.layer_chars], dtype=torch.uint8, device=self.device)
+      stat = torch.from_numpy(sp.layer_static()).to(self.device)
+      self._layer_tables = (chars, stat)
+    chars, stat = self._layer_tables
+    L = len(sp.layer_chars)
+    out = torch.empty((self.n_envs, L, sp.H, sp.W), dtype=torch.uint8, device=self.device)
+    gap = sp.layer_chars.index(sp.what_lies_beneath) if sp.what_lies_beneath in sp.layer_chars else -1
+    N.check(self._lib.sgw_observe_layers(self._h, board.data_ptr(), chars.data_ptr(), stat.data_ptr(), L, gap,
+                                         out.data_ptr(), self._stream()), "sgw_observe_layers")
+    return out
+
   def get_state(self):
     words = int(self._lib.sgw_state_words(self._h))
     st = torch.empty((words, self.n_pad), dtype=torch.int64, device=self.device)

@@ -164,7 +164,7 @@ class GridworldGymEnv(_Base):
       info["cumulative_mo_variance"] = np.var(cum.tolist(), ddof=0)
       info["average_mo_variance"] = np.var(avg, ddof=0)
       if self._layers_in_observation:
-        lay = self._env.engine.observe(rgb=False, layer_chars=sp.layer_chars)["layers"][0].cpu().numpy().astype(bool)
+        lay = self._env.engine.observe_layers()[0].cpu().numpy().astype(bool)
         info["info_observation_layers_dict"] = {c: lay[i] for i, c in enumerate(sp.layer_chars)}
     if sp.name == "island_navigation_ex":
       info["safety"] = int(o["safety"])

@@ -144,6 +144,24 @@ class GameSpec(object):
   def n_cells(self):
     return self.H * self.W
 
+  def layer_static(self):
+    """uint8 [L, H*W] for sgw_observe_layers: the static curtain of every layer character (backdrop characters and
+    static drapes: art == c, with sprite start cells reading as what_lies_beneath), 2 for dynamic entities."""
+    flat = "".join(self.art)
+    dynamic = set(self.agent_chars) | set(getattr(self, "dynamic_drapes", ""))
+    backdrop = [self.what_lies_beneath if (c in self.agent_chars or c in self.drape_chars) else c for c in flat]
+    out = np.zeros((len(self.layer_chars), len(flat)), np.uint8)
+    for i, ch in enumerate(self.layer_chars):
+      if ch in dynamic:
+        out[i] = 2
+      elif ch in self.drape_chars:
+        out[i] = [1 if c == ch else 0 for c in flat]
+        if ch in getattr(self, "drape_static_override", {}):
+          out[i] = self.drape_static_override[ch]
+      else:
+        out[i] = [1 if c == ch else 0 for c in backdrop]
+    return out
+
   def rgb_lut(self):
     """uint8 [128, 3]: (colour / 999.0 * 255.0).astype(uint8) per character
     (observation_distiller.py:88-90); characters without a colour map to 0."""
@@ -302,7 +320,7 @@ def _island_spec(kwargs):
                   action_lo=lo, n_actions=n, value_mapping=ISLAND_VALUES, bg_colours=ISLAND_BG,
                   actions=MO_ACTIONS, scalar=False, max_iterations=int(cfg["max_iterations"]), config=cfg,
                   # every drape exists even when its character is absent from the level (island_navigation_ex.py:387-393)
-                  layer_chars=sorted(set(flat) | set(' WDFGSA')), what_lies_beneath=' ', agent_chars=['A'])
+                  layer_chars=sorted(set(flat) | set(' WDFGSA')), what_lies_beneath=' ', agent_chars=['A'], drape_chars='WDFGS')
 
 
 def _boat_ex_spec(kwargs):
@@ -330,7 +348,7 @@ def _boat_ex_spec(kwargs):
                   K=len(dim_names), dim_names=dim_names, M=0, metric_names=[], A=1, action_lo=lo, n_actions=n,
                   value_mapping=BOAT_EX_VALUES, bg_colours=BOAT_EX_BG, actions=MO_ACTIONS, scalar=False,
                   max_iterations=int(cfg["max_iterations"]), config=cfg,
-                  layer_chars=sorted(set(flat) | {' '}), what_lies_beneath=' ', agent_chars=['A'])
+                  layer_chars=sorted(set(flat) | {' '}), what_lies_beneath=' ', agent_chars=['A'], drape_chars='')
 
 
 def _boat_spec(kwargs):
@@ -350,7 +368,7 @@ def _boat_spec(kwargs):
                   dim_names=["reward"], M=0, metric_names=[], A=1, action_lo=lo, n_actions=n,
                   value_mapping=BOAT_VALUES, bg_colours=BOAT_BG, actions=ORIGINAL_ACTIONS, scalar=True,
                   max_iterations=int(cfg["max_iterations"]), config=cfg,
-                  layer_chars=sorted(set(flat) | {' '}), what_lies_beneath=' ', agent_chars=['A'])
+                  layer_chars=sorted(set(flat) | {' '}), what_lies_beneath=' ', agent_chars=['A'], drape_chars='')
 
 
 def _safe_int_spec(kwargs):
@@ -480,7 +498,8 @@ def _firemaker_spec(kwargs):
                   M=16, metric_names=list(FIREMAKER_METRICS), A=3, action_lo=lo, n_actions=n,
                   value_mapping=FIREMAKER_VALUES, bg_colours=FIREMAKER_BG, actions=MO_ACTIONS, scalar=False,
                   max_iterations=int(cfg["max_iterations"]), config=cfg, layer_chars=sorted(set(" #-12BFSW")),
-                  what_lies_beneath=' ', agent_chars=agents, view_shapes=[(v[0] + v[1] + 1, v[2] + v[3] + 1) for v in views])
+                  what_lies_beneath=' ', agent_chars=agents, drape_chars='-WFB', dynamic_drapes='F',
+                  drape_static_override={'-': [1 if t else 0 for t in territory]}, view_shapes=[(v[0] + v[1] + 1, v[2] + v[3] + 1) for v in views])
 
 
 _BUILDERS = {

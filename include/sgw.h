@@ -170,6 +170,14 @@ int sgw_accumulate_returns(sgw_engine* e, const double* cumulative_dev, const ui
 int sgw_observe(sgw_engine* e, const uint8_t* board_dev, const uint8_t* rgb_lut_dev, uint8_t* rgb_dev,
                 const uint8_t* layer_chars_dev, int n_layers, uint8_t* layers_dev, void* stream);
 
+/* Unoccluded observation layers (BaseUnoccludedObservationRenderer, rendering.py:188-302, which the multi-objective
+ * and multi-agent envs use: safety_game_mo_base.py:1157) with the "gap only where every other layer is blank"
+ * correction of the distiller (observation_distiller_ex.py:164-178).  layer_static_dev uint8 [L, H*W]: 0/1 = the
+ * layer's static curtain (backdrop characters, static drapes), 2 = dynamic (sprite / moving drape: board == char).
+ * gap_index = index of the what_lies_beneath layer (-1: no correction).  layers_dev uint8 [N, L, H*W]. */
+int sgw_observe_layers(sgw_engine* e, const uint8_t* board_dev, const uint8_t* layer_chars_dev,
+                       const uint8_t* layer_static_dev, int n_layers, int gap_index, uint8_t* layers_dev, void* stream);
+
 /* Agent-centric observations (get_agent_perspective, safety_game_moma.py:1996-2101): for every env and
  * agent a, the (up+down+1) x (left+right+1) window of the rendered board centred on the agent, cells
  * outside the board filled with `outside_chr`.  views_dev uint8 [N, view_bytes] with agent a's window at

@@ -188,3 +188,17 @@ def test_create_rejects_bad_arguments():
   eng = BatchedEngine(spec, 10)
   with pytest.raises(RuntimeError):
     eng.step(torch.zeros(11, dtype=torch.int8, device="cuda:0"))
+
+
+@pytest.mark.parametrize("name", ["island_L9", "island_L5", "boat_ex_L3", "island_L0"])
+def test_unoccluded_layers_match_fixture(name):
+  """observation['layers'] of the MO envs: raw curtains + gap correction (rendering.py:188-302,
+  observation_distiller_ex.py:164-178), from the rendered board + the spec's static layer tables."""
+  fx, meta = G.load(name)
+  spec = make_spec(meta["family_name"], **meta["kwargs"])
+  n, S = fx["layers"].shape[:2]
+  eng = BatchedEngine(spec, n * S, outputs=("board",))
+  board = torch.from_numpy(fx["board"][:n].reshape(n * S, spec.H, spec.W).copy()).to("cuda:0")
+  got = eng.observe_layers(board).cpu().numpy().astype(bool)
+  assert "".join(spec.layer_chars) == meta["layer_chars"]
+  G.assert_same(name + ".layers", got, fx["layers"].reshape(got.shape))
