@@ -33,12 +33,13 @@ def init(backend=None):
   os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
   os.environ.setdefault("MASTER_PORT", "29500")
   os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  backend = os.environ.get("SGW_DIST_BACKEND", backend)      # rehearsal override (e.g. gloo on a 1-GPU box)
   if backend is None:
     backend = "nccl" if torch.cuda.is_available() else "gloo"
   if not dist.is_initialized():
     if backend == "nccl":
-      torch.cuda.set_device(local_rank)
-      dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+      torch.cuda.set_device(local_device(local_rank))
+      dist.init_process_group("nccl", device_id=local_device(local_rank))
     else:
       dist.init_process_group(backend)
   return dist
@@ -47,14 +48,25 @@ def init(backend=None):
 def allreduce_returns(accum, dist=None):
   """Sum the [A*K + 1] episodic-return accumulators over all ranks (in place); returns the tensor."""
   if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-    dist.all_reduce(accum, op=dist.ReduceOp.SUM)
+    if accum.is_cuda and dist.get_backend() == "gloo":       # gloo reduces host tensors
+      host = accum.cpu()
+      dist.all_reduce(host, op=dist.ReduceOp.SUM)
+      accum.copy_(host)
+    else:
+      dist.all_reduce(accum, op=dist.ReduceOp.SUM)
   return accum
+
+
+def local_device(local_rank):
+  """cuda:<local_rank>, folded onto the visible devices (lets several ranks share one GPU in rehearsals)."""
+  n = torch.cuda.device_count()
+  return torch.device("cuda", local_rank % max(n, 1))
 
 
 def max_over_ranks(value, device, dist=None):
   """max over ranks of a python float (the timed region's wall time)."""
   if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
     return float(value)
-  t = torch.tensor([value], dtype=torch.float64, device=device)
+  t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
   dist.all_reduce(t, op=dist.ReduceOp.MAX)
   return float(t.item())

@@ -119,7 +119,7 @@ def main():
       sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
     a.gpus = world
   dist = parallel.init("nccl") if world > 1 else None
-  device = torch.device("cuda", local_rank)
+  device = parallel.local_device(local_rank)
   torch.cuda.set_device(device)
 
   K, W = a.steps, a.warmup
@@ -146,7 +146,7 @@ def main():
   def barrier():
     torch.cuda.synchronize(device)
     if dist is not None:
-      dist.barrier()
+      dist.barrier()                                    # nccl: on this rank's device; gloo (rehearsal): host
     torch.cuda.synchronize(device)
 
   def run(lo, hi, accumulate):

@@ -202,3 +202,40 @@ def test_unoccluded_layers_match_fixture(name):
   got = eng.observe_layers(board).cpu().numpy().astype(bool)
   assert "".join(spec.layer_chars) == meta["layer_chars"]
   G.assert_same(name + ".layers", got, fx["layers"].reshape(got.shape))
+
+
+@pytest.mark.parametrize("env_name,kw,lo,n", [("island_navigation_ex", dict(level=9), 0, 5),
+                                              ("boat_race_ex", dict(level=3), 0, 5)])
+def test_full_baseline_size_matches_oracle(env_name, kw, lo, n):
+  """BASELINE.json sizes: 65 536 envs, compared directly with the oracle (it finishes in seconds) and through
+  size-independent properties: sharding invariance (two half-size engines keyed by global env id reproduce the
+  full engine) and fused rollout == step loop on the device-generated action stream."""
+  from oracle import oracle as O
+  N_ENVS, T, seed = 65536, 24, 0x5AFE
+  spec = make_spec(env_name, **kw)
+  outs = ("board", "reward", "cumulative", "step_type", "term_reason")
+  full = BatchedEngine(spec, N_ENVS, outputs=outs)
+  full.reset()
+  acts = full.fill_actions(T, seed)
+  host_acts = philox.actions(seed, np.arange(N_ENVS), np.arange(T), lo, n)
+  assert np.array_equal(acts.cpu().numpy(), host_acts)
+  want = O.run_streams(O.make_config(env_name, **kw), host_acts.T.copy(),
+                       fields=["board", "reward", "cumulative", "step_type", "term_reason"], nthreads=16)
+  got = full.step_n(acts, write_every=True)
+  for k in outs:
+    g = got[k].cpu().numpy()                                    # [T, N, ...]
+    w = np.moveaxis(want[k][:, 1:], 0, 1).reshape(g.shape)
+    if k == "term_reason":
+      g = g.astype(np.int16); g[g == 255] = -1
+    assert np.array_equal(g, w), k
+  # sharding invariance
+  halves = [BatchedEngine(spec, N_ENVS // 2, env_id_base=b, outputs=outs) for b in (0, N_ENVS // 2)]
+  ro = []
+  for h in halves:
+    h.reset()
+    ro.append({k: v.clone() for k, v in h.rollout(T, seed, write_every=True).items()})
+  for k in outs:
+    both = torch.cat([ro[0][k], ro[1][k]], dim=1)
+    assert torch.equal(both, got[k]), k
+  ret = sum(h.read_returns() for h in halves)
+  assert ret.abs().sum().item() == 0                              # accumulate was off
