@@ -43,7 +43,24 @@ struct KArgs {
   long long step0;
   int write_every;
   double* ep_acc;            // per-wave episodic-return accumulators [n_pad/64][A*K+1], or nullptr
+#ifdef SGW_STAMPS
+  SGW_STAMP_DECL             // diagnostic build only (tools/diag/stamp_probe.hip): per-wave phase stamps
+#endif
 };
+
+// In-kernel phase stamps: compiled in ONLY by the diagnostic probe (-DSGW_STAMPS); libsgw.so carries none.
+#ifdef SGW_STAMPS
+#define SGW_STAMP(a, k)                                                                          \
+  do {                                                                                           \
+    unsigned long long t_;                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    if (threadIdx.x == 0) (a).sgw_stamps[blockIdx.x * 8 + (k)] = t_;                             \
+  } while (0)
+#else
+#define SGW_STAMP(a, k) do { } while (0)
+#endif
 
 enum { MODE_STEP = 0, MODE_RESET = 1 };
 enum { ST_FIRST = 0, ST_MID = 1, ST_LAST = 2, ST_NONE = 3 };   // ST_NONE: never reset yet

@@ -120,12 +120,14 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
   const long long env_id = a.env_id_base + env;
   const bool real = env < a.n_envs;
 
+  SGW_STAMP(a, 0);
   // issue the level-table loads and the env's state-column loads back to back: one HBM/L2 round trip, not two
   lds_load_tables(smem, a.tables);
   const Lds l = lds_carve(smem, a.sp);
   typename F::State s;
   F::load(s, a, env);
   __syncthreads();
+  SGW_STAMP(a, 1);
 
   if (KIND == K_RESET) {
     const bool m = a.mask ? (real && a.mask[env] != 0) : true;
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
       for (int u = 0; u < F::NU; ++u) s.cum[u] += r[u];                          // safety_game_mo.py:996-997
       over_now = over;
     }
+    SGW_STAMP(a, 2);
     // Episodic-return accumulators (end-of-batch all-reduce buffer).  Lanes whose episode just ended stage their
     // return vector in LDS; lanes 0..A*K then each sum one column over the wave in a FIXED order (deterministic,
     // no atomics) and add it to this wave's row.  Traffic: one 8-byte RMW per column per WAVE, not per env.
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
     const bool last_t = (t == TT - 1);
     if (a.write_every != 0 || last_t)
       emit<F>(s, r, discount, a, l, env0, lane, a.write_every != 0 ? (long long)t * a.n_pad : 0, true, true);
+    SGW_STAMP(a, 3);
     if (acc_any) {
       lds_wave_sync();
       // lane = part*16 + column: 4 partial sums of 16 rows each (reads batched), combined in a fixed tree
@@ -199,8 +203,9 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
       if (lane < C) a.ep_acc[(long long)blockIdx.x * C + lane] = acc_old + p;
     }
   }
+  SGW_STAMP(a, 4);
   F::store(s, a, env);
-
+  SGW_STAMP(a, 5);
 }
 
 // synthetic action stream materialised in HBM: int8 [T, N, A]
