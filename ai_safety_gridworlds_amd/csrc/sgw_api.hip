@@ -329,6 +329,23 @@ int sgw_observe(sgw_engine* e, const uint8_t* board_dev, const uint8_t* rgb_lut_
   return SGW_OK;
 }
 
+int sgw_derived_stats(sgw_engine* e, const double* reward_dev, const double* cumulative_dev, const int32_t* frame_dev,
+                      const int32_t* k_agent, double* stats_dev, void* stream) {
+  if (!e || !reward_dev || !cumulative_dev || !frame_dev || !k_agent || !stats_dev)
+    return fail(SGW_ERR_ARG, "sgw_derived_stats: null argument");
+  AgentK ak; memset(&ak, 0, sizeof(ak));
+  for (int a = 0; a < e->spec.A; ++a) {
+    if (k_agent[a] < 0 || k_agent[a] > e->spec.K) return fail(SGW_ERR_ARG, "sgw_derived_stats: k_agent out of range");
+    ak.k[a] = k_agent[a];
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  const long long total = e->n_envs * e->spec.A;
+  hipLaunchKernelGGL(k_derived_stats, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)stream, reward_dev,
+                     cumulative_dev, frame_dev, e->n_envs, e->spec.A, e->spec.K, ak, stats_dev);
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
 int sgw_observe_layers(sgw_engine* e, const uint8_t* board_dev, const uint8_t* layer_chars_dev,
                        const uint8_t* layer_static_dev, int n_layers, int gap_index, uint8_t* layers_dev, void* stream) {
   if (!e || !board_dev || !layer_chars_dev || !layer_static_dev || !layers_dev || n_layers < 1 || gap_index >= n_layers)

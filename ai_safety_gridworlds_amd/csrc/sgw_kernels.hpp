@@ -259,6 +259,59 @@ __global__ void k_set_rng(uint64_t* state, long long n_pad, long long n, const u
   state[2 * n_pad + e] &= ~0xffffffffull;
 }
 
+// ---- derived statistics (safety_game_mo.py:1027-1084) in numpy's summation order -----------------------------
+// numpy pairwise_sum for a contiguous double array (umath loops): n < 8 sequential; n <= 128 eight accumulators
+// over blocks of 8, tree-combined, remainder added sequentially; larger n split recursively (n2 = n/2 rounded
+// down to a multiple of 8).  Here n <= 256 (K <= 16, K*K outer differences).
+__device__ inline double np_pairwise_block(const double* a, int n) {
+  if (n < 8) { double r = 0.0; for (int i = 0; i < n; ++i) r += a[i]; return r; }
+  double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) { r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3]; r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7]; }
+  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (; i < n; ++i) res += a[i];
+  return res;
+}
+__device__ inline double np_sum(const double* a, int n) {
+  if (n <= 128) return np_pairwise_block(a, n);
+  int n2 = n / 2; n2 -= n2 % 8;
+  return np_sum(a, n2) + np_sum(a + n2, n - n2);
+}
+__device__ inline double np_gini100(const double* v, int k, double* scratch) {   // gini_coefficient(...) * 100
+  if (k == 0) return 0.0;
+  double mn = v[0];
+  for (int i = 1; i < k; ++i) mn = v[i] < mn ? v[i] : mn;                         // python min()
+  double d[SGW_MAX_K];
+  for (int i = 0; i < k; ++i) d[i] = v[i] - mn;
+  for (int i = 0; i < k; ++i) for (int j = 0; j < k; ++j) scratch[i * k + j] = fabs(d[i] - d[j]);
+  const double mad = np_sum(scratch, k * k) / (double)(k * k);
+  const double rel = mad / (np_sum(d, k) / (double)k + 2.220446049250313e-16);
+  return 0.5 * rel * 100.0;
+}
+__device__ inline double np_var(const double* v, int k, double* scratch) {        // np.var(list, ddof=0)
+  const double mean = np_sum(v, k) / (double)k;
+  for (int i = 0; i < k; ++i) { const double x = v[i] - mean; scratch[i] = x * x; }
+  return np_sum(scratch, k) / (double)k;
+}
+struct AgentK { int k[SGW_MAX_AGENTS]; };
+__global__ void k_derived_stats(const double* reward, const double* cumulative, const int* frame, long long n, int A, int K,
+                                AgentK ak, double* stats) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * A) return;
+  const long long e = i / A;
+  const int ag = (int)(i % A), k = ak.k[ag];
+  double r[SGW_MAX_K], c[SGW_MAX_K], avg[SGW_MAX_K], scratch[SGW_MAX_K * SGW_MAX_K];
+  const double denom = (double)(frame[e] + 1);
+  for (int j = 0; j < k; ++j) { r[j] = reward[i * K + j]; c[j] = cumulative[i * K + j]; avg[j] = c[j] / denom; }
+  double* o = stats + i * (5 + K);
+  o[0] = np_gini100(r, k, scratch);
+  o[1] = np_gini100(c, k, scratch);
+  o[2] = np_var(r, k, scratch);
+  o[3] = np_var(c, k, scratch);
+  o[4] = np_var(avg, k, scratch);
+  for (int j = 0; j < K; ++j) o[5 + j] = j < k ? avg[j] : 0.0;
+}
+
 // unoccluded layers + gap correction (rendering.py:188-302, observation_distiller_ex.py:164-178); thread per cell
 __global__ void k_observe_layers(const uint8_t* board, long long n, int HW, const uint8_t* chars, const uint8_t* stat,
                                  int L, int gap, uint8_t* layers) {

@@ -227,6 +227,31 @@ class BatchedEngine(object):
                                   layers.data_ptr() if layer_chars else None, self._stream()), "sgw_observe")
     return out
 
+  def derived_stats(self):
+    """Per-step derived statistics of _process_timestep (safety_game_mo.py:1027-1084) for the last step, on device,
+    in numpy's summation order: dict of float64 tensors gini_index / cumulative_gini_index / mo_variance /
+    cumulative_mo_variance / average_mo_variance [N(, A)] and average_reward [N(, A), K].
+    Needs the 'reward', 'cumulative' and 'frame' outputs."""
+    sp = self.spec
+    for k in ("reward", "cumulative", "frame"):
+      if k not in self._bufs or self._T != 1:
+        raise N.SgwError("derived_stats needs the 'reward', 'cumulative' and 'frame' outputs of a single step")
+    if sp.A > 1:
+      ks = [len(sp.agent_dim_names[c]) for c in sp.agent_chars]
+    else:
+      ks = [sp.K]
+    karr = (C.c_int32 * N.MAX_AGENTS)(*(ks + [0] * (N.MAX_AGENTS - len(ks))))
+    stats = torch.empty((self.n_envs, sp.A, 5 + sp.K), dtype=torch.float64, device=self.device)
+    N.check(self._lib.sgw_derived_stats(self._h, self._bufs["reward"].data_ptr(), self._bufs["cumulative"].data_ptr(),
+                                        self._bufs["frame"].data_ptr(), karr, stats.data_ptr(), self._stream()),
+            "sgw_derived_stats")
+    if sp.A == 1:
+      stats = stats[:, 0]
+    names = ("gini_index", "cumulative_gini_index", "mo_variance", "cumulative_mo_variance", "average_mo_variance")
+    out = {nm: stats[..., i] for i, nm in enumerate(names)}
+    out["average_reward"] = stats[..., 5:]
+    return out
+
   def observe_layers(self, board=None):
     """Unoccluded per-character layers with the gap correction: uint8 [N, L, H, W], L = len(spec.layer_chars)
     (what the MO/MA envs put in observation['layers']: rendering.py:188-302, observation_distiller_ex.py:164-178)."""

@@ -170,6 +170,13 @@ int sgw_accumulate_returns(sgw_engine* e, const double* cumulative_dev, const ui
 int sgw_observe(sgw_engine* e, const uint8_t* board_dev, const uint8_t* rgb_lut_dev, uint8_t* rgb_dev,
                 const uint8_t* layer_chars_dev, int n_layers, uint8_t* layers_dev, void* stream);
 
+/* Derived per-step statistics of _process_timestep (safety_game_mo.py:1027-1084, gini_coefficient 1645-1681),
+ * computed from a step's outputs with numpy's own reduction order (8-accumulator pairwise sums), per env and agent:
+ * stats_dev double [N, A, 5 + K] = (gini_index, cumulative_gini_index, mo_variance, cumulative_mo_variance,
+ * average_mo_variance, average_reward[K]).  k_agent[A] = number of reward dimensions of each agent (<= K). */
+int sgw_derived_stats(sgw_engine* e, const double* reward_dev, const double* cumulative_dev, const int32_t* frame_dev,
+                      const int32_t* k_agent, double* stats_dev, void* stream);
+
 /* Unoccluded observation layers (BaseUnoccludedObservationRenderer, rendering.py:188-302, which the multi-objective
  * and multi-agent envs use: safety_game_mo_base.py:1157) with the "gap only where every other layer is blank"
  * correction of the distiller (observation_distiller_ex.py:164-178).  layer_static_dev uint8 [L, H*W]: 0/1 = the

@@ -239,3 +239,26 @@ def test_full_baseline_size_matches_oracle(env_name, kw, lo, n):
     assert torch.equal(both, got[k]), k
   ret = sum(h.read_returns() for h in halves)
   assert ret.abs().sum().item() == 0                              # accumulate was off
+
+
+@pytest.mark.parametrize("name", ["island_L9", "island_L5", "island_L9_prop", "island_L0", "boat_ex_L3", "boat_ex_L0"])
+def test_derived_statistics_match_fixture(name):
+  """gini x100, the three variances and the average reward, computed ON DEVICE in numpy's
+  reduction order (safety_game_mo.py:1027-1084, 1645-1681) -- bit-exact against the reference's values."""
+  fx, meta = G.load(name)
+  spec = make_spec(meta["family_name"], **meta["kwargs"])
+  E = min(64, fx["actions"].shape[0]); T = 60
+  eng = BatchedEngine(spec, E, outputs=("reward", "cumulative", "frame", "step_type"))
+  acts = torch.from_numpy(np.ascontiguousarray(fx["actions"][:E, :T].T)).to("cuda:0")
+  eng.reset()
+  keys = ("gini_index", "cumulative_gini_index", "mo_variance", "cumulative_mo_variance", "average_mo_variance",
+          "average_reward")
+  rec = {k: [eng.derived_stats()[k].clone()] for k in keys}
+  for t in range(T):
+    eng.step(acts[t])
+    d = eng.derived_stats()
+    for k in keys:
+      rec[k].append(d[k].clone())
+  for k in keys:
+    got = torch.stack(rec[k], dim=1).cpu().numpy()
+    G.assert_same(name + "." + k, got, fx[k][:E, :T + 1])
