@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsgw.so")
 
 MAX_CELLS, MAX_K, MAX_M, MAX_AGENTS, N_PARAMS, ENV_ALIGN = 320, 16, 16, 4, 48, 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ISLAND_NAVIGATION_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INTERRUPTIBILITY, FIREMAKER_EX_MA = range(5)
 FIRST, MID, LAST, DEAD = 0, 1, 2, 3
@@ -38,7 +38,7 @@ class Spec(C.Structure):
 
 
 OUT_FIELDS = ("board", "obs_board", "reward", "cumulative", "step_type", "term_reason",
-              "actual_action", "discount", "hidden", "safety", "metrics", "frame", "agent_pos")
+              "actual_action", "discount", "hidden", "safety", "metrics", "frame", "agent_pos", "agent_flags")
 
 
 class Out(C.Structure):
@@ -85,9 +85,11 @@ def lib():
   L.sgw_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                             C.c_void_p, C.c_void_p]
   L.sgw_derived_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-  L.sgw_observe_layers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+  L.sgw_observe_layers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_void_p]
   L.sgw_view_bytes.argtypes = [C.c_void_p]
   L.sgw_agent_views.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint8, C.c_void_p, C.c_void_p]
+  L.sgw_agent_layer_views.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint8, C.c_void_p, C.c_void_p]
   L.sgw_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   L.sgw_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   if L.sgw_abi_version() != ABI_VERSION:
@@ -104,7 +106,7 @@ EXPORTS = [
     "sgw_abi_version", "sgw_last_error", "sgw_sizeof_spec", "sgw_sizeof_out", "sgw_create",
     "sgw_destroy", "sgw_n_envs", "sgw_n_pad", "sgw_state_bytes", "sgw_set_episode_bits",
     "sgw_set_rng_state", "sgw_reset", "sgw_step", "sgw_step_n", "sgw_rollout", "sgw_read_returns", "sgw_fill_actions",
-    "sgw_accumulate_returns", "sgw_observe", "sgw_derived_stats", "sgw_observe_layers", "sgw_view_bytes", "sgw_agent_views", "sgw_state_words", "sgw_get_state", "sgw_set_state"]
+    "sgw_accumulate_returns", "sgw_observe", "sgw_derived_stats", "sgw_observe_layers", "sgw_view_bytes", "sgw_agent_views", "sgw_agent_layer_views", "sgw_state_words", "sgw_get_state", "sgw_set_state"]
 
 
 def check(rc, what=""):

@@ -251,6 +251,8 @@ static void offset_out(sgw_out& o, const sgw_spec& sp, long long n_pad, long lon
   if (o.safety) o.safety += r;
   if (o.metrics) o.metrics += r * M;
   if (o.frame) o.frame += r;
+  if (o.agent_pos) o.agent_pos += r * A * 2;
+  if (o.agent_flags) o.agent_flags += r * A;
 }
 
 int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out,
@@ -347,14 +349,18 @@ int sgw_derived_stats(sgw_engine* e, const double* reward_dev, const double* cum
 }
 
 int sgw_observe_layers(sgw_engine* e, const uint8_t* board_dev, const uint8_t* layer_chars_dev,
-                       const uint8_t* layer_static_dev, int n_layers, int gap_index, uint8_t* layers_dev, void* stream) {
+                       const uint8_t* layer_static_dev, int n_layers, int gap_index, const uint8_t* agent_pos_dev,
+                       const uint8_t* agent_flags_dev, int hidden_layer, uint8_t* layers_dev, void* stream) {
+  if ((agent_pos_dev == nullptr) != (agent_flags_dev == nullptr) || hidden_layer >= n_layers)
+    return fail(SGW_ERR_ARG, "sgw_observe_layers: agent_pos/agent_flags/hidden_layer mismatch");
   if (!e || !board_dev || !layer_chars_dev || !layer_static_dev || !layers_dev || n_layers < 1 || gap_index >= n_layers)
     return fail(SGW_ERR_ARG, "sgw_observe_layers: bad argument");
   HIP_TRY(hipSetDevice(e->device));
   long long total = e->n_envs * e->ks.HW;
   int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(k_observe_layers, dim3(blocks), dim3(256), 0, (hipStream_t)stream, board_dev, e->n_envs, e->ks.HW,
-                     layer_chars_dev, layer_static_dev, n_layers, gap_index, layers_dev);
+                     e->ks.W, layer_chars_dev, layer_static_dev, n_layers, gap_index, agent_pos_dev, agent_flags_dev,
+                     e->spec.A, agent_pos_dev ? hidden_layer : -1, layers_dev);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }
@@ -387,6 +393,21 @@ int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agen
   int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   hipLaunchKernelGGL(k_agent_views, dim3(blocks), dim3(256), 0, (hipStream_t)stream, board_dev, agent_pos_dev,
                      e->n_envs, v, outside_chr, views_dev);
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
+int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_t* agent_pos_dev,
+                          const uint8_t* layer_chars_dev, int n_layers, uint8_t outside_chr, uint8_t* out_dev, void* stream) {
+  if (!e || !layers_dev || !agent_pos_dev || !layer_chars_dev || !out_dev || n_layers < 1)
+    return fail(SGW_ERR_ARG, "sgw_agent_layer_views: bad argument");
+  ViewSpec v = make_viewspec(e);
+  if (v.total <= 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_agent_layer_views: the spec defines no agent views");
+  HIP_TRY(hipSetDevice(e->device));
+  long long total = e->n_envs * (long long)v.total * n_layers;
+  int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+  hipLaunchKernelGGL(k_agent_layer_views, dim3(blocks), dim3(256), 0, (hipStream_t)stream, layers_dev, agent_pos_dev,
+                     e->n_envs, v, layer_chars_dev, n_layers, outside_chr, out_dev);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }

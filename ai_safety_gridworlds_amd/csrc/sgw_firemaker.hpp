@@ -389,6 +389,8 @@ struct Firemaker {
   static __device__ int safety(const State& s) { return s.n_ext; }
   static __device__ int actual(const State&, int) { return -1; }
   static __device__ void agent_pos(const State& s, int ag, int& r, int& c) { r = s.row[ag]; c = s.col[ag]; }
+  // fire can spread under an agent (FM:580-582 is a no-op); the sprite hides it in the board but not in the layers
+  static __device__ int agent_flags(const State& s, int ag) { return get_bit(s.fire, s.row[ag] * W + s.col[ag]) ? 1 : 0; }
 };
 
 }  // namespace sgw

@@ -99,6 +99,10 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
         o.agent_pos[(row * F::NA + ag) * 2] = (uint8_t)pr; o.agent_pos[(row * F::NA + ag) * 2 + 1] = (uint8_t)pc;
       }
     }
+    if (o.agent_flags) {
+#pragma unroll
+      for (int ag = 0; ag < F::NA; ++ag) o.agent_flags[row * F::NA + ag] = (uint8_t)F::agent_flags(s, ag);
+    }
     if (o.discount) o.discount[row] = discount;
     if (o.hidden) o.hidden[row] = F::hidden(s);
     if (o.safety) o.safety[row] = F::safety(s);
@@ -313,8 +317,8 @@ __global__ void k_derived_stats(const double* reward, const double* cumulative, 
 }
 
 // unoccluded layers + gap correction (rendering.py:188-302, observation_distiller_ex.py:164-178); thread per cell
-__global__ void k_observe_layers(const uint8_t* board, long long n, int HW, const uint8_t* chars, const uint8_t* stat,
-                                 int L, int gap, uint8_t* layers) {
+__global__ void k_observe_layers(const uint8_t* board, long long n, int HW, int W, const uint8_t* chars, const uint8_t* stat,
+                                 int L, int gap, const uint8_t* pos, const uint8_t* flags, int A, int hidden, uint8_t* layers) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = n * HW;
   for (; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -324,7 +328,10 @@ __global__ void k_observe_layers(const uint8_t* board, long long n, int HW, cons
     bool any_other = false;
     for (int k = 0; k < L; ++k) {
       const uint8_t st = stat[k * HW + c];
-      const bool on = st == 2 ? (ch == chars[k]) : (st != 0);
+      bool on = st == 2 ? (ch == chars[k]) : (st != 0);
+      if (k == hidden && pos)
+        for (int ag = 0; ag < A; ++ag)
+          on |= (flags[e * A + ag] & 1) && ((int)pos[(e * A + ag) * 2] * W + (int)pos[(e * A + ag) * 2 + 1] == c);
       if (k != gap) { any_other |= on; layers[(e * L + k) * HW + c] = (uint8_t)on; }
     }
     if (gap >= 0) layers[(e * L + gap) * HW + c] = (uint8_t)((stat[gap * HW + c] != 0) && !any_other);
@@ -346,6 +353,26 @@ __global__ void k_agent_views(const uint8_t* board, const uint8_t* pos, long lon
     const int vr = b / v.vw[ag], vc = b % v.vw[ag];
     const int r = (int)pos[(e * v.A + ag) * 2] - v.up[ag] + vr, c = (int)pos[(e * v.A + ag) * 2 + 1] - v.left[ag] + vc;
     views[i] = (r < 0 || r >= v.H || c < 0 || c >= v.W) ? outside : board[e * (v.H * v.W) + r * v.W + c];
+  }
+}
+
+// per-layer agent windows: out[e][agent][layer][vr][vc]
+__global__ void k_agent_layer_views(const uint8_t* layers, const uint8_t* pos, long long n, ViewSpec v, const uint8_t* chars,
+                                    int L, uint8_t outside, uint8_t* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per_env = (long long)v.total * L, total = n * per_env;
+  for (; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i / per_env;
+    int b = (int)(i % per_env), ag = 0;
+#pragma unroll
+    for (int k = 1; k < SGW_MAX_AGENTS; ++k) if (k < v.A && b >= v.off[k] * L) ag = k;
+    b -= v.off[ag] * L;
+    const int cells = v.vh[ag] * v.vw[ag];
+    const int li = b / cells, c2 = b % cells;
+    const int vr = c2 / v.vw[ag], vc = c2 % v.vw[ag];
+    const int r = (int)pos[(e * v.A + ag) * 2] - v.up[ag] + vr, c = (int)pos[(e * v.A + ag) * 2 + 1] - v.left[ag] + vc;
+    out[i] = (r < 0 || r >= v.H || c < 0 || c >= v.W) ? (uint8_t)(chars[li] == outside)
+                                                     : layers[(e * L + li) * (v.H * v.W) + r * v.W + c];
   }
 }
 

@@ -102,6 +102,7 @@ struct SafeInt {
   static __device__ uint32_t board_dword(const State&, const KSpec&, const Lds&, int) { return 0; }
   static __device__ int actual(const State& s, int) { return s.actual; }
   static __device__ void agent_pos(const State& s, int, int& r, int& c) { r = s.row; c = s.col; }
+  static __device__ int agent_flags(const State&, int) { return 0; }
   static __device__ const uint8_t* board_layers(const State& s, const KSpec& sp, const Lds& l, int (&cells)[1],
                                                 uint8_t (&chars)[1]) {
     cells[0] = s.row * sp.W + s.col; chars[0] = 'A';

@@ -28,6 +28,7 @@ def _dtype_shape(spec, name):
       "actual_action": (torch.int8, (A,)), "discount": (torch.float64, ()),
       "hidden": (torch.float64, ()), "safety": (torch.int32, ()),
       "metrics": (torch.float64, (M,)), "frame": (torch.int32, ()), "agent_pos": (torch.uint8, (A * 2,)),
+      "agent_flags": (torch.uint8, (A,)),
   }[name]
 
 
@@ -204,6 +205,25 @@ class BatchedEngine(object):
       off += h * w
     return out
 
+  def agent_layer_views(self, layers=None, agent_pos=None, outside_chr='#'):
+    """Per-agent crops of every observation layer (safety_game_moma.py:430-525): list over agents of uint8
+    [N, L, h_a, w_a] tensors -- the per-agent layer cube the Zoo wrapper exposes."""
+    sp = self.spec
+    if layers is None:
+      layers = self.observe_layers()
+    agent_pos = self._bufs["agent_pos"] if agent_pos is None else agent_pos
+    L = len(sp.layer_chars)
+    chars, _ = self._layer_tables
+    vb = int(self._lib.sgw_view_bytes(self._h))
+    out = torch.empty((self.n_envs, vb * L), dtype=torch.uint8, device=self.device)
+    N.check(self._lib.sgw_agent_layer_views(self._h, layers.data_ptr(), agent_pos.data_ptr(), chars.data_ptr(), L,
+                                            ord(outside_chr), out.data_ptr(), self._stream()), "sgw_agent_layer_views")
+    res, off = [], 0
+    for (h, w) in sp.view_shapes:
+      res.append(out[:, off:off + L * h * w].reshape(self.n_envs, L, h, w))
+      off += L * h * w
+    return res
+
   def observe(self, board=None, rgb=True, layer_chars=None):
     """RGB uint8 [N, 3, H, W] and/or occluded layers uint8 [N, L, H, W] of a rendered ascii board."""
     if board is None:
@@ -252,7 +272,7 @@ class BatchedEngine(object):
     out["average_reward"] = stats[..., 5:]
     return out
 
-  def observe_layers(self, board=None):
+  def observe_layers(self, board=None, agent_pos=None, agent_flags=None):
     """Unoccluded per-character layers with the gap correction: uint8 [N, L, H, W], L = len(spec.layer_chars)
     (what the MO/MA envs put in observation['layers']: rendering.py:188-302, observation_distiller_ex.py:164-178)."""
     sp = self.spec
@@ -267,8 +287,17 @@ class BatchedEngine(object):
     L = len(sp.layer_chars)
     out = torch.empty((self.n_envs, L, sp.H, sp.W), dtype=torch.uint8, device=self.device)
     gap = sp.layer_chars.index(sp.what_lies_beneath) if sp.what_lies_beneath in sp.layer_chars else -1
+    hidden = getattr(sp, "hidden_layer_char", None)
+    pp = fp = None
+    hidx = -1
+    if hidden is not None:                       # a dynamic drape that can lie under a sprite (firemaker fire)
+      if agent_pos is None and "agent_pos" in self._bufs and "agent_flags" in self._bufs:
+        agent_pos, agent_flags = self._bufs["agent_pos"], self._bufs["agent_flags"]
+      if agent_pos is None or agent_flags is None:
+        raise N.SgwError("observe_layers: this family needs the 'agent_pos' and 'agent_flags' outputs")
+      pp, fp, hidx = agent_pos.data_ptr(), agent_flags.data_ptr(), sp.layer_chars.index(hidden)
     N.check(self._lib.sgw_observe_layers(self._h, board.data_ptr(), chars.data_ptr(), stat.data_ptr(), L, gap,
-                                         out.data_ptr(), self._stream()), "sgw_observe_layers")
+                                         pp, fp, hidx, out.data_ptr(), self._stream()), "sgw_observe_layers")
     return out
 
   def get_state(self):

@@ -498,7 +498,7 @@ def _firemaker_spec(kwargs):
                   M=16, metric_names=list(FIREMAKER_METRICS), A=3, action_lo=lo, n_actions=n,
                   value_mapping=FIREMAKER_VALUES, bg_colours=FIREMAKER_BG, actions=MO_ACTIONS, scalar=False,
                   max_iterations=int(cfg["max_iterations"]), config=cfg, layer_chars=sorted(set(" #-12BFSW")),
-                  what_lies_beneath=' ', agent_chars=agents, drape_chars='-WFB', dynamic_drapes='F',
+                  what_lies_beneath=' ', agent_chars=agents, drape_chars='-WFB', dynamic_drapes='F', hidden_layer_char='F',
                   drape_static_override={'-': [1 if t else 0 for t in territory]}, view_shapes=[(v[0] + v[1] + 1, v[2] + v[3] + 1) for v in views])
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SGW_ABI_VERSION 2
+#define SGW_ABI_VERSION 3
 #define SGW_MAX_CELLS 320      /* >= 17*17 */
 #define SGW_MAX_K 16           /* reward dimensions per agent */
 #define SGW_MAX_M 16           /* metrics per env */
@@ -95,6 +95,7 @@ typedef struct sgw_out {
   double* metrics;       /* [N_pad, M]    metrics_dict values in METRICS_LABELS order */
   int32_t* frame;        /* [N_pad]       the_plot.frame */
   uint8_t* agent_pos;    /* [N_pad, A, 2] (row, col) of every agent sprite */
+  uint8_t* agent_flags;  /* [N_pad, A]    bit0: a dynamic drape (firemaker: fire) lies hidden under this agent */
 } sgw_out;
 
 typedef struct sgw_engine sgw_engine;
@@ -181,9 +182,12 @@ int sgw_derived_stats(sgw_engine* e, const double* reward_dev, const double* cum
  * and multi-agent envs use: safety_game_mo_base.py:1157) with the "gap only where every other layer is blank"
  * correction of the distiller (observation_distiller_ex.py:164-178).  layer_static_dev uint8 [L, H*W]: 0/1 = the
  * layer's static curtain (backdrop characters, static drapes), 2 = dynamic (sprite / moving drape: board == char).
- * gap_index = index of the what_lies_beneath layer (-1: no correction).  layers_dev uint8 [N, L, H*W]. */
+ * gap_index = index of the what_lies_beneath layer (-1: no correction).  layers_dev uint8 [N, L, H*W].
+ * A dynamic drape hidden under a sprite (fire that spread under an agent) is invisible in the board: pass the
+ * step's agent_pos / agent_flags outputs and hidden_layer = that drape's layer index (else NULL, NULL, -1). */
 int sgw_observe_layers(sgw_engine* e, const uint8_t* board_dev, const uint8_t* layer_chars_dev,
-                       const uint8_t* layer_static_dev, int n_layers, int gap_index, uint8_t* layers_dev, void* stream);
+                       const uint8_t* layer_static_dev, int n_layers, int gap_index, const uint8_t* agent_pos_dev,
+                       const uint8_t* agent_flags_dev, int hidden_layer, uint8_t* layers_dev, void* stream);
 
 /* Agent-centric observations (get_agent_perspective, safety_game_moma.py:1996-2101): for every env and
  * agent a, the (up+down+1) x (left+right+1) window of the rendered board centred on the agent, cells
@@ -192,6 +196,12 @@ int sgw_observe_layers(sgw_engine* e, const uint8_t* board_dev, const uint8_t* l
 int sgw_view_bytes(const sgw_engine* e);
 int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agent_pos_dev, uint8_t outside_chr,
                     uint8_t* views_dev, void* stream);
+
+/* The same agent-centric windows for every observation LAYER (agent_perspectives_with_layers,
+ * safety_game_moma.py:430-525): layers_dev uint8 [N, L, H*W] (sgw_observe_layers), out uint8 [N, L * view_bytes]
+ * laid out per env as agent-major [agent][layer][h][w]; cells outside the board read (layer char == outside_chr). */
+int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_t* agent_pos_dev,
+                          const uint8_t* layer_chars_dev, int n_layers, uint8_t outside_chr, uint8_t* out_dev, void* stream);
 
 /* Raw SoA state copy-out / copy-in (tests, checkpointing): uint64 [words][N_pad]. */
 int sgw_state_words(const sgw_engine* e);

@@ -54,6 +54,7 @@ def main():
   for name in only:
     kw, E, T = CONFIGS[name]
     A, K, S = 3, 3, T + 1
+    NL, LAYER_CHARS = 2, sorted(" #-12BFSW")
     agents = ['1', '2', 'S']
     acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(A)], axis=-1)  # [T,E,A]
     rec = dict(
@@ -64,7 +65,10 @@ def main():
         frame=np.zeros((E, S), np.int32), board=np.zeros((E, S, 17, 17), np.uint8), metrics=np.zeros((E, S, 16)),
         pos=np.zeros((E, S, A, 2), np.int32), rng=np.zeros((E, S, 4), np.uint64), rng_has_uint32=np.zeros((E, S), np.uint8),
         rng_uinteger=np.zeros((E, S), np.uint32), view_worker=np.zeros((E, S, 2, 5, 5), np.uint8),
-        view_supervisor=np.zeros((E, S, 33, 33), np.uint8), obs_board=np.zeros((E, S, 17, 17), np.float32))
+        view_supervisor=np.zeros((E, S, 33, 33), np.uint8), obs_board=np.zeros((E, S, 17, 17), np.float32),
+        # observation['layers'] (unoccluded + gap correction) and the per-agent crops of every layer, first NL streams
+        layers=np.zeros((NL, S, 9, 17, 17), bool), agent_layers_worker=np.zeros((NL, S, 2, 9, 5, 5), bool),
+        agent_layers_supervisor=np.zeros((NL, S, 9, 33, 33), bool))
     t0 = time.time()
     labels = None
     for e in range(E):
@@ -113,6 +117,17 @@ def main():
             rec["view_worker"][e, t, ai] = view
           else:
             rec["view_supervisor"][e, t] = view
+        if e < NL:
+          for li, c in enumerate(LAYER_CHARS):
+            rec["layers"][e, t, li] = ts.observation["layers"][c]
+          per = env.agent_perspectives_with_layers(ts.observation, include_layers=True, board=False, ascii=True)
+          for ai, ch in enumerate(agents):
+            for li, c in enumerate(LAYER_CHARS):
+              lay = per[ch]["layers"][c]
+              if ai < 2:
+                rec["agent_layers_worker"][e, t, ai, li] = lay
+              else:
+                rec["agent_layers_supervisor"][e, t, li] = lay
 
       ts = env.reset()
       if labels is None:
@@ -124,7 +139,7 @@ def main():
         record(t + 1, ts)
     dt = time.time() - t0
     meta = dict(name=name, family="firemaker_ex_ma", kwargs=repr(sorted(kw.items())), E=E, T=T, seed=SEED,
-                metric_labels="|".join(labels), reference_rounds_per_s=E * T / dt)
+                metric_labels="|".join(labels), reference_rounds_per_s=E * T / dt, layer_chars="".join(LAYER_CHARS))
     rec.update({"meta_" + k: np.array(v) for k, v in meta.items()})
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
     print("%-24s E=%d T=%d  %.0f ref rounds/s  fires(max cells)=%d  episodes=%d" % (

@@ -12,7 +12,7 @@ from tests import golden_util as G
 pytestmark = pytest.mark.gpu
 
 OUTS = ("board", "reward", "cumulative", "step_type", "term_reason", "discount", "metrics", "frame", "agent_pos",
-        "safety", "obs_board")
+        "safety", "obs_board", "agent_flags")
 
 
 def run(spec, actions, rng_states):
@@ -52,6 +52,13 @@ def check(name, got, want):
   G.assert_same(name + ".pos", got["agent_pos"], want["pos"])
   tr = got["term_reason"].astype(np.int16); tr[tr == 255] = -1
   G.assert_same(name + ".term_reason", tr, want["term_reason"][..., 0])
+  if "layers" in getattr(want, "files", []):      # fire hidden under an agent sprite, from the engine state
+    nl = want["layers"].shape[0]
+    Fi = sorted(" #-12BFSW").index('F')
+    for a in range(3):
+      p = want["pos"][:nl, :, a]
+      hid = np.take_along_axis(want["layers"][:, :, Fi].reshape(nl, -1, 289), (p[..., 0] * 17 + p[..., 1])[..., None], axis=2)[..., 0]
+      G.assert_same(name + ".agent_flags%d" % a, got["agent_flags"][:nl, :, a], hid.astype(np.uint8))
   G.assert_same(name + ".view_worker", np.stack([got["views"][0], got["views"][1]], axis=2), want["view_worker"])
   G.assert_same(name + ".view_supervisor", got["views"][2], want["view_supervisor"])
   G.assert_same(name + ".rng", got["rng_final"], want["rng"][:, -1])
@@ -108,3 +115,28 @@ def test_firemaker_needs_rng_and_rollout_matches_steps():
   for k in per:
     assert torch.equal(torch.stack(per[k]), ro[k]), k
   assert torch.equal(a.get_state()[:, :n], b.get_state()[:, :n])
+
+
+def test_firemaker_layers_and_agent_layer_cubes_match_fixture():
+  """observation['layers'] and the per-agent crops of every layer (agent_perspectives_with_layers,
+  safety_game_moma.py:430-525) from the rendered board + agent positions."""
+  fx, meta = G.load("firemaker_L0_maxit60")
+  spec = make_spec("firemaker_ex_ma", **meta["kwargs"])
+  assert "".join(spec.layer_chars) == meta["layer_chars"]
+  nl, S = fx["layers"].shape[:2]
+  eng = BatchedEngine(spec, nl * S, outputs=("board", "agent_pos"))
+  board = torch.from_numpy(fx["board"][:nl].reshape(nl * S, 17, 17).copy()).to("cuda:0")
+  pos = torch.from_numpy(fx["pos"][:nl].reshape(nl * S, 3, 2).astype(np.uint8)).to("cuda:0")
+  # fire hidden under an agent: in the fixture it is exactly (layer F at the agent's cell)
+  fl = np.zeros((nl * S, 3), np.uint8)
+  Fi = spec.layer_chars.index('F')
+  fxl = fx["layers"].reshape(nl * S, 9, 17, 17); fxp = fx["pos"][:nl].reshape(nl * S, 3, 2)
+  for i in range(nl * S):
+    for a in range(3):
+      fl[i, a] = fxl[i, Fi, fxp[i, a, 0], fxp[i, a, 1]]
+  layers = eng.observe_layers(board, pos, torch.from_numpy(fl).to("cuda:0"))
+  G.assert_same("layers", layers.cpu().numpy().astype(bool), fx["layers"].reshape(nl * S, 9, 17, 17))
+  cubes = eng.agent_layer_views(layers, pos)
+  G.assert_same("worker1", cubes[0].cpu().numpy().astype(bool), fx["agent_layers_worker"][:, :, 0].reshape(nl * S, 9, 5, 5))
+  G.assert_same("worker2", cubes[1].cpu().numpy().astype(bool), fx["agent_layers_worker"][:, :, 1].reshape(nl * S, 9, 5, 5))
+  G.assert_same("supervisor", cubes[2].cpu().numpy().astype(bool), fx["agent_layers_supervisor"].reshape(nl * S, 9, 33, 33))
