@@ -77,11 +77,12 @@ struct Lds {
   double* vec_c;           // 64*A*K doubles: cumulative rows
   double* vec_m;           // 64*M doubles: metrics rows
   double* vec_a;           // 64*(A*K+1) doubles: finished-episode returns staged for the per-wave sum
+  double* trash;           // 64 doubles: where writes of not-enabled reward dimensions / absent metrics land (branch-free)
 };
 
 __host__ __device__ inline size_t lds_board_bytes(int HW) { return ((size_t)64 * HW + 15) / 16 * 16 + 16; }
 __host__ __device__ inline size_t lds_vec_bytes(int A, int K, int M) {
-  return (size_t)64 * 8 * (3 * (A * K > 0 ? A * K : 1) + 1 + (M > 0 ? M : 1));   // reward + cumulative + returns + metrics staging
+  return (size_t)64 * 8 * (3 * (A * K > 0 ? A * K : 1) + 1 + (M > 0 ? M : 1) + 1);   // reward + cumulative + returns + metrics staging + trash
 }
 __host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M) {
   return TABLE_BYTES + lds_board_bytes(HW) + lds_vec_bytes(A, K, M);
@@ -99,6 +100,7 @@ __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp) {
   l.vec_c = l.vec_r + 64 * (sp.A * sp.K > 0 ? sp.A * sp.K : 1);
   l.vec_m = l.vec_c + 64 * (sp.A * sp.K > 0 ? sp.A * sp.K : 1);
   l.vec_a = l.vec_m + 64 * (sp.M > 0 ? sp.M : 1);
+  l.trash = l.vec_a + 64 * (sp.A * sp.K + 1);
   return l;
 }
 
@@ -117,6 +119,12 @@ __device__ inline void lds_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Row element `slot` of this lane's staging row, or the lane's trash cell when the dimension is not enabled: one
+// unconditional ds_write instead of a scalar branch around it (a taken/untaken branch costs a lone wave ~20 cycles).
+__device__ inline double* stage_cell(double* region, double* trash, int lane, int row_len, int slot) {
+  return slot >= 0 ? region + lane * row_len + slot : trash + lane;
 }
 
 // ---- Philox-4x32-10 (same stream as ai_safety_gridworlds_amd/philox.py) ---------------------
@@ -167,6 +175,15 @@ struct Cursor {
   __device__ void put(uint64_t v) { *p = v; p += stride; }
   __device__ void putf(double v) { put((uint64_t)__double_as_longlong(v)); }
   __device__ void skip(int n) { p += stride * n; }
+  // conditional (wave-uniform) column access without a branch: a disabled slot reads the env's word 0 (always valid)
+  // and contributes `fallback`; an enabled one advances the cursor.  Stores to a disabled slot are skipped by
+  // pointing them at `trash` (a per-env scratch column the caller owns).
+  __device__ double getf_if(bool on, const uint64_t* dummy, double fallback) {
+    const uint64_t* q = on ? p : dummy;
+    const double v = __longlong_as_double((long long)*q);
+    p += on ? stride : 0;
+    return on ? v : fallback;
+  }
 };
 
 // ---- cooperative (wave-wide) env-major output stores -----------------------------------------
@@ -176,12 +193,17 @@ __device__ inline void coop_store(void* dst, long long env0, int row_bytes, cons
   uint4* g = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(dst) + env0 * row_bytes);
   const uint4* s = reinterpret_cast<const uint4*>(lds_src);
   const int nchunk = 4 * row_bytes;               // 64 * row_bytes / 16
-  int c = threadIdx.x;
-  for (; c + 3 * WAVE < nchunk; c += 4 * WAVE) {  // 4 LDS reads in flight, then 4 stores: one LDS wait per batch
-    const uint4 v0 = s[c], v1 = s[c + WAVE], v2 = s[c + 2 * WAVE], v3 = s[c + 3 * WAVE];
-    g[c] = v0; g[c + WAVE] = v1; g[c + 2 * WAVE] = v2; g[c + 3 * WAVE] = v3;
+  // batches of 4 chunks per lane: the 4 LDS reads are unconditional (index clamped) so they issue back to back;
+  // only the stores are guarded
+  for (int base = threadIdx.x; base < nchunk; base += 4 * WAVE) {
+    const int last = nchunk - 1;
+    const int c0 = base, c1 = base + WAVE, c2 = base + 2 * WAVE, c3 = base + 3 * WAVE;
+    const uint4 v0 = s[c0], v1 = s[c1 < last ? c1 : last], v2 = s[c2 < last ? c2 : last], v3 = s[c3 < last ? c3 : last];
+    g[c0] = v0;
+    if (c1 < nchunk) g[c1] = v1;
+    if (c2 < nchunk) g[c2] = v2;
+    if (c3 < nchunk) g[c3] = v3;
   }
-  for (; c < nchunk; c += WAVE) g[c] = s[c];
 }
 // Slow path (masked reset): each lane copies only its own row.
 __device__ inline void lane_store(void* dst, long long env, int row_bytes, const void* lds_src, int lane) {

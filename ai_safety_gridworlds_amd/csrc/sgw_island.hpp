@@ -64,7 +64,7 @@ struct Island {
     s.d_avail = c.getf(); s.f_avail = c.getf();
     s.d_frac = c.getf(); s.f_frac = c.getf();
 #pragma unroll
-    for (int u = 0; u < NU; ++u) s.cum[u] = (a.sp.dim_slot[0][u] >= 0) ? c.getf() : 0.0;   // slots ascend with u
+    for (int u = 0; u < NU; ++u) s.cum[u] = c.getf_if(a.sp.dim_slot[0][u] >= 0, a.state + env, 0.0);   // slots ascend with u
   }
 
   static __device__ void store(const State& s, const KArgs& a, long long env) {
@@ -105,7 +105,13 @@ struct Island {
                                 long long env) {
     const int action = actions[0];
     const KSpec& sp = a.sp;
-    const double* p = l.params;
+    // all family constants in one batch of LDS reads (one wait) instead of a read + wait at every use
+    double p[P_COUNT];
+#pragma unroll
+    for (int i = 0; i < P_COUNT / 2; ++i) {
+      const double2 v = reinterpret_cast<const double2*>(l.params)[i];
+      p[2 * i] = v.x; p[2 * i + 1] = v.y;
+    }
     const int W = sp.W;
     const bool oversat = (sp.flags & F_OVERSAT) != 0, prop = (sp.flags & F_PROP) != 0;
     const bool death = (sp.flags & F_DEATH) != 0, sustain = (sp.flags & F_SUSTAIN) != 0;
@@ -184,7 +190,11 @@ struct Island {
       const bool k = (pend & 1) == 0;                          // false: drink, true: food
       const double base = (k ? (s.f_avail + s.f_frac) : (s.d_avail + s.d_frac)) + 1.0;
       const double lim = k ? p[P_F_GROWTH_LIMIT] : p[P_D_GROWTH_LIMIT];
+#ifdef SGW_EXP_NOPOW   // diagnostic probe only: how much of `play` is the regrowth pow?
+      const double x = fmin(lim, base * e);
+#else
       const double x = fmin(lim, pow(base, e));                // math.pow == libm pow
+#endif
       const double fl = (double)(long long)x;                  // int()
       const double fr = x - fl;
       s.f_avail = k ? fl : s.f_avail; s.f_frac = k ? fr : s.f_frac;

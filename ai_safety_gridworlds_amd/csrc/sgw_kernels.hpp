@@ -37,15 +37,15 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
   }
   if (o.reward) {
 #pragma unroll
-    for (int u = 0; u < F::NU; ++u) { int slot = sp.dim_slot[0][u]; if (slot >= 0) l.vec_r[lane * K + slot] = r[u]; }
+    for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_r, l.trash, lane, K, sp.dim_slot[0][u]) = r[u];
   }
   if (o.cumulative) {
 #pragma unroll
-    for (int u = 0; u < F::NU; ++u) { int slot = sp.dim_slot[0][u]; if (slot >= 0) l.vec_c[lane * K + slot] = s.cum[u]; }
+    for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_c, l.trash, lane, K, sp.dim_slot[0][u]) = s.cum[u];
   }
   if (o.metrics && M > 0) {
 #pragma unroll
-    for (int id = 0; id < F::NMETRIC; ++id) { int slot = sp.metric_slot[id]; if (slot >= 0) l.vec_m[lane * M + slot] = F::metric(s, id); }
+    for (int id = 0; id < F::NMETRIC; ++id) *stage_cell(l.vec_m, l.trash, lane, M, sp.metric_slot[id]) = F::metric(s, id);
   }
   lds_wave_sync();
 
@@ -130,6 +130,11 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
   const Lds l = lds_carve(smem, a.sp);
   typename F::State s;
   F::load(s, a, env);
+  // ... and the first step's actions in the same round trip (a dependent load here would cost a second one)
+  int action0[F::NA];
+#pragma unroll
+  for (int ag = 0; ag < F::NA; ++ag)
+    action0[ag] = (KIND != K_RESET && a.actions && real) ? (int)a.actions[env * F::NA + ag] : 0;
   __syncthreads();
   SGW_STAMP(a, 1);
 
@@ -158,7 +163,8 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
       int action[F::NA];
 #pragma unroll
       for (int ag = 0; ag < F::NA; ++ag) {
-        if (a.actions) action[ag] = real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0;
+        if (a.actions) action[ag] = (t == 0) ? action0[ag]
+                                             : (real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0);
         else action[ag] = synth_action(a.seed, env_id, a.step0 + t, ag, a.sp.action_lo, a.sp.n_actions);
       }
       discount = F::play(s, action, a, l, r, env);
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
       if (acc_any) {
         if (lane < C) acc_old = a.ep_acc[(long long)blockIdx.x * C + lane];   // consumed after the output phase
 #pragma unroll
-        for (int u = 0; u < F::NU; ++u) { int slot = a.sp.dim_slot[0][u]; if (slot >= 0) l.vec_a[lane * C + slot] = over_now ? s.cum[u] : 0.0; }
+        for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_a, l.trash, lane, C, a.sp.dim_slot[0][u]) = over_now ? s.cum[u] : 0.0;
         l.vec_a[lane * C + C - 1] = over_now ? 1.0 : 0.0;    // made visible by the output phase's LDS fence
       }
     }
