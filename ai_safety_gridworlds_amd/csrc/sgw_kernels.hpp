@@ -85,28 +85,28 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
     const long long row = toff + env;
     if (o.step_type) {
 #pragma unroll
-      for (int ag = 0; ag < F::NA; ++ag) o.step_type[row * F::NA + ag] = (uint8_t)s.step_type;
+      for (int ag = 0; ag < F::NA; ++ag) store_wt(o.step_type + row * F::NA + ag, (uint8_t)s.step_type);
     }
-    if (o.term_reason) o.term_reason[row] = (s.step_type == ST_LAST) ? (uint8_t)s.term : (uint8_t)SGW_TERM_NONE;
+    if (o.term_reason) store_wt(o.term_reason + row, (s.step_type == ST_LAST) ? (uint8_t)s.term : (uint8_t)SGW_TERM_NONE);
     if (o.actual_action) {
 #pragma unroll
-      for (int ag = 0; ag < F::NA; ++ag) o.actual_action[row * F::NA + ag] = (int8_t)F::actual(s, ag);
+      for (int ag = 0; ag < F::NA; ++ag) store_wt(o.actual_action + row * F::NA + ag, (int8_t)F::actual(s, ag));
     }
     if (o.agent_pos) {
 #pragma unroll
       for (int ag = 0; ag < F::NA; ++ag) {
         int pr, pc; F::agent_pos(s, ag, pr, pc);
-        o.agent_pos[(row * F::NA + ag) * 2] = (uint8_t)pr; o.agent_pos[(row * F::NA + ag) * 2 + 1] = (uint8_t)pc;
+        store_wt(o.agent_pos + (row * F::NA + ag) * 2, (uint8_t)pr); store_wt(o.agent_pos + (row * F::NA + ag) * 2 + 1, (uint8_t)pc);
       }
     }
     if (o.agent_flags) {
 #pragma unroll
-      for (int ag = 0; ag < F::NA; ++ag) o.agent_flags[row * F::NA + ag] = (uint8_t)F::agent_flags(s, ag);
+      for (int ag = 0; ag < F::NA; ++ag) store_wt(o.agent_flags + row * F::NA + ag, (uint8_t)F::agent_flags(s, ag));
     }
-    if (o.discount) o.discount[row] = discount;
-    if (o.hidden) o.hidden[row] = F::hidden(s);
-    if (o.safety) o.safety[row] = F::safety(s);
-    if (o.frame) o.frame[row] = s.frame;
+    if (o.discount) store_wt(o.discount + row, discount);
+    if (o.hidden) store_wt(o.hidden + row, F::hidden(s));
+    if (o.safety) store_wt(o.safety + row, F::safety(s));
+    if (o.frame) store_wt(o.frame + row, s.frame);
   }
 }
 
