@@ -41,7 +41,6 @@ struct sgw_engine {
   const uint8_t* ep_bits;
   int ep_bits_n;
   unsigned long long ep_seed;
-  size_t lds_bytes;
   double* acc_dev;         // [n_pad/64][A*K+1] per-wave episodic-return accumulators (lazily allocated)
   int rng_set;
 };
@@ -106,7 +105,6 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   memcpy(k.start_cell, spec->start_cell, sizeof(k.start_cell));
   memcpy(k.dim_slot, spec->dim_slot, sizeof(k.dim_slot));
   memcpy(k.metric_slot, spec->metric_slot, sizeof(k.metric_slot));
-  e->lds_bytes = lds_total_bytes(HW, spec->A, spec->K, spec->M);
 
   const size_t tbytes = TABLE_BYTES;
   uint8_t host_tables[TABLE_BYTES];
@@ -201,11 +199,13 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
   a.ep_bits = e->ep_bits; a.ep_bits_n = e->ep_bits_n; a.ep_seed = e->ep_seed;
   const dim3 grid((unsigned)(e->n_pad / WAVE)), block(WAVE);
   const int kind = a.mode == MODE_RESET ? K_RESET : (a.T == 1 ? K_STEP : K_ROLLOUT);
+  size_t lds_bytes = 0;
 #define SGW_LAUNCH(F)                                                                                  \
   do {                                                                                                 \
-    if (kind == K_STEP) hipLaunchKernelGGL((k_engine<F, K_STEP>), grid, block, e->lds_bytes, st, a);   \
-    else if (kind == K_ROLLOUT) hipLaunchKernelGGL((k_engine<F, K_ROLLOUT>), grid, block, e->lds_bytes, st, a); \
-    else hipLaunchKernelGGL((k_engine<F, K_RESET>), grid, block, e->lds_bytes, st, a);                 \
+    lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, lds_need(a, F::LDS_SCRATCH_M));       \
+    if (kind == K_STEP) hipLaunchKernelGGL((k_engine<F, K_STEP>), grid, block, lds_bytes, st, a);   \
+    else if (kind == K_ROLLOUT) hipLaunchKernelGGL((k_engine<F, K_ROLLOUT>), grid, block, lds_bytes, st, a); \
+    else hipLaunchKernelGGL((k_engine<F, K_RESET>), grid, block, lds_bytes, st, a);                 \
   } while (0)
   switch (e->spec.family) {
     case SGW_ISLAND_NAVIGATION_EX: SGW_LAUNCH(Island); break;

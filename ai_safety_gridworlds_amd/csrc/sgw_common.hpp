@@ -58,8 +58,17 @@ struct KArgs {
     __builtin_amdgcn_sched_barrier(0);                                                           \
     if (threadIdx.x == 0) (a).sgw_stamps[blockIdx.x * 8 + (k)] = t_;                             \
   } while (0)
+#define SGW_STAMP_RT(a, k)                                                                       \
+  do {                                                                                           \
+    unsigned long long t_;                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    if (threadIdx.x == 0) (a).sgw_stamps[blockIdx.x * 8 + (k)] = t_;                             \
+  } while (0)
 #else
 #define SGW_STAMP(a, k) do { } while (0)
+#define SGW_STAMP_RT(a, k) do { } while (0)
 #endif
 
 enum { MODE_STEP = 0, MODE_RESET = 1 };
@@ -81,14 +90,30 @@ struct Lds {
 };
 
 __host__ __device__ inline size_t lds_board_bytes(int HW) { return ((size_t)64 * HW + 15) / 16 * 16 + 16; }
-__host__ __device__ inline size_t lds_vec_bytes(int A, int K, int M) {
-  return (size_t)64 * 8 * (3 * (A * K > 0 ? A * K : 1) + 1 + (M > 0 ? M : 1) + 1);   // reward + cumulative + returns + metrics staging + trash
+// Staging regions are carved only for the outputs a launch asked for (host and device evaluate the same
+// arithmetic on the same KArgs): the LDS footprint of a wave decides how many waves a CU keeps resident when a launch
+// has more than one wave per SIMD (26 KB/wave with everything staged caps a CU at 4 waves; reward-only island is 16 KB).
+enum { LN_REWARD = 1, LN_CUMULATIVE = 2, LN_METRICS = 4, LN_RETURNS = 8 };
+__host__ __device__ inline int lds_need(const KArgs& a, bool family_scratch_m) {
+  return (a.out.reward ? LN_REWARD : 0) | (a.out.cumulative ? LN_CUMULATIVE : 0) |
+         ((a.out.metrics || family_scratch_m) ? LN_METRICS : 0) | (a.ep_acc ? LN_RETURNS : 0);
 }
-__host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M) {
-  return TABLE_BYTES + lds_board_bytes(HW) + lds_vec_bytes(A, K, M);
+__host__ __device__ inline size_t lds_rows(int A, int K, int M, int need, int which) {
+  const int ak = A * K > 0 ? A * K : 1;
+  switch (which) {
+    case LN_REWARD: return (need & LN_REWARD) ? ak : 0;
+    case LN_CUMULATIVE: return (need & LN_CUMULATIVE) ? ak : 0;
+    case LN_METRICS: return (need & LN_METRICS) ? (M > 6 ? M : 6) : 0;      // firemaker parks six mask words here
+    default: return (need & LN_RETURNS) ? A * K + 1 : 0;
+  }
+}
+__host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M, int need) {
+  const size_t rows = lds_rows(A, K, M, need, LN_REWARD) + lds_rows(A, K, M, need, LN_CUMULATIVE) +
+                      lds_rows(A, K, M, need, LN_METRICS) + lds_rows(A, K, M, need, LN_RETURNS) + 1;   // + trash
+  return TABLE_BYTES + lds_board_bytes(HW) + rows * 64 * 8;
 }
 
-__device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp) {
+__device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp, int need) {
   Lds l;
   l.static_board = smem;
   l.art = smem + SGW_MAX_CELLS;
@@ -97,10 +122,10 @@ __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp) {
   l.params = reinterpret_cast<const double*>(smem + 3 * SGW_MAX_CELLS + 512);
   l.board = reinterpret_cast<uint32_t*>(smem + TABLE_BYTES);
   l.vec_r = reinterpret_cast<double*>(smem + TABLE_BYTES + lds_board_bytes(sp.HW));
-  l.vec_c = l.vec_r + 64 * (sp.A * sp.K > 0 ? sp.A * sp.K : 1);
-  l.vec_m = l.vec_c + 64 * (sp.A * sp.K > 0 ? sp.A * sp.K : 1);
-  l.vec_a = l.vec_m + 64 * (sp.M > 0 ? sp.M : 1);
-  l.trash = l.vec_a + 64 * (sp.A * sp.K + 1);
+  l.vec_c = l.vec_r + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_REWARD);
+  l.vec_m = l.vec_c + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_CUMULATIVE);
+  l.vec_a = l.vec_m + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_METRICS);
+  l.trash = l.vec_a + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_RETURNS);
   return l;
 }
 

@@ -45,6 +45,7 @@ struct Firemaker {
   static constexpr int NMETRIC = 16;
   static constexpr int NSPRITE = 3;
   static constexpr bool CUSTOM_BOARD = true;
+  static constexpr bool LDS_SCRATCH_M = true;   // borrows the metrics staging rows as per-lane scratch
   static constexpr int W = 17, H = 17, CELLS = 289;
   enum { F_SHUFFLE = 1 };
   enum P { P_AGENT_MOVE, P_AGENT_WORK, P_AGENT_WS_ENERGY, P_SUP_MOVE, P_SUP_EXT_FIRE, P_SUP_TRESPASS, P_SUP_BUTTON,

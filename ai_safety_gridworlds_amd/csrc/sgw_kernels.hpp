@@ -124,10 +124,11 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
   const long long env_id = a.env_id_base + env;
   const bool real = env < a.n_envs;
 
+  SGW_STAMP_RT(a, 6);
   SGW_STAMP(a, 0);
   // issue the level-table loads and the env's state-column loads back to back: one HBM/L2 round trip, not two
   lds_load_tables(smem, a.tables);
-  const Lds l = lds_carve(smem, a.sp);
+  const Lds l = lds_carve(smem, a.sp, lds_need(a, F::LDS_SCRATCH_M));
   typename F::State s;
   F::load(s, a, env);
   // ... and the first step's actions in the same round trip (a dependent load here would cost a second one)
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
   SGW_STAMP(a, 4);
   F::store(s, a, env);
   SGW_STAMP(a, 5);
+  SGW_STAMP_RT(a, 7);
 }
 
 // synthetic action stream materialised in HBM: int8 [T, N, A]

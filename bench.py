@@ -186,11 +186,12 @@ def main():
       eng2.set_episode_bits(None, seed=SEED)
     eng2.reset()
     Tf = min(K, 512 if e["fam"] != "firemaker_ex_ma" else 128)
-    eng2.rollout(min(W, 64) or 1, SEED, step0=0, write_every=True)
+    eng2.rollout(Tf, SEED, step0=0, write_every=True)   # untimed: allocates the [Tf, N, ...] outputs, warms the code object
+    torch.cuda.synchronize(device)
     barrier()
     f0 = time.perf_counter()
     ev0.record()
-    eng2.rollout(Tf, SEED, step0=W, write_every=True)
+    eng2.rollout(Tf, SEED, step0=Tf, write_every=True)
     ev1.record()
     torch.cuda.synchronize(device)
     felapsed = time.perf_counter() - f0

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 
@@ -16,8 +17,9 @@ using namespace sgw;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-int main() {
-  const long long n = 65536;
+int main(int argc, char** argv) {
+  const long long n = argc > 1 ? atoll(argv[1]) : 65536;
+  const int NW = (int)(n / 64);
   const int K = 10, HW = 48, words = Island::words(K);
   KArgs a; memset(&a, 0, sizeof(a));
   KSpec& sp = a.sp;
@@ -44,13 +46,15 @@ int main() {
   std::vector<signed char> acts(T * n);
   unsigned x = 12345; for (auto& v : acts) { x = x * 1664525u + 1013904223u; v = (signed char)((x >> 24) % 5); }
   CK(hipMemcpy(d_act, acts.data(), T * n, hipMemcpyHostToDevice));
-  CK(hipMalloc(&d_stamps, 1024 * 8 * 8)); CK(hipMalloc(&d_board, n * HW)); CK(hipMalloc(&d_reward, n * K * 8));
+  CK(hipMalloc(&d_stamps, (size_t)NW * 8 * 8)); CK(hipMalloc(&d_board, n * HW)); CK(hipMalloc(&d_reward, n * K * 8));
   CK(hipMalloc(&d_st, n)); CK(hipMalloc(&d_term, n)); CK(hipMalloc(&d_safety, n * 4)); CK(hipMalloc(&d_frame, n * 4));
   a.tables = d_tables; a.state = reinterpret_cast<uint64_t*>(d_state); a.n_pad = n; a.n_envs = n; a.mode = MODE_STEP; a.T = 1;
   a.out.board = d_board; a.out.reward = d_reward; a.out.step_type = d_st; a.out.term_reason = d_term; a.out.safety = d_safety; a.out.frame = d_frame;
   a.sgw_stamps = d_stamps;
-  const size_t lds = lds_total_bytes(HW, 1, K, 9);
-  std::vector<unsigned long long> h(1024 * 8);
+  const size_t lds = lds_total_bytes(HW, 1, K, 9, lds_need(a, false)) + (argc > 2 ? atoll(argv[2]) : 0);
+  printf("n %lld, dynamic LDS %zu bytes per workgroup\n", n, lds);
+  std::vector<unsigned long long> h((size_t)NW * 8);
+  std::vector<double> starts, ends;
   double acc[8] = {0}; int cnt = 0;
   for (int t = 0; t < T; ++t) {
     a.actions = d_act + t * n;
@@ -59,10 +63,13 @@ int main() {
       CK(hipDeviceSynchronize());
       CK(hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost));
       unsigned long long t0min = ~0ull, tend = 0;
-      for (int w = 0; w < 1024; ++w) { t0min = std::min(t0min, h[w * 8]); tend = std::max(tend, h[w * 8 + 5]); }
-      for (int k = 1; k < 6; ++k) { double s = 0; for (int w = 0; w < 1024; ++w) s += (double)(h[w * 8 + k] - h[w * 8 + k - 1]); acc[k] += s / 1024; }
-      double s0 = 0; for (int w = 0; w < 1024; ++w) s0 += (double)(h[w * 8] - t0min); acc[0] += s0 / 1024;
+      for (int w = 0; w < NW; ++w) { t0min = std::min(t0min, h[w * 8]); tend = std::max(tend, h[w * 8 + 5]); }
+      for (int k = 1; k < 6; ++k) { double s = 0; for (int w = 0; w < NW; ++w) s += (double)(h[w * 8 + k] - h[w * 8 + k - 1]); acc[k] += s / NW; }
+      double s0 = 0; for (int w = 0; w < NW; ++w) s0 += (double)(h[w * 8] - t0min); acc[0] += s0 / NW;
       acc[6] += (double)(tend - t0min); ++cnt;
+      unsigned long long r0 = ~0ull;                       // s_memrealtime: 100 MHz, one clock for all XCDs
+      for (int w = 0; w < NW; ++w) r0 = std::min(r0, h[w * 8 + 6]);
+      for (int w = 0; w < NW; ++w) { starts.push_back((double)(h[w * 8 + 6] - r0) * 0.01); ends.push_back((double)(h[w * 8 + 7] - r0) * 0.01); }
     }
   }
   CK(hipDeviceSynchronize());
@@ -70,5 +77,11 @@ int main() {
                          "return staging + output phase issued", "accumulate tail", "state stores issued", "first wave start -> last wave end"};
   printf("mean shader cycles per wave (s_memtime ticks; 2.4 GHz nominal)\n");
   for (int k = 0; k < 7; ++k) printf("  %-48s %9.0f cycles  %6.2f us\n", names[k], acc[k] / cnt, acc[k] / cnt / 2400.0);
+  std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
+  auto pct = [](const std::vector<double>& v, double q) { return v[(size_t)(q * (v.size() - 1))]; };
+  printf("wave START after the launch's first wave (us, s_memrealtime): p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f\n",
+         pct(starts, .1), pct(starts, .5), pct(starts, .9), pct(starts, .99), starts.back());
+  printf("wave END   after the launch's first wave (us):                p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f\n",
+         pct(ends, .1), pct(ends, .5), pct(ends, .9), pct(ends, .99), ends.back());
   return 0;
 }
