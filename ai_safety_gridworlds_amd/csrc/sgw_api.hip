@@ -197,12 +197,13 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
   a.sp = e->ks; a.tables = e->tables_dev; a.state = e->state_dev;
   a.n_pad = e->n_pad; a.n_envs = e->n_envs; a.env_id_base = e->env_id_base;
   a.ep_bits = e->ep_bits; a.ep_bits_n = e->ep_bits_n; a.ep_seed = e->ep_seed;
-  const dim3 grid((unsigned)(e->n_pad / WAVE)), block(WAVE);
+  const dim3 grid((unsigned)(e->n_pad / WAVE));
   const int kind = a.mode == MODE_RESET ? K_RESET : (a.T == 1 ? K_STEP : K_ROLLOUT);
   size_t lds_bytes = 0;
 #define SGW_LAUNCH(F)                                                                                  \
   do {                                                                                                 \
-    lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, lds_need(a, F::LDS_SCRATCH_M));       \
+    lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, lds_need(a, F::LDS_SCRATCH_M)) + F::LDS_EXTRA; \
+    const dim3 block(F::WAVES * WAVE);                                                                 \
     if (kind == K_STEP) hipLaunchKernelGGL((k_engine<F, K_STEP>), grid, block, lds_bytes, st, a);   \
     else if (kind == K_ROLLOUT) hipLaunchKernelGGL((k_engine<F, K_ROLLOUT>), grid, block, lds_bytes, st, a); \
     else hipLaunchKernelGGL((k_engine<F, K_RESET>), grid, block, lds_bytes, st, a);                 \

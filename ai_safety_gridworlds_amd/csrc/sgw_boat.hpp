@@ -138,6 +138,10 @@ struct Boat {
   static constexpr int NA = 1;
   static constexpr bool CUSTOM_BOARD = false;
   static constexpr bool LDS_SCRATCH_M = false;   // borrows the metrics staging rows as per-lane scratch
+  static constexpr int WAVES = 1, LDS_EXTRA = 0;
+  static constexpr bool COOPERATIVE = false;
+  struct Ctx {};
+  static __device__ void init_ctx(Ctx&, const Lds&) {}
   static __device__ void pre_autoreset(State&, const KArgs&) {}
   static __device__ uint32_t board_dword(const State&, const KSpec&, const Lds&, int) { return 0; }
   static __device__ int actual(const State& s, int) { return s.actual; }

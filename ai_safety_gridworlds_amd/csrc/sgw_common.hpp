@@ -87,6 +87,7 @@ struct Lds {
   double* vec_m;           // 64*M doubles: metrics rows
   double* vec_a;           // 64*(A*K+1) doubles: finished-episode returns staged for the per-wave sum
   double* trash;           // 64 doubles: where writes of not-enabled reward dimensions / absent metrics land (branch-free)
+  uint8_t* extra;          // F::LDS_EXTRA bytes of family-private LDS (16-byte aligned), after everything else
 };
 
 __host__ __device__ inline size_t lds_board_bytes(int HW) { return ((size_t)64 * HW + 15) / 16 * 16 + 16; }
@@ -110,7 +111,7 @@ __host__ __device__ inline size_t lds_rows(int A, int K, int M, int need, int wh
 __host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M, int need) {
   const size_t rows = lds_rows(A, K, M, need, LN_REWARD) + lds_rows(A, K, M, need, LN_CUMULATIVE) +
                       lds_rows(A, K, M, need, LN_METRICS) + lds_rows(A, K, M, need, LN_RETURNS) + 1;   // + trash
-  return TABLE_BYTES + lds_board_bytes(HW) + rows * 64 * 8;
+  return TABLE_BYTES + lds_board_bytes(HW) + rows * 64 * 8;   // the family's LDS_EXTRA is added by the launcher
 }
 
 __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp, int need) {
@@ -126,15 +127,21 @@ __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp, int need) {
   l.vec_m = l.vec_c + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_CUMULATIVE);
   l.vec_a = l.vec_m + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_METRICS);
   l.trash = l.vec_a + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_RETURNS);
+  l.extra = reinterpret_cast<uint8_t*>(l.trash + 64);
   return l;
 }
 
 // tables (2048 bytes) -> LDS: exactly two 16-byte loads per lane, both in flight before the single wait
+template <int WAVES>
 __device__ inline void lds_load_tables(uint8_t* smem, const uint8_t* tables) {
   const uint4* src = reinterpret_cast<const uint4*>(tables);
   uint4* dst = reinterpret_cast<uint4*>(smem);
-  const uint4 t0 = src[threadIdx.x], t1 = src[threadIdx.x + WAVE];
-  dst[threadIdx.x] = t0; dst[threadIdx.x + WAVE] = t1;
+  if constexpr (WAVES == 1) {
+    const uint4 t0 = src[threadIdx.x], t1 = src[threadIdx.x + WAVE];
+    dst[threadIdx.x] = t0; dst[threadIdx.x + WAVE] = t1;
+  } else {
+    if (threadIdx.x < TABLE_BYTES / 16) dst[threadIdx.x] = src[threadIdx.x];
+  }
 }
 
 // One wavefront per workgroup: lanes exchange data through LDS in program order (the LDS pipeline executes

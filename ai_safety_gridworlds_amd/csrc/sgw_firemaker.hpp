@@ -39,13 +39,27 @@ namespace sgw {
 // indexed loads from a stack copy = scratch traffic in the innermost loops)
 struct M5 { uint64_t a, b, c, d, e; };
 
+// PCG64 jump-ahead table: row j = (A^j, G_j = 1 + A + ... + A^(j-1)) mod 2^128, so state_{n+j} = A^j state_n + G_j inc
+struct PcgJump { uint64_t v[65][4]; };
+constexpr PcgJump make_pcg_jump() {
+  PcgJump t{};
+  const unsigned __int128 mult = ((unsigned __int128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL;
+  unsigned __int128 a = 1, g = 0;
+  for (int j = 0; j <= 64; ++j) {
+    t.v[j][0] = (uint64_t)(a >> 64); t.v[j][1] = (uint64_t)a; t.v[j][2] = (uint64_t)(g >> 64); t.v[j][3] = (uint64_t)g;
+    g += a; a *= mult;
+  }
+  return t;
+}
+__device__ const PcgJump g_pcg_jump = make_pcg_jump();
+
 struct Firemaker {
   static constexpr int NA = 3;
   static constexpr int NU = 9;          // [agent][3]
   static constexpr int NMETRIC = 16;
   static constexpr int NSPRITE = 3;
   static constexpr bool CUSTOM_BOARD = true;
-  static constexpr bool LDS_SCRATCH_M = true;   // borrows the metrics staging rows as per-lane scratch
+  static constexpr bool LDS_SCRATCH_M = false;
   static constexpr int W = 17, H = 17, CELLS = 289;
   enum { F_SHUFFLE = 1 };
   enum P { P_AGENT_MOVE, P_AGENT_WORK, P_AGENT_WS_ENERGY, P_SUP_MOVE, P_SUP_EXT_FIRE, P_SUP_TRESPASS, P_SUP_BUTTON,
@@ -188,33 +202,157 @@ struct Firemaker {
     if (on) or_word(m, k >> 6, bit); else clear_word(m, k >> 6, bit);
   }
   static __device__ bool get_bit(const M5& m, int k) { return (word_of(m, k >> 6) >> (k & 63)) & 1; }
-  // The pre-spread fire mask is constant while the candidates are scanned: park it in LDS ([word][lane], six
-  // words, the last zero) so that the per-row window extraction is two ds_read_b64 instead of two mask-selects.
-  static __device__ void park_mask(const Lds& l, const M5& m) {
-    uint64_t* q = reinterpret_cast<uint64_t*>(l.vec_m) + threadIdx.x;
-    q[0] = m.a; q[64] = m.b; q[128] = m.c; q[192] = m.d; q[256] = m.e; q[320] = 0ull;
-  }
-  // 5 consecutive bits starting at bit b (b may be negative at the top-left corner: those bits are walls)
-  static __device__ uint32_t bits5(const Lds& l, int b) {
-    const uint64_t* q = reinterpret_cast<const uint64_t*>(l.vec_m) + threadIdx.x;
-    if (b < 0) return (uint32_t)(q[0] << (-b)) & 31u;
-    const int wi = b >> 6, sh = b & 63;
-    const uint64_t lo = q[wi * 64] >> sh;
-    const uint64_t hi = sh ? (q[wi * 64 + 64] << (64 - sh)) : 0ull;
-    return (uint32_t)(lo | hi) & 31u;
-  }
   static __device__ uint64_t pword(const Lds& l, int i) { return (uint64_t)__double_as_longlong(l.params[i]); }
 
-  // FireDrape.update (FM:536-629)
-  static __device__ void fire_update(State& s, const Lds& l, double (&r)[NU]) {
+  // ---- wave-cooperative fire spread -----------------------------------------------------------
+  // FireDrape.update is the only part of a round whose cost depends on the board: ~100 burning cells mean ~100
+  // candidate targets x ~11 sources each and ~200 PCG64 draws, and about half of the envs have no fire at all.  Lane
+  // per env that is a deeply divergent double loop; here ONE ENV AT A TIME is spread by the whole wave, one lane per
+  // board cell (5 passes of 64 cells), the env's masks and RNG state broadcast with v_readlane (they become scalars):
+  //   * candidate / source masks are scalar 64-bit words; "cell t+off burns" for all 64 cells of a pass is a scalar
+  //     funnel shift, and an offset none of the pass's candidates sees is skipped by a scalar branch;
+  //   * the per-target probability chain runs in the reference's source order (row-major) with a v_cndmask on the
+  //     scalar mask -- no per-lane bit tests;
+  //   * Bernoulli draws: wavefront ballot + mbcnt give every needing cell its index in the env's draw order; the
+  //     PCG64 stream is produced 64 draws at a time by jump-ahead (lane j holds state_{n+j+1} = A^(j+1) s_n + G_(j+1) inc,
+  //     then the whole block leaps by A^64), so the sequence is exactly numpy's.
+  // The workgroup's 4 waves hold the same 64 envs (see k_engine); wave w spreads envs 16w..16w+15 and the results are
+  // exchanged through LDS with one barrier per update.
+  static constexpr int WAVES = 4;
+  static constexpr bool COOPERATIVE = true;
+  static constexpr int X_JUMP = 0, X_DRAWS = 2112, X_EXCH = X_DRAWS + WAVES * 128 * 8, LDS_EXTRA = X_EXCH + 2 * 7 * 64 * 8;
+  struct Ctx { const uint64_t* jump; double* draws; uint64_t* exch; int wave, lane, parity; };
+  static __device__ void init_ctx(Ctx& cx, const Lds& l) {
+    cx.lane = threadIdx.x & 63;
+    cx.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint64_t* j = reinterpret_cast<uint64_t*>(l.extra + X_JUMP);
+    for (int i = threadIdx.x; i < 65 * 4; i += WAVES * WAVE) j[i] = g_pcg_jump.v[i >> 2][i & 3];   // visible after k_engine's barrier
+    cx.jump = j;
+    cx.draws = reinterpret_cast<double*>(l.extra + X_DRAWS) + cx.wave * 128;
+    cx.exch = reinterpret_cast<uint64_t*>(l.extra + X_EXCH);
+    cx.parity = 0;
+  }
+
+  struct U128 { uint64_t hi, lo; };
+  static __device__ U128 mul128(const U128& x, const U128& y) {
+    U128 r; r.lo = x.lo * y.lo; r.hi = __umul64hi(x.lo, y.lo) + x.hi * y.lo + x.lo * y.hi; return r;
+  }
+  static __device__ U128 add128(const U128& x, const U128& y) {
+    U128 r; r.lo = x.lo + y.lo; r.hi = x.hi + y.hi + (r.lo < x.lo ? 1ull : 0ull); return r;
+  }
+  static __device__ double pcg_double(const U128& x) {             // XSL-RR 128/64, then Generator.random()
+    uint64_t v = x.hi ^ x.lo;
+    const unsigned rot = (unsigned)(x.hi >> 58);
+    v = (v >> rot) | (v << ((64u - rot) & 63u));
+    return (double)(v >> 11) * (1.0 / 9007199254740992.0);
+  }
+  static __device__ uint32_t rl32(uint32_t v, int e) { return (uint32_t)__builtin_amdgcn_readlane((int)v, e); }
+  static __device__ uint64_t rl64(uint64_t v, int e) { return (uint64_t)rl32((uint32_t)v, e) | ((uint64_t)rl32((uint32_t)(v >> 32), e) << 32); }
+  // per-lane select by bit `lane` of a SCALAR mask: one v_cndmask per half, the mask goes in as an SGPR pair
+  static __device__ double sel_mask(uint64_t m, double if_set, double if_clear) {
+    const uint64_t a = (uint64_t)__double_as_longlong(if_set), b = (uint64_t)__double_as_longlong(if_clear);
+    uint32_t lo, hi;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(lo) : "v"((uint32_t)b), "v"((uint32_t)a), "s"(m));
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"((uint32_t)(b >> 32)), "v"((uint32_t)(a >> 32)), "s"(m));
+    return __longlong_as_double((long long)((uint64_t)lo | ((uint64_t)hi << 32)));
+  }
+  // bits [64*wi + off, 64*wi + off + 64) of a 320-bit scalar mask (zero outside): "is cell t+off set" for the pass's 64 cells
+  template <int WI, int OFF>
+  static __device__ uint64_t window(const uint64_t (&o)[5]) {
+    constexpr int pos = WI * 64 + OFF;
+    constexpr int q = pos >= 0 ? pos / 64 : -((-pos + 63) / 64);
+    constexpr int sh = pos - q * 64;
+    uint64_t v = 0;
+    if constexpr (q >= 0 && q <= 4) v = o[q] >> sh;
+    if constexpr (sh != 0 && q + 1 >= 0 && q + 1 <= 4) v |= o[q + 1] << (64 - sh);
+    return v;
+  }
+  template <int WI, int DR, int DC>
+  static __device__ void spread_from(double& cum, const uint64_t (&o)[5], uint64_t cw, uint32_t valid, const double (&q)[9]) {
+    constexpr int adr = DR < 0 ? -DR : DR, adc = DC < 0 ? -DC : DC, k = adr * 3 + adc;
+    if constexpr (k != 0) {
+      if ((valid >> k) & 1u) {
+        const uint64_t m = window<WI, DR * W + DC>(o) & cw;
+        if (m) cum = sel_mask(m, 1.0 - (1.0 - cum) * q[k], cum);      // FM:601-609, sources in row-major order
+      }
+    }
+  }
+  template <int WI, int DR>
+  static __device__ void spread_row(double& cum, const uint64_t (&o)[5], uint64_t cw, uint32_t valid, const double (&q)[9]) {
+    spread_from<WI, DR, -2>(cum, o, cw, valid, q); spread_from<WI, DR, -1>(cum, o, cw, valid, q);
+    spread_from<WI, DR, 0>(cum, o, cw, valid, q); spread_from<WI, DR, 1>(cum, o, cw, valid, q);
+    spread_from<WI, DR, 2>(cum, o, cw, valid, q);
+  }
+  struct Ring { U128 xa, xb, a64, c64; int blk, consumed; };        // xa / xb: this lane's state in draw blocks blk / blk+1
+  // make draws [consumed, consumed + 64) readable: block b lives in ring slot b & 1
+  static __device__ void ring_ready(Ring& g, Ctx& cx) {
+    while (g.blk < (g.consumed >> 6)) {                               // scalar loop
+      g.xa = g.xb; g.xb = add128(mul128(g.a64, g.xb), g.c64);
+      g.blk += 1;
+      lds_wave_sync();
+      cx.draws[((g.blk + 1) & 1) * 64 + cx.lane] = pcg_double(g.xb);
+    }
+    lds_wave_sync();
+  }
+  template <int WI>
+  static __device__ void spread_pass(const uint64_t (&o)[5], const uint64_t (&c)[5], uint64_t (&nf)[5], uint32_t valid,
+                                     const double (&q)[9], uint32_t ws, const Lds& l, Ring& g, Ctx& cx) {
+    const uint64_t cw = c[WI];
+    if (cw == 0) return;
+    double cum = 0.0;
+    spread_row<WI, -2>(cum, o, cw, valid, q); spread_row<WI, -1>(cum, o, cw, valid, q); spread_row<WI, 0>(cum, o, cw, valid, q);
+    spread_row<WI, 1>(cum, o, cw, valid, q); spread_row<WI, 2>(cum, o, cw, valid, q);
+    if (ws & 3u) {                                                     // then the virtual workshop sources, agent order
+      const int t = WI * 64 + cx.lane, tr = (t * 241) >> 12, tc = t - tr * W;
+      const bool is_cand = (cw >> cx.lane) & 1ull;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        if ((ws >> a) & 1u) {
+          const int wc = (int)((ws >> (8 + 9 * a)) & 0x1ffu), wr = (wc * 241) >> 12;
+          const int adr = abs(wr - tr), adc = abs(wc - wr * W - tc);
+          const bool near = is_cand && adr <= 2 && adc <= 2;
+          const int k = near ? adr * 3 + adc : 0;
+          if (near && ((valid >> k) & 1u)) cum = 1.0 - (1.0 - cum) * (1.0 - l.params[P_SPREAD0 + k]);
+        }
+      }
+    }
+    const uint64_t need = __ballot(cum > 0.0);                        // FM:612: one draw per target with p > 0, row-major
+    if (need) {
+      ring_ready(g, cx);
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+      const double u = cx.draws[(g.consumed + rank) & 127];
+      nf[WI] |= __ballot(cum > 0.0 && u < cum);
+      g.consumed += __builtin_popcountll(need);
+    }
+  }
+  template <int WI>
+  static __device__ void continue_pass(const uint64_t (&o)[5], uint64_t (&nf)[5], double cont, Ring& g, Ctx& cx) {
+    const uint64_t ow = o[WI];                                        // FM:619-621: one draw per ORIGINAL fire cell
+    if (ow == 0) return;
+    ring_ready(g, cx);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ow >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ow, 0u));
+    const double u = cx.draws[(g.consumed + rank) & 127];
+    nf[WI] &= ~(__ballot(!(u < cont)) & ow);
+    g.consumed += __builtin_popcountll(ow);
+  }
+
+  // FireDrape.update (FM:536-629).  Runs with all 64 lanes of all 4 waves active (see k_engine).
+  static __device__ void fire_update(State& s, const Lds& l, double (&r)[NU], bool live, Ctx& cx) {
     const double* p = l.params;
+    const int lane = cx.lane;
 #pragma unroll
     for (int ag = 0; ag < 3; ++ag) set_bit(s.fire, s.row[ag] * W + s.col[ag], false);     // FM:540-542
     const M5 old = s.fire;
     M5 src = old;                                              // + workers on an active workshop (FM:550-554)
     const bool ws_active = (s.countdown == 0);
+    uint32_t ws = 0;
 #pragma unroll
-    for (int ag = 0; ag < 2; ++ag) if (ws_active && ((s.at_ws >> ag) & 1)) set_bit(src, s.row[ag] * W + s.col[ag], true);
+    for (int ag = 0; ag < 2; ++ag) {
+      const bool on = ws_active && ((s.at_ws >> ag) & 1);
+      const int cell = s.row[ag] * W + s.col[ag];
+      if (on) set_bit(src, cell, true);
+      ws |= on ? ((1u << ag) | ((uint32_t)cell << (8 + 9 * ag))) : 0u;
+    }
     // candidate targets: separable 5x5 dilation of the sources, minus burning / blocked cells
     M5 hz = or5(or5(src, or5(shl(src, 1), shl(src, 2))), or5(shr(src, 1), shr(src, 2)));
     M5 dil = or5(or5(hz, or5(shl(hz, 17), shl(hz, 34))), or5(shr(hz, 17), shr(hz, 34)));
@@ -222,132 +360,140 @@ struct Firemaker {
     cand.a = dil.a & ~old.a & pword(l, P_ALLOWED0 + 0); cand.b = dil.b & ~old.b & pword(l, P_ALLOWED0 + 1);
     cand.c = dil.c & ~old.c & pword(l, P_ALLOWED0 + 2); cand.d = dil.d & ~old.d & pword(l, P_ALLOWED0 + 3);
     cand.e = dil.e & ~old.e & pword(l, P_ALLOWED0 + 4);
-    park_mask(l, old);
-    const uint32_t valid = (uint32_t)p[P_VALID];
-    const int w1c = s.row[0] * W + s.col[0], w2c = s.row[1] * W + s.col[1];
-    const bool w1src = ws_active && (s.at_ws & 1), w2src = ws_active && (s.at_ws & 2);
-#pragma nounroll
-    for (int wi = 0; wi < 5; ++wi) {
-      uint64_t cw = word_of(cand, wi);
-      uint64_t lit = 0;
-      while (cw) {                                             // ascending bit order == np.where order (FM:612)
-        const int b = __builtin_ctzll(cw);
-        cw &= cw - 1;
-        const int t = wi * 64 + b, tr = t / W, tc = t - tr * W;
-        double cum = 0.0;
-#pragma nounroll
-        for (int dr = -2; dr <= 2; ++dr) {                     // fire sources in row-major order (FM:565-609)
-          const int sr = tr + dr;
-          if (sr < 0 || sr >= H) continue;
-          uint32_t row5 = bits5(l, sr * W + tc - 2);
-          const int adr = dr < 0 ? -dr : dr;
-          while (row5) {
-            const int j = __builtin_ctz(row5);
-            row5 &= row5 - 1;
-            const int adc = j < 2 ? 2 - j : j - 2;
-            const int o = adr * 3 + adc;
-            if ((valid >> o) & 1) cum = 1.0 - (1.0 - cum) * (1.0 - p[P_SPREAD0 + o]);
-          }
+
+    // ---- cooperative phase: this wave's 16 envs, one at a time; envs with nothing burning and nothing to ignite are skipped
+    M5 res = old;
+    uint64_t res_hi = s.rs_hi, res_lo = s.rs_lo;
+    const bool has_work = ((old.a | old.b | old.c | old.d | old.e | cand.a | cand.b | cand.c | cand.d | cand.e) != 0ull);
+    uint32_t mine = (uint32_t)(__ballot(has_work) >> (cx.wave * 16)) & 0xffffu;             // scalar
+    if (mine) {
+      const uint32_t valid = (uint32_t)p[P_VALID];
+      const double cont = p[P_CONTINUE];
+      double q[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) q[k] = 1.0 - p[P_SPREAD0 + k];
+      const uint64_t* jt = cx.jump + (lane + 1) * 4;
+      const U128 aj = {jt[0], jt[1]}, gj = {jt[2], jt[3]};
+      Ring g;
+      g.a64.hi = cx.jump[64 * 4]; g.a64.lo = cx.jump[64 * 4 + 1];
+      while (mine) {
+        const int e = cx.wave * 16 + __builtin_ctz(mine);
+        mine &= mine - 1;
+        const uint64_t o[5] = {rl64(old.a, e), rl64(old.b, e), rl64(old.c, e), rl64(old.d, e), rl64(old.e, e)};
+        const uint64_t c[5] = {rl64(cand.a, e), rl64(cand.b, e), rl64(cand.c, e), rl64(cand.d, e), rl64(cand.e, e)};
+        uint64_t nf[5] = {o[0], o[1], o[2], o[3], o[4]};
+        const U128 st = {rl64(s.rs_hi, e), rl64(s.rs_lo, e)}, inc = {rl64(s.ri_hi, e), rl64(s.ri_lo, e)};
+        const uint32_t wse = rl32(ws, e);
+        const U128 gi = mul128(gj, inc);
+        g.xa = add128(mul128(aj, st), gi);                                // state after lane+1 steps
+        g.c64.hi = rl64(gi.hi, 63); g.c64.lo = rl64(gi.lo, 63);           // G_64 * inc
+        g.xb = add128(mul128(g.a64, g.xa), g.c64);
+        g.blk = 0; g.consumed = 0;
+        lds_wave_sync();
+        cx.draws[lane] = pcg_double(g.xa); cx.draws[64 + lane] = pcg_double(g.xb);
+        spread_pass<0>(o, c, nf, valid, q, wse, l, g, cx); spread_pass<1>(o, c, nf, valid, q, wse, l, g, cx);
+        spread_pass<2>(o, c, nf, valid, q, wse, l, g, cx); spread_pass<3>(o, c, nf, valid, q, wse, l, g, cx);
+        spread_pass<4>(o, c, nf, valid, q, wse, l, g, cx);
+        continue_pass<0>(o, nf, cont, g, cx); continue_pass<1>(o, nf, cont, g, cx); continue_pass<2>(o, nf, cont, g, cx);
+        continue_pass<3>(o, nf, cont, g, cx); continue_pass<4>(o, nf, cont, g, cx);
+        U128 fin = st;
+        if (g.consumed > 0) {                                             // the env's stream stops after its last draw
+          const int t1 = g.consumed - 1, src_lane = t1 & 63;
+          const bool in_b = (t1 >> 6) != g.blk;
+          fin.hi = rl64(in_b ? g.xb.hi : g.xa.hi, src_lane); fin.lo = rl64(in_b ? g.xb.lo : g.xa.lo, src_lane);
         }
-        if (w1src) {                                           // then the virtual workshop sources, agent order
-          const int adr = abs(w1c / W - tr), adc = abs(w1c % W - tc);
-          if (adr <= 2 && adc <= 2 && ((valid >> (adr * 3 + adc)) & 1)) cum = 1.0 - (1.0 - cum) * (1.0 - p[P_SPREAD0 + adr * 3 + adc]);
-        }
-        if (w2src) {
-          const int adr = abs(w2c / W - tr), adc = abs(w2c % W - tc);
-          if (adr <= 2 && adc <= 2 && ((valid >> (adr * 3 + adc)) & 1)) cum = 1.0 - (1.0 - cum) * (1.0 - p[P_SPREAD0 + adr * 3 + adc]);
-        }
-        if (cum > 0.0 && random01(s) < cum) lit |= 1ull << b;   // FM:612-615
+        const bool me = (lane == e);
+        res.a = me ? nf[0] : res.a; res.b = me ? nf[1] : res.b; res.c = me ? nf[2] : res.c; res.d = me ? nf[3] : res.d;
+        res.e = me ? nf[4] : res.e; res_hi = me ? fin.hi : res_hi; res_lo = me ? fin.lo : res_lo;
       }
-      or_word(s.fire, wi, lit);
     }
-    const double cont = p[P_CONTINUE];
-#pragma nounroll
-    for (int wi = 0; wi < 5; ++wi) {                            // continuation draw per ORIGINAL fire cell (FM:619-621)
-      uint64_t ow = word_of(old, wi);
-      uint64_t out = 0;
-      while (ow) {
-        const int b = __builtin_ctzll(ow);
-        ow &= ow - 1;
-        if (!(random01(s) < cont)) out |= 1ull << b;
-      }
-      clear_word(s.fire, wi, out);
+    // ---- exchange: lanes 16w..16w+15 of wave w own the results; everybody reads its env's row after the barrier
+    uint64_t* ex = cx.exch + cx.parity * (7 * 64) + lane;
+    if ((lane >> 4) == cx.wave) {
+      ex[0] = res.a; ex[64] = res.b; ex[128] = res.c; ex[192] = res.d; ex[256] = res.e; ex[320] = res_hi; ex[384] = res_lo;
     }
+    __syncthreads();
+    s.fire.a = ex[0]; s.fire.b = ex[64]; s.fire.c = ex[128]; s.fire.d = ex[192]; s.fire.e = ex[256];
+    s.rs_hi = ex[320]; s.rs_lo = ex[384];
+    cx.parity ^= 1;                                            // double-buffered: the next update writes the other half
+
     const int n = __builtin_popcountll(s.fire.a & ~pword(l, P_TERR0 + 0)) + __builtin_popcountll(s.fire.b & ~pword(l, P_TERR0 + 1)) +
                   __builtin_popcountll(s.fire.c & ~pword(l, P_TERR0 + 2)) + __builtin_popcountll(s.fire.d & ~pword(l, P_TERR0 + 3)) +
                   __builtin_popcountll(s.fire.e & ~pword(l, P_TERR0 + 4));
-    s.n_ext = n;                                                // FM:624-629
-    r[2 * 3 + 1] += (double)n * p[P_SUP_EXT_FIRE];
+    s.n_ext = live ? n : s.n_ext;                               // FM:624-629
+    r[2 * 3 + 1] += live ? (double)n * p[P_SUP_EXT_FIRE] : 0.0;
   }
 
   // one Engine.play({agent: {"step": action}})
-  static __device__ void play_one(State& s, int ag, int action, const Lds& l, double (&r)[NU]) {
+  static __device__ void play_one(State& s, int ag, int action, const Lds& l, double (&r)[NU], bool live, Ctx& cx) {
     const double* p = l.params;
-    s.frame += 1;
-    // AgentSprite.update: MA enum LEFT=1 RIGHT=2 UP=3 DOWN=4; impassable = walls + other agents (FM:399-400)
-    const int dr = (action == 4) - (action == 3), dc = (action == 2) - (action == 1);
-    int cr = s.row[0], cc = s.col[0];
-    cr = ag == 1 ? s.row[1] : cr; cc = ag == 1 ? s.col[1] : cc;
-    cr = ag == 2 ? s.row[2] : cr; cc = ag == 2 ? s.col[2] : cc;
-    const int nr = cr + dr, nc = cc + dc;
-    const bool inside = (nr >= 0) & (nr < H) & (nc >= 0) & (nc < W);
-    const int ncell = inside ? nr * W + nc : 0;
-    bool blocked = !inside || (l.aux[ncell] & C_WALL);
+    if (live) {
+      s.frame += 1;
+      // AgentSprite.update: MA enum LEFT=1 RIGHT=2 UP=3 DOWN=4; impassable = walls + other agents (FM:399-400)
+      const int dr = (action == 4) - (action == 3), dc = (action == 2) - (action == 1);
+      int cr = s.row[0], cc = s.col[0];
+      cr = ag == 1 ? s.row[1] : cr; cc = ag == 1 ? s.col[1] : cc;
+      cr = ag == 2 ? s.row[2] : cr; cc = ag == 2 ? s.col[2] : cc;
+      const int nr = cr + dr, nc = cc + dc;
+      const bool inside = (nr >= 0) & (nr < H) & (nc >= 0) & (nc < W);
+      const int ncell = inside ? nr * W + nc : 0;
+      bool blocked = !inside || (l.aux[ncell] & C_WALL);
 #pragma unroll
-    for (int b = 0; b < 3; ++b) blocked |= (b != ag) & (s.row[b] == nr) & (s.col[b] == nc);
-    const bool moved = ((dr | dc) != 0) & !blocked;
-    const int fr = moved ? nr : cr, fc = moved ? nc : cc;
+      for (int b = 0; b < 3; ++b) blocked |= (b != ag) & (s.row[b] == nr) & (s.col[b] == nc);
+      const bool moved = ((dr | dc) != 0) & !blocked;
+      const int fr = moved ? nr : cr, fc = moved ? nc : cc;
 #pragma unroll
-    for (int b = 0; b < 3; ++b) { s.row[b] = (b == ag) ? fr : s.row[b]; s.col[b] = (b == ag) ? fc : s.col[b]; }
-    // update_reward FM:429-463
-    const bool sup = (ag == 2);
-    const double mv = (action != 0) ? (sup ? p[P_SUP_MOVE] : p[P_AGENT_MOVE]) : 0.0;
+      for (int b = 0; b < 3; ++b) { s.row[b] = (b == ag) ? fr : s.row[b]; s.col[b] = (b == ag) ? fc : s.col[b]; }
+      // update_reward FM:429-463
+      const bool sup = (ag == 2);
+      const double mv = (action != 0) ? (sup ? p[P_SUP_MOVE] : p[P_AGENT_MOVE]) : 0.0;
 #pragma unroll
-    for (int b = 0; b < 3; ++b) r[b * 3 + 0] += (b == ag) ? mv : 0.0;       // static register indices only
-    const int k = fr * W + fc;
-    const uint8_t cls = l.aux[k];
-    const bool on_fire = get_bit(s.fire, k);
+      for (int b = 0; b < 3; ++b) r[b * 3 + 0] += (b == ag) ? mv : 0.0;       // static register indices only
+      const int k = fr * W + fc;
+      const uint8_t cls = l.aux[k];
+      const bool on_fire = get_bit(s.fire, k);
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const uint32_t me = (b == ag) ? 1u : 0u;
-      s.visits[0 + b] += me & (uint32_t)((cls & C_WALL) == 0);     // unoccluded gap layer == backdrop ' ' (Q19)
-      s.visits[3 + b] += me & (uint32_t)((cls & C_TERR) != 0);
-      s.visits[6 + b] += me & (uint32_t)((cls & C_WORKSHOP) != 0);
-      s.visits[9 + b] += me & (uint32_t)on_fire;
-      s.visits[12 + b] += me & (uint32_t)((cls & C_BUTTON) != 0);
+      for (int b = 0; b < 3; ++b) {
+        const uint32_t me = (b == ag) ? 1u : 0u;
+        s.visits[0 + b] += me & (uint32_t)((cls & C_WALL) == 0);     // unoccluded gap layer == backdrop ' ' (Q19)
+        s.visits[3 + b] += me & (uint32_t)((cls & C_TERR) != 0);
+        s.visits[6 + b] += me & (uint32_t)((cls & C_WORKSHOP) != 0);
+        s.visits[9 + b] += me & (uint32_t)on_fire;
+        s.visits[12 + b] += me & (uint32_t)((cls & C_BUTTON) != 0);
+      }
+      // StopButtonDrape.update FM:656-673
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const bool on_b = (l.aux[s.row[b] * W + s.col[b]] & C_BUTTON) != 0;
+        s.countdown = on_b ? (int)p[P_RELOAD] : s.countdown;
+        if (b == 2) r[2 * 3 + 2] += (on_b && s.n_ext == 0) ? p[P_SUP_BUTTON] : 0.0;
+      }
+      s.countdown = s.countdown > 0 ? s.countdown - 1 : 0;
+      // WorkshopDrape.update FM:496-517
+      s.at_ws = 0;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const bool at = (l.aux[s.row[b] * W + s.col[b]] & C_WORKSHOP) != 0;
+        s.at_ws |= at ? (1 << b) : 0;
+        const bool sup_quiet = (b == 2) && (s.n_ext == 0);
+        if (b == 2) r[2 * 3 + 2] += (at && sup_quiet) ? p[P_SUP_WORKSHOP] : 0.0;
+        const bool work = at && !sup_quiet && (s.countdown == 0);
+        r[0 * 3 + 1] += work ? p[P_AGENT_WORK] : 0.0;
+        r[1 * 3 + 1] += work ? p[P_AGENT_WORK] : 0.0;             // amount_agents > 2 (FM:509-510)
+        r[b * 3 + 0] += work ? p[P_AGENT_WS_ENERGY] : 0.0;
+      }
     }
-    // StopButtonDrape.update FM:656-673
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const bool on_b = (l.aux[s.row[b] * W + s.col[b]] & C_BUTTON) != 0;
-      s.countdown = on_b ? (int)p[P_RELOAD] : s.countdown;
-      if (b == 2) r[2 * 3 + 2] += (on_b && s.n_ext == 0) ? p[P_SUP_BUTTON] : 0.0;
-    }
-    s.countdown = s.countdown > 0 ? s.countdown - 1 : 0;
-    // WorkshopDrape.update FM:496-517
-    s.at_ws = 0;
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const bool at = (l.aux[s.row[b] * W + s.col[b]] & C_WORKSHOP) != 0;
-      s.at_ws |= at ? (1 << b) : 0;
-      const bool sup_quiet = (b == 2) && (s.n_ext == 0);
-      if (b == 2) r[2 * 3 + 2] += (at && sup_quiet) ? p[P_SUP_WORKSHOP] : 0.0;
-      const bool work = at && !sup_quiet && (s.countdown == 0);
-      r[0 * 3 + 1] += work ? p[P_AGENT_WORK] : 0.0;
-      r[1 * 3 + 1] += work ? p[P_AGENT_WORK] : 0.0;             // amount_agents > 2 (FM:509-510)
-      r[b * 3 + 0] += work ? p[P_AGENT_WS_ENERGY] : 0.0;
-    }
-    fire_update(s, l, r);
+    fire_update(s, l, r, live, cx);
     // WorkshopTerritoryDrape.update FM:702-709
-    r[2 * 3 + 2] += ((l.aux[s.row[2] * W + s.col[2]] & C_TERR) && s.n_ext == 0) ? p[P_SUP_TRESPASS] : 0.0;
+    r[2 * 3 + 2] += (live && (l.aux[s.row[2] * W + s.col[2]] & C_TERR) && s.n_ext == 0) ? p[P_SUP_TRESPASS] : 0.0;
   }
 
   // one ROUND (EnvironmentMa.step): shuffle, then one play per agent.  Returns the discount (always 1.0:
   // firemaker has no terminating entity; the episode ends through max_iterations).
   static __device__ double play(State& s, const int (&actions)[3], const KArgs& a, const Lds& l, double (&r)[NU],
-                                long long env) {
+                                long long env, bool live, Ctx& cx) {
     int o0 = 0, o1 = 1, o2 = 2;
-    if (a.sp.flags & F_SHUFFLE) {                               // Generator.shuffle(list): i = 2, then i = 1
+    if (live && (a.sp.flags & F_SHUFFLE)) {                     // Generator.shuffle(list): i = 2, then i = 1
       int j = interval(s, 2);
       int t2 = j == 0 ? o0 : (j == 1 ? o1 : o2);
       o0 = j == 0 ? o2 : o0; o1 = j == 1 ? o2 : o1; o2 = t2;
@@ -359,7 +505,7 @@ struct Firemaker {
     for (int i = 0; i < 3; ++i) {
       const int ag = i == 0 ? o0 : (i == 1 ? o1 : o2);
       const int act = ag == 0 ? actions[0] : (ag == 1 ? actions[1] : actions[2]);
-      play_one(s, ag, act, l, r);
+      play_one(s, ag, act, l, r, live, cx);
     }
     return 1.0;
   }

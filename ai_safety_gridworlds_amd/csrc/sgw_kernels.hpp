@@ -115,10 +115,16 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
 // costs ~200 SGPR spills that the one-step kernel does not pay).
 enum { K_STEP = 0, K_ROLLOUT = 1, K_RESET = 2 };
 
+//
+// F::WAVES > 1 (cooperative families, firemaker): the workgroup's 64 envs are REPLICATED in every wave -- each wave
+// runs the same lane-per-env code on the same state, so control flow (and every s_barrier) is identical across
+// the waves -- and the family splits its wave-cooperative phase (one env at a time, one lane per board cell) over
+// the waves.  Only wave 0 ("leader") writes outputs, accumulators and state.
 template <class F, int KIND>
-__global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
+__global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const bool leader = F::WAVES == 1 || threadIdx.x < WAVE;
   const long long env0 = (long long)blockIdx.x * WAVE;
   const long long env = env0 + lane;
   const long long env_id = a.env_id_base + env;
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
   SGW_STAMP_RT(a, 6);
   SGW_STAMP(a, 0);
   // issue the level-table loads and the env's state-column loads back to back: one HBM/L2 round trip, not two
-  lds_load_tables(smem, a.tables);
+  lds_load_tables<F::WAVES>(smem, a.tables);
   const Lds l = lds_carve(smem, a.sp, lds_need(a, F::LDS_SCRATCH_M));
   typename F::State s;
   F::load(s, a, env);
@@ -136,6 +142,8 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
 #pragma unroll
   for (int ag = 0; ag < F::NA; ++ag)
     action0[ag] = (KIND != K_RESET && a.actions && real) ? (int)a.actions[env * F::NA + ag] : 0;
+  typename F::Ctx cx;
+  F::init_ctx(cx, l);
   __syncthreads();
   SGW_STAMP(a, 1);
 
@@ -144,8 +152,8 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
     double r[F::NU];
 #pragma unroll
     for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
-    if (m) { F::begin_episode(s, a, l, env, env_id); F::store(s, a, env); }
-    emit<F>(s, r, __longlong_as_double(0x7ff8000000000000LL), a, l, env0, lane, 0, a.mask == nullptr, m);
+    if (m) { F::begin_episode(s, a, l, env, env_id); if (leader) F::store(s, a, env); }
+    if (leader) emit<F>(s, r, __longlong_as_double(0x7ff8000000000000LL), a, l, env0, lane, 0, a.mask == nullptr, m);
     return;
   }
 
@@ -156,11 +164,32 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
     for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
     double discount = __longlong_as_double(0x7ff8000000000000LL);   // None at FIRST
     bool over_now = false;
-    if (s.step_type >= ST_LAST) {
-      // step after LAST (or before any reset): new episode, action discarded (pycolab_interface_mo.py:175-178)
-      F::pre_autoreset(s, a);
-      F::begin_episode(s, a, l, env, env_id);
+    if constexpr (!F::COOPERATIVE) {
+      if (s.step_type >= ST_LAST) {
+        // step after LAST (or before any reset): new episode, action discarded (pycolab_interface_mo.py:175-178)
+        F::pre_autoreset(s, a);
+        F::begin_episode(s, a, l, env, env_id);
+      } else {
+        int action[F::NA];
+#pragma unroll
+        for (int ag = 0; ag < F::NA; ++ag) {
+          if (a.actions) action[ag] = (t == 0) ? action0[ag]
+                                               : (real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0);
+          else action[ag] = synth_action(a.seed, env_id, a.step0 + t, ag, a.sp.action_lo, a.sp.n_actions);
+        }
+        discount = F::play(s, action, a, l, r, env);
+        const bool over = (discount == 0.0) || (s.frame >= a.sp.max_iterations);   // pycolab_interface.py:292-303
+        s.step_type = over ? ST_LAST : ST_MID;
+        if (over && s.term == TERM_NONE4) s.term = SGW_MAX_STEPS;                   // safety_game.py:294-296
+#pragma unroll
+        for (int u = 0; u < F::NU; ++u) s.cum[u] += r[u];                          // safety_game_mo.py:996-997
+        over_now = over;
+      }
     } else {
+      // cooperative families run play() with every lane active (their wave-wide phases need full EXEC and every wave
+      // must reach the same barriers); lanes that auto-reset this step pass live = false and change nothing
+      const bool resetting = s.step_type >= ST_LAST;
+      if (resetting) { F::pre_autoreset(s, a); F::begin_episode(s, a, l, env, env_id); }
       int action[F::NA];
 #pragma unroll
       for (int ag = 0; ag < F::NA; ++ag) {
@@ -168,13 +197,16 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
                                              : (real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0);
         else action[ag] = synth_action(a.seed, env_id, a.step0 + t, ag, a.sp.action_lo, a.sp.n_actions);
       }
-      discount = F::play(s, action, a, l, r, env);
-      const bool over = (discount == 0.0) || (s.frame >= a.sp.max_iterations);   // pycolab_interface.py:292-303
-      s.step_type = over ? ST_LAST : ST_MID;
-      if (over && s.term == TERM_NONE4) s.term = SGW_MAX_STEPS;                   // safety_game.py:294-296
+      const double d = F::play(s, action, a, l, r, env, !resetting, cx);
+      if (!resetting) {
+        discount = d;
+        const bool over = (discount == 0.0) || (s.frame >= a.sp.max_iterations);
+        s.step_type = over ? ST_LAST : ST_MID;
+        if (over && s.term == TERM_NONE4) s.term = SGW_MAX_STEPS;
 #pragma unroll
-      for (int u = 0; u < F::NU; ++u) s.cum[u] += r[u];                          // safety_game_mo.py:996-997
-      over_now = over;
+        for (int u = 0; u < F::NU; ++u) s.cum[u] += r[u];
+        over_now = over;
+      }
     }
     SGW_STAMP(a, 2);
     // Episodic-return accumulators (end-of-batch all-reduce buffer).  Lanes whose episode just ended stage their
@@ -183,7 +215,7 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
     const int C = a.sp.A * a.sp.K + 1;
     bool acc_any = false;
     double acc_old = 0.0;
-    if (a.ep_acc) {
+    if (a.ep_acc && leader) {
       acc_any = __ballot(over_now && real) != 0ull;          // wave-uniform
       if (acc_any) {
         if (lane < C) acc_old = a.ep_acc[(long long)blockIdx.x * C + lane];   // consumed after the output phase
@@ -193,7 +225,7 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
       }
     }
     const bool last_t = (t == TT - 1);
-    if (a.write_every != 0 || last_t)
+    if ((a.write_every != 0 || last_t) && leader)
       emit<F>(s, r, discount, a, l, env0, lane, a.write_every != 0 ? (long long)t * a.n_pad : 0, true, true);
     SGW_STAMP(a, 3);
     if (acc_any) {
@@ -215,7 +247,7 @@ __global__ __launch_bounds__(WAVE) void k_engine(const KArgs a) {
     }
   }
   SGW_STAMP(a, 4);
-  F::store(s, a, env);
+  if (leader) F::store(s, a, env);
   SGW_STAMP(a, 5);
   SGW_STAMP_RT(a, 7);
 }
