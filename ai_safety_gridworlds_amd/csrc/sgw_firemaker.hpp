@@ -216,9 +216,9 @@ struct Firemaker {
   //   * Bernoulli draws: wavefront ballot + mbcnt give every needing cell its index in the env's draw order; the
   //     PCG64 stream is produced 64 draws at a time by jump-ahead (lane j holds state_{n+j+1} = A^(j+1) s_n + G_(j+1) inc,
   //     then the whole block leaps by A^64), so the sequence is exactly numpy's.
-  // The workgroup's 4 waves hold the same 64 envs (see k_engine); wave w spreads envs 16w..16w+15 and the results are
-  // exchanged through LDS with one barrier per update.
-  static constexpr int WAVES = 4;
+  // The workgroup's WAVES waves hold the same 64 envs (see k_engine); the burning envs are dealt round-robin to the
+  // waves and the results are exchanged through LDS with one barrier per update.
+  static constexpr int WAVES = 8;
   static constexpr bool COOPERATIVE = true;
   static constexpr int X_JUMP = 0, X_DRAWS = 2112, X_EXCH = X_DRAWS + WAVES * 128 * 8, LDS_EXTRA = X_EXCH + 2 * 7 * 64 * 8;
   struct Ctx { const uint64_t* jump; double* draws; uint64_t* exch; int wave, lane, parity; };
@@ -365,7 +365,11 @@ struct Firemaker {
     M5 res = old;
     uint64_t res_hi = s.rs_hi, res_lo = s.rs_lo;
     const bool has_work = ((old.a | old.b | old.c | old.d | old.e | cand.a | cand.b | cand.c | cand.d | cand.e) != 0ull);
-    uint32_t mine = (uint32_t)(__ballot(has_work) >> (cx.wave * 16)) & 0xffffu;             // scalar
+    // burning envs are dealt round-robin to the waves (k-th burning env -> wave k % WAVES): balanced whatever the pattern
+    const uint64_t work = __ballot(has_work);                                                // scalar
+    const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(work >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)work, 0u));
+    const bool mine_lane = has_work && (my_rank % WAVES) == cx.wave;                        // this wave spreads this lane's env
+    uint64_t mine = __ballot(mine_lane);
     if (mine) {
       const uint32_t valid = (uint32_t)p[P_VALID];
       const double cont = p[P_CONTINUE];
@@ -377,7 +381,7 @@ struct Firemaker {
       Ring g;
       g.a64.hi = cx.jump[64 * 4]; g.a64.lo = cx.jump[64 * 4 + 1];
       while (mine) {
-        const int e = cx.wave * 16 + __builtin_ctz(mine);
+        const int e = __builtin_ctzll(mine);
         mine &= mine - 1;
         const uint64_t o[5] = {rl64(old.a, e), rl64(old.b, e), rl64(old.c, e), rl64(old.d, e), rl64(old.e, e)};
         const uint64_t c[5] = {rl64(cand.a, e), rl64(cand.b, e), rl64(cand.c, e), rl64(cand.d, e), rl64(cand.e, e)};
@@ -407,14 +411,16 @@ struct Firemaker {
         res.e = me ? nf[4] : res.e; res_hi = me ? fin.hi : res_hi; res_lo = me ? fin.lo : res_lo;
       }
     }
-    // ---- exchange: lanes 16w..16w+15 of wave w own the results; everybody reads its env's row after the barrier
+    // ---- exchange: the wave that spread an env publishes its row; every wave reads the rows of the envs that had work
     uint64_t* ex = cx.exch + cx.parity * (7 * 64) + lane;
-    if ((lane >> 4) == cx.wave) {
+    if (mine_lane) {
       ex[0] = res.a; ex[64] = res.b; ex[128] = res.c; ex[192] = res.d; ex[256] = res.e; ex[320] = res_hi; ex[384] = res_lo;
     }
     __syncthreads();
-    s.fire.a = ex[0]; s.fire.b = ex[64]; s.fire.c = ex[128]; s.fire.d = ex[192]; s.fire.e = ex[256];
-    s.rs_hi = ex[320]; s.rs_lo = ex[384];
+    if (has_work) {
+      s.fire.a = ex[0]; s.fire.b = ex[64]; s.fire.c = ex[128]; s.fire.d = ex[192]; s.fire.e = ex[256];
+      s.rs_hi = ex[320]; s.rs_lo = ex[384];
+    }
     cx.parity ^= 1;                                            // double-buffered: the next update writes the other half
 
     const int n = __builtin_popcountll(s.fire.a & ~pword(l, P_TERR0 + 0)) + __builtin_popcountll(s.fire.b & ~pword(l, P_TERR0 + 1)) +
