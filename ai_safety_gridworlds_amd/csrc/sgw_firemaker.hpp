@@ -220,8 +220,8 @@ struct Firemaker {
   // waves and the results are exchanged through LDS with one barrier per update.
   static constexpr int WAVES = 8;
   static constexpr bool COOPERATIVE = true;
-  static constexpr int X_JUMP = 0, X_DRAWS = 2112, X_EXCH = X_DRAWS + WAVES * 128 * 8, LDS_EXTRA = X_EXCH + 2 * 7 * 64 * 8;
-  struct Ctx { const uint64_t* jump; double* draws; uint64_t* exch; int wave, lane, parity; };
+  static constexpr int X_JUMP = 0, X_DRAWS = 2112, X_EXCH = X_DRAWS + WAVES * 128 * 8, X_TICKET = X_EXCH + 2 * 7 * 64 * 8, LDS_EXTRA = X_TICKET + 16;
+  struct Ctx { const uint64_t* jump; double* draws; uint64_t* exch; uint32_t* ticket; int wave, lane, parity; uint32_t base; };
   static __device__ void init_ctx(Ctx& cx, const Lds& l) {
     cx.lane = threadIdx.x & 63;
     cx.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -231,6 +231,9 @@ struct Firemaker {
     cx.draws = reinterpret_cast<double*>(l.extra + X_DRAWS) + cx.wave * 128;
     cx.exch = reinterpret_cast<uint64_t*>(l.extra + X_EXCH);
     cx.parity = 0;
+    cx.ticket = reinterpret_cast<uint32_t*>(l.extra + X_TICKET);
+    if (threadIdx.x == 0) *cx.ticket = 0u;
+    cx.base = 0u;
   }
 
   struct U128 { uint64_t hi, lo; };
@@ -267,21 +270,29 @@ struct Firemaker {
     if constexpr (sh != 0 && q + 1 >= 0 && q + 1 <= 4) v |= o[q + 1] << (64 - sh);
     return v;
   }
-  template <int WI, int DR, int DC>
-  static __device__ void spread_from(double& cum, const uint64_t (&o)[5], uint64_t cw, uint32_t valid, const double (&q)[9]) {
+  // One source offset applied to all five passes at once: five INDEPENDENT dependency chains of straight-line code
+  // (no scalar branch around an empty mask: v_cndmask with m == 0 keeps cum), so the f64 pipeline always has work.
+  template <int DR, int DC>
+  static __device__ void spread_from(double (&cum)[5], const uint64_t (&o)[5], const uint64_t (&c)[5], const uint64_t (&vm)[9],
+                                     const double (&q)[9]) {
     constexpr int adr = DR < 0 ? -DR : DR, adc = DC < 0 ? -DC : DC, k = adr * 3 + adc;
     if constexpr (k != 0) {
-      if ((valid >> k) & 1u) {
-        const uint64_t m = window<WI, DR * W + DC>(o) & cw;
-        if (m) cum = sel_mask(m, 1.0 - (1.0 - cum) * q[k], cum);      // FM:601-609, sources in row-major order
-      }
+      constexpr int off = DR * W + DC;
+      const uint64_t m0 = window<0, off>(o) & c[0] & vm[k], m1 = window<1, off>(o) & c[1] & vm[k],
+                     m2 = window<2, off>(o) & c[2] & vm[k], m3 = window<3, off>(o) & c[3] & vm[k],
+                     m4 = window<4, off>(o) & c[4] & vm[k];
+      cum[0] = sel_mask(m0, 1.0 - (1.0 - cum[0]) * q[k], cum[0]);      // FM:601-609, sources in row-major order
+      cum[1] = sel_mask(m1, 1.0 - (1.0 - cum[1]) * q[k], cum[1]);
+      cum[2] = sel_mask(m2, 1.0 - (1.0 - cum[2]) * q[k], cum[2]);
+      cum[3] = sel_mask(m3, 1.0 - (1.0 - cum[3]) * q[k], cum[3]);
+      cum[4] = sel_mask(m4, 1.0 - (1.0 - cum[4]) * q[k], cum[4]);
     }
   }
-  template <int WI, int DR>
-  static __device__ void spread_row(double& cum, const uint64_t (&o)[5], uint64_t cw, uint32_t valid, const double (&q)[9]) {
-    spread_from<WI, DR, -2>(cum, o, cw, valid, q); spread_from<WI, DR, -1>(cum, o, cw, valid, q);
-    spread_from<WI, DR, 0>(cum, o, cw, valid, q); spread_from<WI, DR, 1>(cum, o, cw, valid, q);
-    spread_from<WI, DR, 2>(cum, o, cw, valid, q);
+  template <int DR>
+  static __device__ void spread_row(double (&cum)[5], const uint64_t (&o)[5], const uint64_t (&c)[5], const uint64_t (&vm)[9],
+                                    const double (&q)[9]) {
+    spread_from<DR, -2>(cum, o, c, vm, q); spread_from<DR, -1>(cum, o, c, vm, q); spread_from<DR, 0>(cum, o, c, vm, q);
+    spread_from<DR, 1>(cum, o, c, vm, q); spread_from<DR, 2>(cum, o, c, vm, q);
   }
   struct Ring { U128 xa, xb, a64, c64; int blk, consumed; };        // xa / xb: this lane's state in draw blocks blk / blk+1
   // make draws [consumed, consumed + 64) readable: block b lives in ring slot b & 1
@@ -295,13 +306,8 @@ struct Firemaker {
     lds_wave_sync();
   }
   template <int WI>
-  static __device__ void spread_pass(const uint64_t (&o)[5], const uint64_t (&c)[5], uint64_t (&nf)[5], uint32_t valid,
-                                     const double (&q)[9], uint32_t ws, const Lds& l, Ring& g, Ctx& cx) {
-    const uint64_t cw = c[WI];
+  static __device__ void draw_pass(double cum, uint64_t cw, uint64_t (&nf)[5], uint32_t valid, uint32_t ws, const Lds& l, Ring& g, Ctx& cx) {
     if (cw == 0) return;
-    double cum = 0.0;
-    spread_row<WI, -2>(cum, o, cw, valid, q); spread_row<WI, -1>(cum, o, cw, valid, q); spread_row<WI, 0>(cum, o, cw, valid, q);
-    spread_row<WI, 1>(cum, o, cw, valid, q); spread_row<WI, 2>(cum, o, cw, valid, q);
     if (ws & 3u) {                                                     // then the virtual workshop sources, agent order
       const int t = WI * 64 + cx.lane, tr = (t * 241) >> 12, tc = t - tr * W;
       const bool is_cand = (cw >> cx.lane) & 1ull;
@@ -365,24 +371,30 @@ struct Firemaker {
     M5 res = old;
     uint64_t res_hi = s.rs_hi, res_lo = s.rs_lo;
     const bool has_work = ((old.a | old.b | old.c | old.d | old.e | cand.a | cand.b | cand.c | cand.d | cand.e) != 0ull);
-    // burning envs are dealt round-robin to the waves (k-th burning env -> wave k % WAVES): balanced whatever the pattern
+    // burning envs are handed out dynamically: every wave pulls tickets from one LDS counter until it draws one past
+    // the end (the counter only grows; all waves track the same base), so a wave that gets cheap envs takes more of them
     const uint64_t work = __ballot(has_work);                                                // scalar
+    const int n_work = __builtin_popcountll(work);
     const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(work >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)work, 0u));
-    const bool mine_lane = has_work && (my_rank % WAVES) == cx.wave;                        // this wave spreads this lane's env
-    uint64_t mine = __ballot(mine_lane);
-    if (mine) {
+    bool mine_lane = false;                                                                  // this wave spread this lane's env
+    if (n_work) {
       const uint32_t valid = (uint32_t)p[P_VALID];
       const double cont = p[P_CONTINUE];
       double q[9];
+      uint64_t vm[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) q[k] = 1.0 - p[P_SPREAD0 + k];
+      for (int k = 0; k < 9; ++k) { q[k] = 1.0 - p[P_SPREAD0 + k]; vm[k] = ((valid >> k) & 1u) ? ~0ull : 0ull; }
       const uint64_t* jt = cx.jump + (lane + 1) * 4;
       const U128 aj = {jt[0], jt[1]}, gj = {jt[2], jt[3]};
       Ring g;
       g.a64.hi = cx.jump[64 * 4]; g.a64.lo = cx.jump[64 * 4 + 1];
-      while (mine) {
-        const int e = __builtin_ctzll(mine);
-        mine &= mine - 1;
+      for (;;) {
+        uint32_t tk = 0;
+        if (lane == 0) tk = atomicAdd(cx.ticket, 1u);
+        const int k = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)tk) - cx.base);
+        if (k >= n_work) break;
+        const int e = __builtin_ctzll(__ballot(has_work && my_rank == k));
+        mine_lane = mine_lane || (lane == e);
         const uint64_t o[5] = {rl64(old.a, e), rl64(old.b, e), rl64(old.c, e), rl64(old.d, e), rl64(old.e, e)};
         const uint64_t c[5] = {rl64(cand.a, e), rl64(cand.b, e), rl64(cand.c, e), rl64(cand.d, e), rl64(cand.e, e)};
         uint64_t nf[5] = {o[0], o[1], o[2], o[3], o[4]};
@@ -395,9 +407,12 @@ struct Firemaker {
         g.blk = 0; g.consumed = 0;
         lds_wave_sync();
         cx.draws[lane] = pcg_double(g.xa); cx.draws[64 + lane] = pcg_double(g.xb);
-        spread_pass<0>(o, c, nf, valid, q, wse, l, g, cx); spread_pass<1>(o, c, nf, valid, q, wse, l, g, cx);
-        spread_pass<2>(o, c, nf, valid, q, wse, l, g, cx); spread_pass<3>(o, c, nf, valid, q, wse, l, g, cx);
-        spread_pass<4>(o, c, nf, valid, q, wse, l, g, cx);
+        double cum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        spread_row<-2>(cum, o, c, vm, q); spread_row<-1>(cum, o, c, vm, q); spread_row<0>(cum, o, c, vm, q);
+        spread_row<1>(cum, o, c, vm, q); spread_row<2>(cum, o, c, vm, q);
+        draw_pass<0>(cum[0], c[0], nf, valid, wse, l, g, cx); draw_pass<1>(cum[1], c[1], nf, valid, wse, l, g, cx);
+        draw_pass<2>(cum[2], c[2], nf, valid, wse, l, g, cx); draw_pass<3>(cum[3], c[3], nf, valid, wse, l, g, cx);
+        draw_pass<4>(cum[4], c[4], nf, valid, wse, l, g, cx);
         continue_pass<0>(o, nf, cont, g, cx); continue_pass<1>(o, nf, cont, g, cx); continue_pass<2>(o, nf, cont, g, cx);
         continue_pass<3>(o, nf, cont, g, cx); continue_pass<4>(o, nf, cont, g, cx);
         U128 fin = st;
@@ -410,6 +425,7 @@ struct Firemaker {
         res.a = me ? nf[0] : res.a; res.b = me ? nf[1] : res.b; res.c = me ? nf[2] : res.c; res.d = me ? nf[3] : res.d;
         res.e = me ? nf[4] : res.e; res_hi = me ? fin.hi : res_hi; res_lo = me ? fin.lo : res_lo;
       }
+      cx.base += (uint32_t)(n_work + WAVES);                     // every wave drew exactly one ticket past the end
     }
     // ---- exchange: the wave that spread an env publishes its row; every wave reads the rows of the envs that had work
     uint64_t* ex = cx.exch + cx.parity * (7 * 64) + lane;
