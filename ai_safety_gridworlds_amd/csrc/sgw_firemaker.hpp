@@ -249,6 +249,12 @@ struct Firemaker {
     v = (v >> rot) | (v << ((64u - rot) & 63u));
     return (double)(v >> 11) * (1.0 / 9007199254740992.0);
   }
+  // values every lane holds identically (LDS constants): move them to SGPRs so they cost no vector registers
+  static __device__ uint64_t uniform_u64(uint64_t v) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+  }
+  static __device__ double uniform_f64(double v) { return __longlong_as_double((long long)uniform_u64((uint64_t)__double_as_longlong(v))); }
   static __device__ uint32_t rl32(uint32_t v, int e) { return (uint32_t)__builtin_amdgcn_readlane((int)v, e); }
   static __device__ uint64_t rl64(uint64_t v, int e) { return (uint64_t)rl32((uint32_t)v, e) | ((uint64_t)rl32((uint32_t)(v >> 32), e) << 32); }
   // per-lane select by bit `lane` of a SCALAR mask: one v_cndmask per half, the mask goes in as an SGPR pair
@@ -378,16 +384,16 @@ struct Firemaker {
     const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(work >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)work, 0u));
     bool mine_lane = false;                                                                  // this wave spread this lane's env
     if (n_work) {
-      const uint32_t valid = (uint32_t)p[P_VALID];
-      const double cont = p[P_CONTINUE];
+      const uint32_t valid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p[P_VALID]);
+      const double cont = uniform_f64(p[P_CONTINUE]);
       double q[9];
       uint64_t vm[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) { q[k] = 1.0 - p[P_SPREAD0 + k]; vm[k] = ((valid >> k) & 1u) ? ~0ull : 0ull; }
+      for (int k = 0; k < 9; ++k) { q[k] = uniform_f64(1.0 - p[P_SPREAD0 + k]); vm[k] = ((valid >> k) & 1u) ? ~0ull : 0ull; }
       const uint64_t* jt = cx.jump + (lane + 1) * 4;
       const U128 aj = {jt[0], jt[1]}, gj = {jt[2], jt[3]};
       Ring g;
-      g.a64.hi = cx.jump[64 * 4]; g.a64.lo = cx.jump[64 * 4 + 1];
+      g.a64.hi = uniform_u64(cx.jump[64 * 4]); g.a64.lo = uniform_u64(cx.jump[64 * 4 + 1]);
       for (;;) {
         uint32_t tk = 0;
         if (lane == 0) tk = atomicAdd(cx.ticket, 1u);
