@@ -11,12 +11,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libsgw_oracle.so")
-SOURCES = ["sgw_oracle.c", "sgw_oracle_ma.c"]
+SOURCES = ["sgw_oracle.c", "sgw_oracle_ma.c", "sgw_oracle_ima.c"]
 
 
 def build(force=False, verbose=False):
   srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
-  deps = srcs + [os.path.join(HERE, "sgw_oracle.h")]
+  deps = srcs + [os.path.join(HERE, "sgw_oracle.h"), os.path.join(HERE, "sgw_pcg.h")]
   if (not force and os.path.exists(LIB)
       and os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps)):
     return LIB

@@ -66,33 +66,7 @@ typedef struct {
   uint8_t view_supervisor[33 * 33];
 } or_ma_timestep;
 
-/* ---------------------------------------------------------------- numpy PCG64 -- */
-typedef unsigned __int128 u128;
-typedef struct { u128 state, inc; int has_uint32; uint32_t uinteger; } pcg_t;
-static const u128 PCG_MULT = (((u128)0x2360ED051FC65DA4ULL) << 64) | 0x4385DF649FCCF645ULL;
-
-static uint64_t pcg_next64(pcg_t* g) {        /* pcg64.h: pcg_setseq_128_step_r then XSL-RR 128/64 */
-  g->state = g->state * PCG_MULT + g->inc;
-  uint64_t hi = (uint64_t)(g->state >> 64), lo = (uint64_t)g->state;
-  uint64_t x = hi ^ lo;
-  unsigned rot = (unsigned)(hi >> 58);
-  return (x >> rot) | (x << ((-rot) & 63));
-}
-static uint32_t pcg_next32(pcg_t* g) {        /* pcg64.h pcg64_next32: low half first, high half buffered */
-  if (g->has_uint32) { g->has_uint32 = 0; return g->uinteger; }
-  uint64_t n = pcg_next64(g);
-  g->has_uint32 = 1; g->uinteger = (uint32_t)(n >> 32);
-  return (uint32_t)n;
-}
-static double pcg_random(pcg_t* g) { return (double)(pcg_next64(g) >> 11) * (1.0 / 9007199254740992.0); }
-static uint64_t random_interval(pcg_t* g, uint64_t max) {   /* distributions.c random_interval */
-  if (max == 0) return 0;
-  uint64_t mask = max, value;
-  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
-  if (max <= 0xffffffffULL) { while ((value = (pcg_next32(g) & mask)) > max) {} }
-  else { while ((value = (pcg_next64(g) & mask)) > max) {} }
-  return value;
-}
+#include "sgw_pcg.h"
 
 /* ------------------------------------------------------------------- the env -- */
 typedef struct {

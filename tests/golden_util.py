@@ -20,7 +20,7 @@ def fixture_names(prefixes=None):
 
 def load(name):
   fx = np.load(os.path.join(GOLDEN, name + ".npz"))
-  meta = {k[5:]: fx[k].item() for k in fx.files if k.startswith("meta_")}
+  meta = {k[5:]: (fx[k].item() if fx[k].ndim == 0 else fx[k]) for k in fx.files if k.startswith("meta_")}
   meta["family_name"] = FAMILY_NAMES.get(meta["family"], meta["family"])
   meta["kwargs"] = dict(ast.literal_eval(meta["kwargs"]))
   meta["dim_names"] = [s for s in meta.get("dim_names", "").split("|") if s]
