@@ -7,9 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsgw.so")
 
 MAX_CELLS, MAX_K, MAX_M, MAX_AGENTS, N_PARAMS, ENV_ALIGN = 320, 16, 16, 4, 48, 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 
-ISLAND_NAVIGATION_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INTERRUPTIBILITY, FIREMAKER_EX_MA = range(5)
+ISLAND_NAVIGATION_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INTERRUPTIBILITY, FIREMAKER_EX_MA, ISLAND_NAVIGATION_EX_MA = range(6)
 FIRST, MID, LAST, DEAD = 0, 1, 2, 3
 TERM_NONE = 255
 
@@ -88,8 +88,8 @@ def lib():
   L.sgw_observe_layers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_void_p, C.c_void_p]
   L.sgw_view_bytes.argtypes = [C.c_void_p]
-  L.sgw_agent_views.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint8, C.c_void_p, C.c_void_p]
-  L.sgw_agent_layer_views.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint8, C.c_void_p, C.c_void_p]
+  L.sgw_agent_views.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint8, C.c_void_p, C.c_void_p]
+  L.sgw_agent_layer_views.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint8, C.c_void_p, C.c_void_p]
   L.sgw_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   L.sgw_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   if L.sgw_abi_version() != ABI_VERSION:

@@ -10,6 +10,7 @@
 #include "../../include/sgw.h"
 #include "sgw_boat.hpp"
 #include "sgw_firemaker.hpp"
+#include "sgw_island_ma.hpp"
 #include "sgw_island.hpp"
 #include "sgw_kernels.hpp"
 #include "sgw_safeint.hpp"
@@ -52,6 +53,7 @@ static int family_words(const sgw_spec& sp) {
     case SGW_BOAT_RACE: return Boat::words(sp.K, sp.H * sp.W);
     case SGW_SAFE_INTERRUPTIBILITY: return SafeInt::words();
     case SGW_FIREMAKER_EX_MA: return Firemaker::words();
+    case SGW_ISLAND_NAVIGATION_EX_MA: return IslandMa::words(sp.K);
     default: return -1;
   }
 }
@@ -170,7 +172,7 @@ int sgw_set_episode_bits(sgw_engine* e, const uint8_t* bits_dev, int n_per_env, 
 
 int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev) {
   if (!e || !pcg_state_dev) return fail(SGW_ERR_ARG, "sgw_set_rng_state: null argument");
-  if (e->spec.family != SGW_FIREMAKER_EX_MA)
+  if (e->spec.family != SGW_FIREMAKER_EX_MA && e->spec.family != SGW_ISLAND_NAVIGATION_EX_MA)
     return fail(SGW_ERR_UNSUPPORTED, "sgw_set_rng_state: this game family has no env-side RNG stream");
   HIP_TRY(hipSetDevice(e->device));
   hipLaunchKernelGGL(k_set_rng, dim3((unsigned)((e->n_envs + 255) / 256)), dim3(256), 0, 0, e->state_dev, e->n_pad,
@@ -193,6 +195,10 @@ static int ensure_acc(sgw_engine* e) {
 static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
   if (e->spec.family == SGW_FIREMAKER_EX_MA && !e->rng_set)
     return fail(SGW_ERR_ARG, "firemaker_ex_ma: call sgw_set_rng_state first (the env draws from a per-env numpy PCG64 stream)");
+  if (e->spec.family == SGW_ISLAND_NAVIGATION_EX_MA && !e->rng_set &&
+      (e->spec.flags & (IslandMa::F_SHUFFLE | (3 << IslandMa::F_MRF_SHIFT))))
+    return fail(SGW_ERR_ARG, "island_navigation_ex_ma: call sgw_set_rng_state first (action-order shuffle / map randomisation "
+                             "draw from a per-env numpy PCG64 stream)");
   HIP_TRY(hipSetDevice(e->device));
   a.sp = e->ks; a.tables = e->tables_dev; a.state = e->state_dev;
   a.n_pad = e->n_pad; a.n_envs = e->n_envs; a.env_id_base = e->env_id_base;
@@ -214,6 +220,7 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
     case SGW_BOAT_RACE: SGW_LAUNCH(Boat); break;
     case SGW_SAFE_INTERRUPTIBILITY: SGW_LAUNCH(SafeInt); break;
     case SGW_FIREMAKER_EX_MA: SGW_LAUNCH(Firemaker); break;
+    case SGW_ISLAND_NAVIGATION_EX_MA: SGW_LAUNCH(IslandMa); break;
     default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
   }
 #undef SGW_LAUNCH
@@ -383,32 +390,42 @@ static ViewSpec make_viewspec(const sgw_engine* e) {
 
 int sgw_view_bytes(const sgw_engine* e) { return e ? make_viewspec(e).total : 0; }
 
-int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agent_pos_dev, uint8_t outside_chr,
-                    uint8_t* views_dev, void* stream) {
+static int check_rotation(const sgw_engine* e, const ViewSpec& v, const uint8_t* flags) {
+  if (!flags) return SGW_OK;
+  for (int a = 0; a < v.A; ++a)
+    if (v.vh[a] != v.vw[a]) return fail(SGW_ERR_UNSUPPORTED, "agent views: rotation by observation direction needs square windows");
+  (void)e;
+  return SGW_OK;
+}
+
+int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agent_pos_dev, const uint8_t* agent_flags_dev,
+                    uint8_t outside_chr, uint8_t* views_dev, void* stream) {
   if (!e || !board_dev || !agent_pos_dev || !views_dev) return fail(SGW_ERR_ARG, "sgw_agent_views: null argument");
   ViewSpec v = make_viewspec(e);
   if (v.total <= 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_agent_views: the spec defines no agent views");
   for (int a = 0; a < v.A; ++a) if (v.vw[a] <= 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_agent_views: every agent needs a view");
+  if (check_rotation(e, v, agent_flags_dev)) return SGW_ERR_UNSUPPORTED;
   HIP_TRY(hipSetDevice(e->device));
   long long total = e->n_envs * v.total;
   int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   hipLaunchKernelGGL(k_agent_views, dim3(blocks), dim3(256), 0, (hipStream_t)stream, board_dev, agent_pos_dev,
-                     e->n_envs, v, outside_chr, views_dev);
+                     agent_flags_dev, e->n_envs, v, outside_chr, views_dev);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }
 
-int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_t* agent_pos_dev,
+int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_t* agent_pos_dev, const uint8_t* agent_flags_dev,
                           const uint8_t* layer_chars_dev, int n_layers, uint8_t outside_chr, uint8_t* out_dev, void* stream) {
   if (!e || !layers_dev || !agent_pos_dev || !layer_chars_dev || !out_dev || n_layers < 1)
     return fail(SGW_ERR_ARG, "sgw_agent_layer_views: bad argument");
   ViewSpec v = make_viewspec(e);
   if (v.total <= 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_agent_layer_views: the spec defines no agent views");
+  if (check_rotation(e, v, agent_flags_dev)) return SGW_ERR_UNSUPPORTED;
   HIP_TRY(hipSetDevice(e->device));
   long long total = e->n_envs * (long long)v.total * n_layers;
   int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
   hipLaunchKernelGGL(k_agent_layer_views, dim3(blocks), dim3(256), 0, (hipStream_t)stream, layers_dev, agent_pos_dev,
-                     e->n_envs, v, layer_chars_dev, n_layers, outside_chr, out_dev);
+                     agent_flags_dev, e->n_envs, v, layer_chars_dev, n_layers, outside_chr, out_dev);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }

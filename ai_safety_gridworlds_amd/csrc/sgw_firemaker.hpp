@@ -59,6 +59,8 @@ struct Firemaker {
   static constexpr int NMETRIC = 16;
   static constexpr int NSPRITE = 3;
   static constexpr bool CUSTOM_BOARD = true;
+  static constexpr bool PER_AGENT = false;
+  static __device__ int slot(const KSpec& sp, int u) { return sp.dim_slot[0][u]; }
   static constexpr bool LDS_SCRATCH_M = false;
   static constexpr int W = 17, H = 17, CELLS = 289;
   enum { F_SHUFFLE = 1 };

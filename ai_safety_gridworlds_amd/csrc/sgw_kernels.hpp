@@ -37,11 +37,11 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
   }
   if (o.reward) {
 #pragma unroll
-    for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_r, l.trash, lane, K, sp.dim_slot[0][u]) = r[u];
+    for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_r, l.trash, lane, K, F::slot(sp, u)) = r[u];
   }
   if (o.cumulative) {
 #pragma unroll
-    for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_c, l.trash, lane, K, sp.dim_slot[0][u]) = s.cum[u];
+    for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_c, l.trash, lane, K, F::slot(sp, u)) = s.cum[u];
   }
   if (o.metrics && M > 0) {
 #pragma unroll
@@ -85,9 +85,19 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
     const long long row = toff + env;
     if (o.step_type) {
 #pragma unroll
-      for (int ag = 0; ag < F::NA; ++ag) store_wt(o.step_type + row * F::NA + ag, (uint8_t)s.step_type);
+      for (int ag = 0; ag < F::NA; ++ag) {
+        if constexpr (F::PER_AGENT) store_wt(o.step_type + row * F::NA + ag, (uint8_t)F::agent_step_type(s, ag));
+        else store_wt(o.step_type + row * F::NA + ag, (uint8_t)s.step_type);
+      }
     }
-    if (o.term_reason) store_wt(o.term_reason + row, (s.step_type == ST_LAST) ? (uint8_t)s.term : (uint8_t)SGW_TERM_NONE);
+    if (o.term_reason) {
+      if constexpr (F::PER_AGENT) {
+#pragma unroll
+        for (int ag = 0; ag < F::NA; ++ag) store_wt(o.term_reason + row * F::NA + ag, (uint8_t)F::agent_term(s, ag));
+      } else {
+        store_wt(o.term_reason + row, (s.step_type == ST_LAST) ? (uint8_t)s.term : (uint8_t)SGW_TERM_NONE);
+      }
+    }
     if (o.actual_action) {
 #pragma unroll
       for (int ag = 0; ag < F::NA; ++ag) store_wt(o.actual_action + row * F::NA + ag, (int8_t)F::actual(s, ag));
@@ -105,7 +115,14 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
     }
     if (o.discount) store_wt(o.discount + row, discount);
     if (o.hidden) store_wt(o.hidden + row, F::hidden(s));
-    if (o.safety) store_wt(o.safety + row, F::safety(s));
+    if (o.safety) {
+      if constexpr (F::PER_AGENT) {
+#pragma unroll
+        for (int ag = 0; ag < F::NA; ++ag) store_wt(o.safety + row * F::NA + ag, (int32_t)F::agent_safety(s, ag, sp));
+      } else {
+        store_wt(o.safety + row, F::safety(s));
+      }
+    }
     if (o.frame) store_wt(o.frame + row, s.frame);
   }
 }
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
       if (acc_any) {
         if (lane < C) acc_old = a.ep_acc[(long long)blockIdx.x * C + lane];   // consumed after the output phase
 #pragma unroll
-        for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_a, l.trash, lane, C, a.sp.dim_slot[0][u]) = over_now ? s.cum[u] : 0.0;
+        for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_a, l.trash, lane, C, F::slot(a.sp, u)) = over_now ? s.cum[u] : 0.0;
         l.vec_a[lane * C + C - 1] = over_now ? 1.0 : 0.0;    // made visible by the output phase's LDS fence
       }
     }
@@ -380,8 +397,16 @@ __global__ void k_observe_layers(const uint8_t* board, long long n, int HW, int 
 
 // agent-centric windows of the rendered board (safety_game_moma.py:1996-2101), one thread per output byte
 struct ViewSpec { int A, H, W, total; int off[SGW_MAX_AGENTS], up[SGW_MAX_AGENTS], left[SGW_MAX_AGENTS], vh[SGW_MAX_AGENTS], vw[SGW_MAX_AGENTS]; };
-__global__ void k_agent_views(const uint8_t* board, const uint8_t* pos, long long n, ViewSpec v, uint8_t outside,
-                              uint8_t* views) {
+// rot90 by the agent's observation direction (Directions LEFT=0 RIGHT=1 UP=2 DOWN=3 in bits 3-4 of agent_flags): first crop,
+// then rotate (safety_game_moma.py:2085-2096).  (vr, vc) of the OUTPUT -> (row, col) of the crop; square windows only.
+__device__ inline void view_unrotate(int dir, int n, int& vr, int& vc) {
+  const int r = vr, c = vc;
+  if (dir == 3) { vr = n - 1 - r; vc = n - 1 - c; }          // DOWN: rot90 k=2
+  else if (dir == 0) { vr = n - 1 - c; vc = r; }             // LEFT: rot90 k=-1 (clockwise)
+  else if (dir == 1) { vr = c; vc = n - 1 - r; }             // RIGHT: rot90 k=1 (counter-clockwise)
+}
+__global__ void k_agent_views(const uint8_t* board, const uint8_t* pos, const uint8_t* flags, long long n, ViewSpec v,
+                              uint8_t outside, uint8_t* views) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = n * v.total;
   for (; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -390,15 +415,16 @@ __global__ void k_agent_views(const uint8_t* board, const uint8_t* pos, long lon
 #pragma unroll
     for (int k = 1; k < SGW_MAX_AGENTS; ++k) if (k < v.A && b >= v.off[k]) ag = k;
     b -= v.off[ag];
-    const int vr = b / v.vw[ag], vc = b % v.vw[ag];
+    int vr = b / v.vw[ag], vc = b % v.vw[ag];
+    if (flags) view_unrotate((flags[e * v.A + ag] >> 3) & 3, v.vw[ag], vr, vc);
     const int r = (int)pos[(e * v.A + ag) * 2] - v.up[ag] + vr, c = (int)pos[(e * v.A + ag) * 2 + 1] - v.left[ag] + vc;
     views[i] = (r < 0 || r >= v.H || c < 0 || c >= v.W) ? outside : board[e * (v.H * v.W) + r * v.W + c];
   }
 }
 
 // per-layer agent windows: out[e][agent][layer][vr][vc]
-__global__ void k_agent_layer_views(const uint8_t* layers, const uint8_t* pos, long long n, ViewSpec v, const uint8_t* chars,
-                                    int L, uint8_t outside, uint8_t* out) {
+__global__ void k_agent_layer_views(const uint8_t* layers, const uint8_t* pos, const uint8_t* flags, long long n, ViewSpec v,
+                                    const uint8_t* chars, int L, uint8_t outside, uint8_t* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long per_env = (long long)v.total * L, total = n * per_env;
   for (; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -409,7 +435,8 @@ __global__ void k_agent_layer_views(const uint8_t* layers, const uint8_t* pos, l
     b -= v.off[ag] * L;
     const int cells = v.vh[ag] * v.vw[ag];
     const int li = b / cells, c2 = b % cells;
-    const int vr = c2 / v.vw[ag], vc = c2 % v.vw[ag];
+    int vr = c2 / v.vw[ag], vc = c2 % v.vw[ag];
+    if (flags) view_unrotate((flags[e * v.A + ag] >> 3) & 3, v.vw[ag], vr, vc);
     const int r = (int)pos[(e * v.A + ag) * 2] - v.up[ag] + vr, c = (int)pos[(e * v.A + ag) * 2 + 1] - v.left[ag] + vc;
     out[i] = (r < 0 || r >= v.H || c < 0 || c >= v.W) ? (uint8_t)(chars[li] == outside)
                                                      : layers[(e * L + li) * (v.H * v.W) + r * v.W + c];

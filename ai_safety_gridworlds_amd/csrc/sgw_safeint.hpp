@@ -98,6 +98,8 @@ struct SafeInt {
   static constexpr int NSPRITE = 1;
   static constexpr int NA = 1;
   static constexpr bool CUSTOM_BOARD = false;
+  static constexpr bool PER_AGENT = false;
+  static __device__ int slot(const KSpec& sp, int u) { return sp.dim_slot[0][u]; }
   static constexpr bool LDS_SCRATCH_M = false;   // borrows the metrics staging rows as per-lane scratch
   static constexpr int WAVES = 1, LDS_EXTRA = 0;
   static constexpr bool COOPERATIVE = false;

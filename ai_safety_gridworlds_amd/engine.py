@@ -21,12 +21,13 @@ ALL_OUTPUTS = N.OUT_FIELDS
 
 def _dtype_shape(spec, name):
   HW, A, K, M = spec.H * spec.W, spec.A, spec.K, max(spec.M, 1)
+  per_agent = (A,) if getattr(spec, "per_agent", False) else ()     # agents terminate individually (island_navigation_ex_ma)
   return {
       "board": (torch.uint8, (HW,)), "obs_board": (torch.float32, (HW,)),
       "reward": (torch.float64, (A * K,)), "cumulative": (torch.float64, (A * K,)),
-      "step_type": (torch.uint8, (A,)), "term_reason": (torch.uint8, ()),
+      "step_type": (torch.uint8, (A,)), "term_reason": (torch.uint8, per_agent),
       "actual_action": (torch.int8, (A,)), "discount": (torch.float64, ()),
-      "hidden": (torch.float64, ()), "safety": (torch.int32, ()),
+      "hidden": (torch.float64, ()), "safety": (torch.int32, per_agent),
       "metrics": (torch.float64, (M,)), "frame": (torch.int32, ()), "agent_pos": (torch.uint8, (A * 2,)),
       "agent_flags": (torch.uint8, (A,)),
   }[name]
@@ -175,7 +176,7 @@ class BatchedEngine(object):
             "sgw_set_episode_bits")
 
   def set_rng_seeds(self, seeds):
-    """firemaker_ex_ma: per-env numpy streams Generator(PCG64(SeedSequence(seed))) -- what
+    """firemaker_ex_ma / island_navigation_ex_ma: per-env numpy streams Generator(PCG64(SeedSequence(seed))) -- what
     gymnasium.utils.seeding.np_random(seed) builds (safety_game_mo.py:283-291).  seeds: int array [N]."""
     seeds = np.asarray(seeds).reshape(-1)
     assert len(seeds) == self.n_envs
@@ -191,32 +192,41 @@ class BatchedEngine(object):
     t = torch.from_numpy(np.ascontiguousarray(words, dtype=np.uint64).view(np.int64)).to(self.device)
     N.check(self._lib.sgw_set_rng_state(self._h, t.data_ptr()), "sgw_set_rng_state")
 
-  def agent_views(self, board=None, agent_pos=None, outside_chr='#'):
-    """Agent-centric windows (safety_game_moma.py:1996-2101): list of uint8 [N, h_a, w_a] tensors, one per agent."""
+  def _view_flags(self, agent_flags):
+    if not getattr(self.spec, "rotating_views", False):
+      return None
+    t = self._bufs["agent_flags"] if agent_flags is None else agent_flags
+    return t.data_ptr()
+
+  def agent_views(self, board=None, agent_pos=None, outside_chr=None, agent_flags=None):
+    """Agent-centric windows (safety_game_moma.py:1996-2101): list of uint8 [N, h_a, w_a] tensors, one per agent
+    (rotated by the agent's observation direction when the env's observation_direction_mode is not 0)."""
     board = self._bufs["board"] if board is None else board
     agent_pos = self._bufs["agent_pos"] if agent_pos is None else agent_pos
+    outside_chr = outside_chr or getattr(self.spec, "what_lies_outside", '#')
     vb = int(self._lib.sgw_view_bytes(self._h))
     views = torch.empty((self.n_envs, vb), dtype=torch.uint8, device=self.device)
-    N.check(self._lib.sgw_agent_views(self._h, board.data_ptr(), agent_pos.data_ptr(), ord(outside_chr),
-                                      views.data_ptr(), self._stream()), "sgw_agent_views")
+    N.check(self._lib.sgw_agent_views(self._h, board.data_ptr(), agent_pos.data_ptr(), self._view_flags(agent_flags),
+                                      ord(outside_chr), views.data_ptr(), self._stream()), "sgw_agent_views")
     out, off = [], 0
     for (h, w) in self.spec.view_shapes:
       out.append(views[:, off:off + h * w].reshape(self.n_envs, h, w))
       off += h * w
     return out
 
-  def agent_layer_views(self, layers=None, agent_pos=None, outside_chr='#'):
+  def agent_layer_views(self, layers=None, agent_pos=None, outside_chr=None, agent_flags=None):
     """Per-agent crops of every observation layer (safety_game_moma.py:430-525): list over agents of uint8
     [N, L, h_a, w_a] tensors -- the per-agent layer cube the Zoo wrapper exposes."""
     sp = self.spec
     if layers is None:
       layers = self.observe_layers()
     agent_pos = self._bufs["agent_pos"] if agent_pos is None else agent_pos
+    outside_chr = outside_chr or getattr(sp, "what_lies_outside", '#')
     L = len(sp.layer_chars)
     chars, _ = self._layer_tables
     vb = int(self._lib.sgw_view_bytes(self._h))
     out = torch.empty((self.n_envs, vb * L), dtype=torch.uint8, device=self.device)
-    N.check(self._lib.sgw_agent_layer_views(self._h, layers.data_ptr(), agent_pos.data_ptr(), chars.data_ptr(), L,
+    N.check(self._lib.sgw_agent_layer_views(self._h, layers.data_ptr(), agent_pos.data_ptr(), self._view_flags(agent_flags), chars.data_ptr(), L,
                                             ord(outside_chr), out.data_ptr(), self._stream()), "sgw_agent_layer_views")
     res, off = [], 0
     for (h, w) in sp.view_shapes:

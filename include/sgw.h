@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SGW_ABI_VERSION 3
+#define SGW_ABI_VERSION 4
 #define SGW_MAX_CELLS 320      /* >= 17*17 */
 #define SGW_MAX_K 16           /* reward dimensions per agent */
 #define SGW_MAX_M 16           /* metrics per env */
@@ -44,7 +44,8 @@ enum sgw_family {
   SGW_BOAT_RACE_EX = 1,           /* environments/boat_race_ex.py */
   SGW_BOAT_RACE = 2,              /* environments/boat_race.py */
   SGW_SAFE_INTERRUPTIBILITY = 3,  /* environments/safe_interruptibility.py */
-  SGW_FIREMAKER_EX_MA = 4         /* environments/firemaker_ex_ma.py */
+  SGW_FIREMAKER_EX_MA = 4,        /* environments/firemaker_ex_ma.py */
+  SGW_ISLAND_NAVIGATION_EX_MA = 5 /* environments/island_navigation_ex_ma.py (agents terminate individually) */
 };
 
 enum sgw_step_type { SGW_FIRST = 0, SGW_MID = 1, SGW_LAST = 2, SGW_DEAD = 3 }; /* rl/environment{,_ma}.py */
@@ -87,15 +88,18 @@ typedef struct sgw_out {
   double* reward;        /* [N_pad, A, K] reward vector in sorted enabled-dimension order; 0 at FIRST */
   double* cumulative;    /* [N_pad, A, K] episode return so far (observation['cumulative_reward']) */
   uint8_t* step_type;    /* [N_pad, A]    sgw_step_type; done == SGW_LAST */
-  uint8_t* term_reason;  /* [N_pad]       sgw_term, SGW_TERM_NONE unless LAST */
+  uint8_t* term_reason;  /* [N_pad]       sgw_term, SGW_TERM_NONE unless LAST; [N_pad, A] for island_navigation_ex_ma (per agent,
+                          *               set once EVERY agent is done, safety_game_moma.py:1219-1233) */
   int8_t* actual_action; /* [N_pad, A]    extra_observations['actual_actions'], -1 = absent */
   double* discount;      /* [N_pad]       NaN at FIRST (None) */
   double* hidden;        /* [N_pad]       the_plot['hidden_reward'] of the running episode */
-  int32_t* safety;       /* [N_pad]       environment_data['safety'] (island_navigation_ex) */
+  int32_t* safety;       /* [N_pad]       environment_data['safety'] (island_navigation_ex); [N_pad, A] 'safety_<agent>' for
+                          *               island_navigation_ex_ma */
   double* metrics;       /* [N_pad, M]    metrics_dict values in METRICS_LABELS order */
   int32_t* frame;        /* [N_pad]       the_plot.frame */
   uint8_t* agent_pos;    /* [N_pad, A, 2] (row, col) of every agent sprite */
-  uint8_t* agent_flags;  /* [N_pad, A]    bit0: a dynamic drape (firemaker: fire) lies hidden under this agent */
+  uint8_t* agent_flags;  /* [N_pad, A]    bit0: a dynamic drape (firemaker: fire) lies hidden under this agent; bits 1-2 action
+                          *               direction, bits 3-4 observation direction (Directions LEFT=0 RIGHT=1 UP=2 DOWN=3) */
 } sgw_out;
 
 typedef struct sgw_engine sgw_engine;
@@ -192,15 +196,17 @@ int sgw_observe_layers(sgw_engine* e, const uint8_t* board_dev, const uint8_t* l
 /* Agent-centric observations (get_agent_perspective, safety_game_moma.py:1996-2101): for every env and
  * agent a, the (up+down+1) x (left+right+1) window of the rendered board centred on the agent, cells
  * outside the board filled with `outside_chr`.  views_dev uint8 [N, view_bytes] with agent a's window at
- * byte offset sum of the previous agents' window sizes (sgw_view_bytes gives the row size). */
+ * byte offset sum of the previous agents' window sizes (sgw_view_bytes gives the row size).
+ * agent_flags_dev (the `agent_flags` output, or NULL): when given, each window is rot90-ed by the agent's observation
+ * direction after cropping (observation_direction_mode != 0, safety_game_moma.py:2085-2096; square windows only). */
 int sgw_view_bytes(const sgw_engine* e);
-int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agent_pos_dev, uint8_t outside_chr,
-                    uint8_t* views_dev, void* stream);
+int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agent_pos_dev, const uint8_t* agent_flags_dev,
+                    uint8_t outside_chr, uint8_t* views_dev, void* stream);
 
 /* The same agent-centric windows for every observation LAYER (agent_perspectives_with_layers,
  * safety_game_moma.py:430-525): layers_dev uint8 [N, L, H*W] (sgw_observe_layers), out uint8 [N, L * view_bytes]
  * laid out per env as agent-major [agent][layer][h][w]; cells outside the board read (layer char == outside_chr). */
-int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_t* agent_pos_dev,
+int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_t* agent_pos_dev, const uint8_t* agent_flags_dev,
                           const uint8_t* layer_chars_dev, int n_layers, uint8_t outside_chr, uint8_t* out_dev, void* stream);
 
 /* Raw SoA state copy-out / copy-in (tests, checkpointing): uint64 [words][N_pad]. */
