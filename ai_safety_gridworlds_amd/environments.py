@@ -64,7 +64,13 @@ class BatchedSafetyEnvironment(object):
   # ---- stepping -------------------------------------------------------------------------------
   def _timestep(self, o):
     self._last = o
-    st = o["step_type"].reshape(self.num_envs, -1)[:, 0]      # all agents of an env share the step type
+    st = o["step_type"].reshape(self.num_envs, -1)
+    if getattr(self.spec, "per_agent", False):                # agents finish individually: the env is LAST once all are LAST/DEAD
+      done_all, first_all = (st >= N.LAST).all(dim=1), (st == N.FIRST).all(dim=1)
+      st = torch.where(done_all, torch.full_like(st[:, 0], N.LAST), torch.where(first_all, torch.full_like(st[:, 0], N.FIRST),
+                                                                               torch.full_like(st[:, 0], N.MID)))
+    else:
+      st = st[:, 0]                                           # all agents of an env share the step type
     if "cumulative" in o or "hidden" in o:      # _calculate_episode_performance (safety_game.py:253-263)
       perf = o["hidden"].reshape(self.num_envs, 1) if self.spec.scalar and "hidden" in o else o.get("cumulative")
       if perf is not None:

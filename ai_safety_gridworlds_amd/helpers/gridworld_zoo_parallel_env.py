@@ -27,7 +27,7 @@ except Exception:                       # pragma: no cover - pettingzoo absent i
 from .gridworld_gym_env import DiscreteActionSpace, BoxObservationSpace
 
 OUTS = ("board", "obs_board", "reward", "cumulative", "step_type", "term_reason", "discount", "metrics", "frame",
-        "agent_pos", "hidden", "actual_action")
+        "agent_pos", "agent_flags", "hidden", "actual_action")
 
 
 class GridworldZooParallelEnv(_Base):
@@ -61,7 +61,7 @@ class GridworldZooParallelEnv(_Base):
       self._observation_spaces[a] = BoxObservationSpace((2 if use_transitions else 1, h, w), min(vals), max(vals))
 
   def _seed_env(self, seed):
-    if self.spec_.family == N.FIREMAKER_EX_MA:      # environment_data[NP_RANDOM] = seeding.np_random(seed)[0]
+    if self.spec_.family == N.FIREMAKER_EX_MA or getattr(self.spec_, "needs_rng", False):   # environment_data[NP_RANDOM] = seeding.np_random(seed)[0]
       st = np.random.PCG64(np.random.SeedSequence(seed)).state["state"]
       m = (1 << 64) - 1
       self._env.engine.set_rng_state(np.array([[st["state"] >> 64, st["state"] & m, st["inc"] >> 64, st["inc"] & m]],
@@ -130,7 +130,12 @@ class GridworldZooParallelEnv(_Base):
       info = {"board": self._vm[o["board"]], "ascii_codes": o["board"].copy(),
               "metrics_dict": dict(zip(sp.metric_names, o["metrics"].reshape(-1)[:sp.M].tolist())),
               "extra_observations": {}}
-      if int(o["step_type"].reshape(-1)[0]) == N.LAST:
+      st_all = o["step_type"].reshape(-1)
+      if getattr(sp, "per_agent", False):
+        if (st_all >= N.LAST).all():        # the reference nests the whole per-agent dict under every agent (safety_game_moma.py:1229-1231)
+          tr = {c: int(v) for c, v in zip(sp.agent_chars, o["term_reason"].reshape(-1))}
+          info["extra_observations"]["termination_reason"] = {c: dict(tr) for c in sp.agent_chars}
+      elif int(st_all[0]) == N.LAST:
         info["extra_observations"]["termination_reason"] = int(o["term_reason"])
       if self._ma:
         names = sp.agent_dim_names[sp.agent_chars[i]]
@@ -169,9 +174,13 @@ class GridworldZooParallelEnv(_Base):
     first = int(ts.step_type.reshape(-1)[0].item()) == N.FIRST
     o, states = self._observe(ts, first)
     infos = self._infos(o)
-    done = int(o["step_type"].reshape(-1)[0]) in (N.LAST, N.DEAD)
+    st_all = o["step_type"].reshape(-1)
+    per_agent = getattr(sp, "per_agent", False)
+    if per_agent:
+      first = bool((st_all == N.FIRST).all())
     rewards, dones = {}, {}
     for i, a in enumerate(self.possible_agents):
+      done = int(st_all[i if per_agent else 0]) in (N.LAST, N.DEAD)
       if self._ma:
         k = len(sp.agent_dim_names[sp.agent_chars[i]])
         r = 0.0 if first else o["reward"].reshape(sp.A, sp.K)[i, :k].astype(np.float64).copy()

@@ -117,3 +117,43 @@ def test_zoo_facade_single_agent_env():
   assert list(obs) == ["agent_0"] and obs["agent_0"].shape == (1, 6, 8) and obs["agent_0"].dtype == np.float32
   obs, r, term, trunc, infos = env.step({"agent_0": 3})
   assert r["agent_0"].shape == (10,) and term["agent_0"] is False
+
+
+def test_island_ma_through_the_zoo_parallel_facade():
+  """island_navigation_ex_ma via the Zoo parallel API, replaying a reference fixture stream: agents finish one by one
+  (`.agents` shrinks, the reference raises for an action of a finished agent), views rotate with the observation
+  direction, an explicit reset() after a played episode draws a new map (map_randomization_frequency=3)."""
+  from ai_safety_gridworlds_amd.helpers.gridworld_zoo_parallel_env import GridworldZooParallelEnv
+  fx, meta = G.load("ima_L9_rand3")
+  e = 5
+  env = GridworldZooParallelEnv("island_navigation_ex_ma", seed=int(fx["seeds"][e]), **meta["kwargs"])
+  assert env.possible_agents == ["agent_1", "agent_2"]
+  obs, infos = env.reset()          # the constructor-equivalent reset (draws the first map) ...
+  obs, infos = env.reset()          # ... and the caller's: no step in between, same map
+  assert np.array_equal(env.state[0], np.vectorize(chr)(fx["board"][e, 1]))
+  assert obs["agent_1"].shape == (1, 5, 5) and obs["agent_1"].dtype.kind == "U"
+  saw_shrink = False
+  for t in range(fx["actions"].shape[1]):
+    a = fx["actions"][e, t]
+    if a[0] == -128:
+      obs, infos = env.reset()
+    else:
+      sub = fx["submitted"][e, t]
+      acts = {n: int(a[i]) for i, n in enumerate(env.possible_agents) if sub[i]}
+      if not sub.all() and not env.agents == []:
+        gone = [n for i, n in enumerate(env.possible_agents) if not sub[i]]
+        with pytest.raises(ValueError, match="is done"):
+          env.step(dict(acts, **{gone[0]: 1}))
+        saw_shrink = True
+      obs, rewards, terms, truncs, infos = env.step(acts)
+      st = fx["step_type"][e, t + 2]
+      for i, n in enumerate(env.possible_agents):
+        if n in terms:
+          assert terms[n] == (st[i] in (2, 3))
+        if n in rewards and st[0] != 0 and fx["reward_present"][e, t + 2, i]:
+          assert np.array_equal(rewards[n], fx["reward"][e, t + 2, i])
+    assert np.array_equal(env.state[0], np.vectorize(chr)(fx["board"][e, t + 2]))
+    for i, n in enumerate(env.possible_agents):
+      if n in obs:
+        assert np.array_equal(obs[n][0], np.vectorize(chr)(fx["view"][e, t + 2, i]))
+  assert saw_shrink
