@@ -80,6 +80,10 @@ WORKLOADS = {
     # not part of this loop: 1815 B/round of SURVEY minus the 1139 view bytes
     "firemaker_ex_ma": dict(kwargs=dict(amount_agents=3), envs=16384, b_step=676, b_fused=354,
                             outputs=("board", "reward", "step_type", "term_reason", "agent_pos")),
+    # one env-step = one ROUND (the agents that are still alive act once); 38-word state (per-env 4-bit map, PCG64,
+    # 2 x K cumulative): 2 + 2*304 + 48 + 128 + 2 + 2 + 8
+    "island_navigation_ex_ma": dict(kwargs={}, envs=65536, b_step=798, b_fused=190,
+                                    outputs=("board", "reward", "step_type", "term_reason", "safety")),
 }
 MIXED = ("island_navigation_ex", "boat_race_ex", "safe_interruptibility")    # BASELINE.json configs[4]
 
@@ -134,7 +138,7 @@ def main():
     wl = WORKLOADS[fam]
     spec = make_spec(fam, **wl["kwargs"])
     eng = BatchedEngine(spec, cnt, device=device, env_id_base=base, outputs=wl["outputs"])
-    if fam == "firemaker_ex_ma":
+    if fam == "firemaker_ex_ma" or getattr(spec, "needs_rng", False):
       eng.set_rng_seeds(base + np.arange(cnt))
     if fam == "safe_interruptibility":
       eng.set_episode_bits(None, seed=SEED)
@@ -180,7 +184,7 @@ def main():
   if not a.no_fused and a.workload != "mixed":
     e = engines[0]
     eng2 = BatchedEngine(e["spec"], e["n"], device=device, env_id_base=rank * e["n"], outputs=e["wl"]["outputs"])
-    if e["fam"] == "firemaker_ex_ma":
+    if e["fam"] == "firemaker_ex_ma" or getattr(e["spec"], "needs_rng", False):
       eng2.set_rng_seeds(rank * e["n"] + np.arange(e["n"]))
     if e["fam"] == "safe_interruptibility":
       eng2.set_episode_bits(None, seed=SEED)
@@ -220,6 +224,7 @@ def main():
     desc = {"island_navigation_ex": "island_navigation_ex level 9 default flags", "boat_race_ex": "boat_race_ex level 3",
             "safe_interruptibility": "safe_interruptibility level 1", "boat_race": "boat_race level 0",
             "firemaker_ex_ma": "firemaker_ex_ma level 0, 3 agents (one env-step = one round)",
+            "island_navigation_ex_ma": "island_navigation_ex_ma level 9 default flags, 2 agents (one env-step = one round)",
             "mixed": "mixed suite island_navigation_ex + boat_race_ex + safe_interruptibility on 3 streams"}[a.workload]
     line = {
         "metric": "env-steps/sec (whole node), 65 536 batched envs per GPU",
