@@ -24,7 +24,8 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
 stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 if stats:
   shutil.copy(stats[0], os.path.join("profiles", "%s_%s_kernel_stats.csv" % (rnd, tag)))
-shutil.copy(os.path.join(src, "bench.json"), os.path.join("profiles", "%s_%s_bench.json" % (rnd, tag)))
+bench_dst = os.path.join("profiles", "%s_%s_bench.json" % (rnd, tag))
+shutil.copy(os.path.join(src, "bench.json"), bench_dst)
 out = {"tag": tag, "kernel": "sgw::k_engine<sgw::Island, K_STEP> (65536 envs, 1024 waves)", "pmc_median_per_launch": pm}
 if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
   # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads exactly half of a wide coalesced streaming read
@@ -37,4 +38,22 @@ json.dump(out, open(os.path.join("profiles", "%s_%s_pmc.json" % (rnd, tag)), "w"
 if "hbm_bytes_per_launch" in out:
   json.dump({"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": "%s_%s_pmc.json" % (rnd, tag)},
             open(os.path.join("profiles", "%s_traffic.json" % rnd), "w"))
+for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
+  shutil.copy(f, os.path.join("profiles", "%s_%s_%s" % (rnd, tag, os.path.basename(f))))
+if os.path.exists(os.path.join(src, "phase_stamps.txt")):
+  shutil.copy(os.path.join(src, "phase_stamps.txt"), os.path.join("profiles", "%s_%s_phase_stamps.txt" % (rnd, tag)))
+fm = {}
+for f in glob.glob(os.path.join(src, "pmc_fm", "*", "*_counter_collection.csv")):
+  acc = {}
+  for r in csv.DictReader(open(f)):
+    if "Firemaker" in r["Kernel_Name"] and "Li0E" in r["Kernel_Name"]:
+      acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+  fm = {k: statistics.median(v[len(v) // 5:]) for k, v in acc.items()}
+if fm:
+  json.dump({"kernel": "sgw::k_engine<sgw::Firemaker, K_STEP> (16384 envs, 256 workgroups x 8 waves)", "pmc_median_per_launch": fm},
+            open(os.path.join("profiles", "%s_%s_pmc_firemaker.json" % (rnd, tag)), "w"), indent=1)
+if "hbm_bytes_per_launch" in out:      # the bench ran before this tag's PMC passes were summarised: carry their traffic figure
+  line = json.loads(open(bench_dst).read().strip().splitlines()[-1])
+  line["roofline"]["traffic"] = out["hbm_bytes_per_launch"]
+  open(bench_dst, "w").write(json.dumps(line) + "\n")
 print(json.dumps(out, indent=1))
