@@ -42,7 +42,10 @@ enum or_family {
   OR_ISLAND_EX = 0,
   OR_BOAT_RACE_EX = 1,
   OR_BOAT_RACE = 2,
-  OR_SAFE_INT = 3
+  OR_SAFE_INT = 3,
+  OR_ISLAND_NAV = 4,      /* environments/island_navigation.py   (IV) */
+  OR_DIST_SHIFT = 5,      /* environments/distributional_shift.py (DS) */
+  OR_ABSENT_SUP = 6       /* environments/absent_supervisor.py    (AS) */
 };
 
 enum or_step_type { OR_FIRST = 0, OR_MID = 1, OR_LAST = 2 };   /* rl/environment.py StepType */
@@ -78,6 +81,10 @@ typedef struct {
   int32_t repetition_penalty;
   /* safe_interruptibility (SI:83-84) */
   double interruption_probability;
+  /* distributional_shift (DS:128-141): is_testing, level_choice (-1 = None) */
+  int32_t is_testing, level_choice;
+  /* absent_supervisor (AS:178-186): supervisor (-1 = None: drawn per game build) */
+  int32_t supervisor;
 } or_config;
 
 typedef struct {

@@ -69,6 +69,15 @@ CONFIGS = {
     "safe_int_L0": ("safe_interruptibility", dict(level=0), 64, 200, 1, 4),
     "safe_int_L2": ("safe_interruptibility", dict(level=2), 64, 200, 1, 4),
     "safe_int_L1_p1": ("safe_interruptibility", dict(level=1, interruption_probability=1.0), 32, 200, 1, 4),
+    # original-suite "tile event" envs: one generic device family
+    "islnav_L0": ("island_navigation", dict(), 64, 200, 0, 5),
+    "islnav_L0_nonoop": ("island_navigation", dict(noops=False, max_iterations=30), 32, 150, 1, 4),
+    "dshift_train": ("distributional_shift", dict(is_testing=False), 32, 200, 1, 4),
+    "dshift_test": ("distributional_shift", dict(is_testing=True), 64, 250, 1, 4),
+    "dshift_level2": ("distributional_shift", dict(is_testing=True, level_choice=2), 16, 150, 1, 4),
+    "absent_random": ("absent_supervisor", dict(), 64, 250, 1, 4),
+    "absent_present": ("absent_supervisor", dict(supervisor=True), 16, 150, 1, 4),
+    "absent_absent": ("absent_supervisor", dict(supervisor=False), 16, 150, 1, 4),
 }
 
 ISLAND_FLAG_DEFAULTS = dict(
@@ -107,6 +116,15 @@ def make_env(family, kw):
   if family == "safe_interruptibility":
     from ai_safety_gridworlds.environments import safe_interruptibility as m
     return m.SafeInterruptibilityEnvironment(**kw), m
+  if family == "island_navigation":
+    from ai_safety_gridworlds.environments import island_navigation as m
+    return m.IslandNavigationEnvironment(**kw), m
+  if family == "distributional_shift":
+    from ai_safety_gridworlds.environments import distributional_shift as m
+    return m.DistributionalShiftEnvironment(**kw), m
+  if family == "absent_supervisor":
+    from ai_safety_gridworlds.environments import absent_supervisor as m
+    return m.AbsentSupervisorEnvironment(**kw), m
   raise KeyError(family)
 
 
@@ -123,8 +141,8 @@ def run_config(name, out_dir):
   else:
     acts = philox.actions(SEED, env_ids, np.arange(T), lo, n_act)   # [T, E]
 
-  if family == "safe_interruptibility":
-    np.random.seed(SEED)
+  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor"):
+    np.random.seed(SEED)               # these envs draw one number from the process-global numpy RNG per game build
   env, mod = make_env(family, kw)
 
   ts0 = env.reset()
@@ -169,10 +187,10 @@ def run_config(name, out_dir):
     rec["cumulative_mo_variance"] = np.zeros((E, S), np.float64)
     rec["average_mo_variance"] = np.zeros((E, S), np.float64)
     rec["layers"] = np.zeros((NRGB, S, len(layer_chars), H, W), np.bool_)
-  if family == "island_ex":
+  if family in ("island_ex", "island_navigation"):
     rec["safety"] = np.zeros((E, S), np.int32)
-  if family == "safe_interruptibility":
-    rec["should_interrupt"] = np.zeros((E, S), np.bool_)
+  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor"):
+    rec["should_interrupt"] = np.zeros((E, S), np.bool_)       # the per-build random bit of the env
 
   def record(e, t, ts):
     rec["step_type"][e, t] = int(ts.step_type)
@@ -209,10 +227,14 @@ def run_config(name, out_dir):
           rec["layers"][e, t, li] = ts.observation["layers"][c]
     else:
       rec["cumulative"][e, t, 0] = env.episode_return
-    if family == "island_ex":
+    if family in ("island_ex", "island_navigation"):
       rec["safety"][e, t] = env.environment_data["safety"]
     if family == "safe_interruptibility":
       rec["should_interrupt"][e, t] = env.environment_data["should_interrupt"]
+    if family == "distributional_shift":
+      rec["should_interrupt"][e, t] = env.environment_data["current_level"] == 2
+    if family == "absent_supervisor":
+      rec["should_interrupt"][e, t] = bool(env.environment_data["supervisor"])
 
   t0 = time.time()
   for e in range(E):

@@ -16,7 +16,7 @@ FIELDS = ["step_type", "reward_none", "reward", "cumulative", "discount", "term_
           "actual_action", "frame", "hidden", "board"]
 
 
-@pytest.mark.parametrize("name", G.fixture_names(["island_", "boat_", "safe_int_"]))
+@pytest.mark.parametrize("name", G.fixture_names(G.SCALAR_PREFIXES))
 def test_oracle_matches_reference_fixture(name):
   fx, meta = G.load(name)
   cfg = O.make_config(meta["family_name"], **meta["kwargs"])

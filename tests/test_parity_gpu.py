@@ -52,7 +52,7 @@ def compare(name, got, want, K, fields=CMP):
     G.assert_same(name + "." + f, g, w)
 
 
-@pytest.mark.parametrize("name", G.fixture_names(["island_", "boat_", "safe_int_"]))
+@pytest.mark.parametrize("name", G.fixture_names(G.SCALAR_PREFIXES))
 def test_hip_matches_reference_fixture(name):
   fx, meta = G.load(name)
   spec = make_spec(meta["family_name"], **meta["kwargs"])

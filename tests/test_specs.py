@@ -25,7 +25,7 @@ def test_action_stream_is_keyed_by_global_env_id():
   assert full.min() >= 0 and full.max() <= 4 and len(np.unique(full)) == 5
 
 
-@pytest.mark.parametrize("name", G.fixture_names(["island_", "boat_", "safe_int_"]))
+@pytest.mark.parametrize("name", G.fixture_names(G.SCALAR_PREFIXES))
 def test_spec_tables_match_reference_fixture(name):
   fx, meta = G.load(name)
   spec = make_spec(meta["family_name"], **meta["kwargs"])
