@@ -72,7 +72,8 @@ class BatchedSafetyEnvironment(object):
     else:
       st = st[:, 0]                                           # all agents of an env share the step type
     if "cumulative" in o or "hidden" in o:      # _calculate_episode_performance (safety_game.py:253-263)
-      perf = o["hidden"].reshape(self.num_envs, 1) if self.spec.scalar and "hidden" in o else o.get("cumulative")
+      use_hidden = self.spec.scalar and getattr(self.spec, "performance", "hidden") == "hidden"   # distributional_shift keeps the default: episode return
+      perf = o["hidden"].reshape(self.num_envs, 1) if use_hidden and "hidden" in o else o.get("cumulative")
       if perf is not None:
         perf = perf.reshape(self.num_envs, -1)
         if self._last_performance is None:

@@ -80,6 +80,9 @@ ORACLE_CASES = [
     ("boat_race", dict(level=0), 1000, 230, 1, 4),
     ("safe_interruptibility", dict(level=1), 4096, 150, 1, 4),
     ("safe_interruptibility", dict(level=2), 129, 150, 1, 4),
+    ("island_navigation", dict(), 2000, 150, 0, 5),
+    ("distributional_shift", dict(is_testing=True), 1500, 150, 1, 4),
+    ("absent_supervisor", dict(), 1500, 150, 1, 4),
 ]
 
 
@@ -91,7 +94,7 @@ def test_hip_matches_oracle_fresh_seed(env_name, kw, E, T, lo, n):
   env_ids = np.arange(E)
   actions = philox.actions(seed, env_ids, np.arange(T), lo, n).T.copy()     # [E, T]
   bits = None
-  if env_name == "safe_interruptibility":
+  if env_name in ("safe_interruptibility", "distributional_shift", "absent_supervisor"):
     bits = (philox.actions(seed ^ 7, env_ids, np.arange(32), 0, 2).T.copy()).astype(np.uint8)
   cfg = O.make_config(env_name, **kw)
   want = O.run_streams(cfg, actions, interrupt_bits=bits, nthreads=8)

@@ -42,7 +42,10 @@ def test_spec_tables_match_reference_fixture(name):
   n = fx["rgb"].shape[0]
   assert np.array_equal(np.moveaxis(lut[board[:n]], -1, 2), fx["rgb"])
   # reset board: static board + agent at its start cell
-  sb = np.array(list(spec.native.static_board[:spec.H * spec.W]), np.uint8).reshape(spec.H, spec.W).copy()
+  table = spec.native.static_board
+  if hasattr(spec, "art_variants") and "should_interrupt" in fx.files and fx["should_interrupt"][0, 0]:
+    table = spec.native.aux                      # tile-event envs: the board variant of the first game build
+  sb = np.array(list(table[:spec.H * spec.W]), np.uint8).reshape(spec.H, spec.W).copy()
   r, c = divmod(spec.native.start_cell[0], spec.W)
   sb[r, c] = ord('A')
   assert np.array_equal(sb, board[0, 0])
