@@ -14,6 +14,7 @@
 #include "sgw_island.hpp"
 #include "sgw_kernels.hpp"
 #include "sgw_safeint.hpp"
+#include "sgw_sokoban.hpp"
 #include "sgw_tile.hpp"
 
 using namespace sgw;
@@ -56,6 +57,7 @@ static int family_words(const sgw_spec& sp) {
     case SGW_FIREMAKER_EX_MA: return Firemaker::words();
     case SGW_ISLAND_NAVIGATION_EX_MA: return IslandMa::words(sp.K);
     case SGW_TILE_EVENTS: return Tile::words();
+    case SGW_SIDE_EFFECTS_SOKOBAN: return Sokoban::words();
     default: return -1;
   }
 }
@@ -224,6 +226,7 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
     case SGW_FIREMAKER_EX_MA: SGW_LAUNCH(Firemaker); break;
     case SGW_ISLAND_NAVIGATION_EX_MA: SGW_LAUNCH(IslandMa); break;
     case SGW_TILE_EVENTS: SGW_LAUNCH(Tile); break;
+    case SGW_SIDE_EFFECTS_SOKOBAN: SGW_LAUNCH(Sokoban); break;
     default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
   }
 #undef SGW_LAUNCH

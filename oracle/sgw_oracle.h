@@ -45,7 +45,8 @@ enum or_family {
   OR_SAFE_INT = 3,
   OR_ISLAND_NAV = 4,      /* environments/island_navigation.py   (IV) */
   OR_DIST_SHIFT = 5,      /* environments/distributional_shift.py (DS) */
-  OR_ABSENT_SUP = 6       /* environments/absent_supervisor.py    (AS) */
+  OR_ABSENT_SUP = 6,      /* environments/absent_supervisor.py    (AS) */
+  OR_SOKOBAN = 7          /* environments/side_effects_sokoban.py (SK) */
 };
 
 enum or_step_type { OR_FIRST = 0, OR_MID = 1, OR_LAST = 2 };   /* rl/environment.py StepType */
@@ -85,6 +86,8 @@ typedef struct {
   int32_t is_testing, level_choice;
   /* absent_supervisor (AS:178-186): supervisor (-1 = None: drawn per game build) */
   int32_t supervisor;
+  /* side_effects_sokoban (SK:63-72, 318-325) */
+  double sk_movement_reward, sk_coin_reward, sk_goal_reward, sk_wall_reward, sk_corner_reward;
 } or_config;
 
 typedef struct {

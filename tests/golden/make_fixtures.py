@@ -78,6 +78,10 @@ CONFIGS = {
     "absent_random": ("absent_supervisor", dict(), 64, 250, 1, 4),
     "absent_present": ("absent_supervisor", dict(supervisor=True), 16, 150, 1, 4),
     "absent_absent": ("absent_supervisor", dict(supervisor=False), 16, 150, 1, 4),
+    "sokoban_L0": ("side_effects_sokoban", dict(level=0), 64, 200, 1, 4),
+    "sokoban_L1": ("side_effects_sokoban", dict(level=1, noops=True), 64, 250, 0, 5),
+    "sokoban_L2": ("side_effects_sokoban", dict(level=2), 32, 200, 1, 4),
+    "sokoban_L3": ("side_effects_sokoban", dict(level=3, noops=True, wall_reward=-3, corner_reward=-7, coin_reward=20), 32, 250, 0, 5),
 }
 
 ISLAND_FLAG_DEFAULTS = dict(
@@ -125,6 +129,12 @@ def make_env(family, kw):
   if family == "absent_supervisor":
     from ai_safety_gridworlds.environments import absent_supervisor as m
     return m.AbsentSupervisorEnvironment(**kw), m
+  if family == "side_effects_sokoban":
+    import numpy
+    if not hasattr(numpy, "Inf"):      # the reference writes np.Inf (side_effects_sokoban.py:230, 234), an alias NumPy 2 removed
+      numpy.Inf = numpy.inf
+    from ai_safety_gridworlds.environments import side_effects_sokoban as m
+    return m.SideEffectsSokobanEnvironment(**kw), m
   raise KeyError(family)
 
 
