@@ -9,6 +9,7 @@
 
 #include "../../include/sgw.h"
 #include "sgw_boat.hpp"
+#include "sgw_conveyor.hpp"
 #include "sgw_firemaker.hpp"
 #include "sgw_island_ma.hpp"
 #include "sgw_island.hpp"
@@ -58,6 +59,7 @@ static int family_words(const sgw_spec& sp) {
     case SGW_ISLAND_NAVIGATION_EX_MA: return IslandMa::words(sp.K);
     case SGW_TILE_EVENTS: return Tile::words();
     case SGW_SIDE_EFFECTS_SOKOBAN: return Sokoban::words();
+    case SGW_CONVEYOR_BELT: return Conveyor::words();
     default: return -1;
   }
 }
@@ -227,6 +229,7 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
     case SGW_ISLAND_NAVIGATION_EX_MA: SGW_LAUNCH(IslandMa); break;
     case SGW_TILE_EVENTS: SGW_LAUNCH(Tile); break;
     case SGW_SIDE_EFFECTS_SOKOBAN: SGW_LAUNCH(Sokoban); break;
+    case SGW_CONVEYOR_BELT: SGW_LAUNCH(Conveyor); break;
     default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
   }
 #undef SGW_LAUNCH

@@ -47,7 +47,8 @@ enum sgw_family {
   SGW_FIREMAKER_EX_MA = 4,        /* environments/firemaker_ex_ma.py */
   SGW_ISLAND_NAVIGATION_EX_MA = 5, /* environments/island_navigation_ex_ma.py (agents terminate individually) */
   SGW_TILE_EVENTS = 6,             /* island_navigation.py, distributional_shift.py, absent_supervisor.py: one table-driven family */
-  SGW_SIDE_EFFECTS_SOKOBAN = 7     /* environments/side_effects_sokoban.py */
+  SGW_SIDE_EFFECTS_SOKOBAN = 7,    /* environments/side_effects_sokoban.py */
+  SGW_CONVEYOR_BELT = 8            /* environments/conveyor_belt.py */
 };
 
 enum sgw_step_type { SGW_FIRST = 0, SGW_MID = 1, SGW_LAST = 2, SGW_DEAD = 3 }; /* rl/environment{,_ma}.py */

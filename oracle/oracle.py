@@ -11,10 +11,11 @@ import numpy as np
 
 from . import build as _build
 
-ISLAND_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INT, ISLAND_NAV, DIST_SHIFT, ABSENT_SUP, SOKOBAN = 0, 1, 2, 3, 4, 5, 6, 7
+ISLAND_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INT, ISLAND_NAV, DIST_SHIFT, ABSENT_SUP, SOKOBAN, CONVEYOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
 FAMILY_IDS = {"island_navigation_ex": ISLAND_EX, "boat_race_ex": BOAT_RACE_EX,
               "boat_race": BOAT_RACE, "safe_interruptibility": SAFE_INT, "island_navigation": ISLAND_NAV,
-              "distributional_shift": DIST_SHIFT, "absent_supervisor": ABSENT_SUP, "side_effects_sokoban": SOKOBAN}
+              "distributional_shift": DIST_SHIFT, "absent_supervisor": ABSENT_SUP, "side_effects_sokoban": SOKOBAN, "conveyor_belt": CONVEYOR}
+CONVEYOR_VARIANTS = ["vase", "sushi", "sushi_goal", "sushi_goal2"]
 MAXCELLS, MAXK, MAXM = 320, 16, 16
 
 _I32 = C.c_int32
@@ -40,7 +41,8 @@ class Config(C.Structure):
           "food_regrowth_exponent", "food_growth_limit", "food_availability_initial")]
       + [("iterations_penalty", _I32), ("repetition_penalty", _I32),
          ("interruption_probability", _F64), ("is_testing", _I32), ("level_choice", _I32), ("supervisor", _I32)]
-      + [(n, _F64) for n in ("sk_movement_reward", "sk_coin_reward", "sk_goal_reward", "sk_wall_reward", "sk_corner_reward")])
+      + [(n, _F64) for n in ("sk_movement_reward", "sk_coin_reward", "sk_goal_reward", "sk_wall_reward", "sk_corner_reward")]
+      + [("variant", _I32), ("cb_goal_reward", _F64)])
 
 
 class TimeStep(C.Structure):
@@ -98,6 +100,10 @@ def make_config(family, **kw):
   names = {f[0] for f in Config._fields_}
   for k, v in kw.items():
     k = k.lower()
+    if fid == CONVEYOR and k == "goal_reward":
+      k = "cb_goal_reward"
+    if fid == CONVEYOR and k == "variant" and isinstance(v, str):
+      v = CONVEYOR_VARIANTS.index(v)
     if fid == SOKOBAN and "sk_" + k in names:       # movement_reward / coin_reward / ... (side_effects_sokoban.py:318-325)
       k = "sk_" + k
     if k not in names:

@@ -46,7 +46,8 @@ enum or_family {
   OR_ISLAND_NAV = 4,      /* environments/island_navigation.py   (IV) */
   OR_DIST_SHIFT = 5,      /* environments/distributional_shift.py (DS) */
   OR_ABSENT_SUP = 6,      /* environments/absent_supervisor.py    (AS) */
-  OR_SOKOBAN = 7          /* environments/side_effects_sokoban.py (SK) */
+  OR_SOKOBAN = 7,         /* environments/side_effects_sokoban.py (SK) */
+  OR_CONVEYOR = 8         /* environments/conveyor_belt.py        (CB) */
 };
 
 enum or_step_type { OR_FIRST = 0, OR_MID = 1, OR_LAST = 2 };   /* rl/environment.py StepType */
@@ -88,6 +89,9 @@ typedef struct {
   int32_t supervisor;
   /* side_effects_sokoban (SK:63-72, 318-325) */
   double sk_movement_reward, sk_coin_reward, sk_goal_reward, sk_wall_reward, sk_corner_reward;
+  /* conveyor_belt (CB:67-80, 262-266): variant 0 vase, 1 sushi, 2 sushi_goal, 3 sushi_goal2 */
+  int32_t variant;
+  double cb_goal_reward;
 } or_config;
 
 typedef struct {

@@ -81,6 +81,10 @@ CONFIGS = {
     "sokoban_L0": ("side_effects_sokoban", dict(level=0), 64, 200, 1, 4),
     "sokoban_L1": ("side_effects_sokoban", dict(level=1, noops=True), 64, 250, 0, 5),
     "sokoban_L2": ("side_effects_sokoban", dict(level=2), 32, 200, 1, 4),
+    "conveyor_vase": ("conveyor_belt", dict(variant="vase"), 64, 200, 1, 4),
+    "conveyor_sushi": ("conveyor_belt", dict(variant="sushi", noops=True), 32, 200, 0, 5),
+    "conveyor_sushi_goal": ("conveyor_belt", dict(variant="sushi_goal", noops=True, goal_reward=30), 64, 200, 0, 5),
+    "conveyor_sushi_goal2": ("conveyor_belt", dict(variant="sushi_goal2", max_iterations=40), 64, 200, 1, 4),
     "sokoban_L3": ("side_effects_sokoban", dict(level=3, noops=True, wall_reward=-3, corner_reward=-7, coin_reward=20), 32, 250, 0, 5),
 }
 
@@ -129,6 +133,9 @@ def make_env(family, kw):
   if family == "absent_supervisor":
     from ai_safety_gridworlds.environments import absent_supervisor as m
     return m.AbsentSupervisorEnvironment(**kw), m
+  if family == "conveyor_belt":
+    from ai_safety_gridworlds.environments import conveyor_belt as m
+    return m.ConveyorBeltEnvironment(**kw), m
   if family == "side_effects_sokoban":
     import numpy
     if not hasattr(numpy, "Inf"):      # the reference writes np.Inf (side_effects_sokoban.py:230, 234), an alias NumPy 2 removed
