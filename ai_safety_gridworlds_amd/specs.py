@@ -325,7 +325,11 @@ def _island_spec(kwargs):
                   action_lo=lo, n_actions=n, value_mapping=ISLAND_VALUES, bg_colours=ISLAND_BG,
                   actions=MO_ACTIONS, scalar=False, max_iterations=int(cfg["max_iterations"]), config=cfg,
                   # every drape exists even when its character is absent from the level (island_navigation_ex.py:387-393)
-                  layer_chars=sorted(set(flat) | set(' WDFGSA')), what_lies_beneath=' ', agent_chars=['A'], drape_chars='WDFGS')
+                  layer_chars=sorted(set(flat) | set(' WDFGSA')), what_lies_beneath=' ', agent_chars=['A'], drape_chars='WDFGS',
+                  # metrics_dict insertion order = order of the first save_metric calls (sprite __init__, sprite update, drapes):
+                  # what the CSV logger's `metrics_keys` iterates (safety_game_mo.py:382, 795)
+                  metrics_log_order=[m for m in metric_names if m.endswith("Visits")] +
+                                    ["DrinkSatiation", "FoodSatiation", "DrinkAvailability", "FoodAvailability"])
 
 
 def _boat_ex_spec(kwargs):

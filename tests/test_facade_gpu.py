@@ -157,3 +157,34 @@ def test_island_ma_through_the_zoo_parallel_facade():
       if n in obs:
         assert np.array_equal(obs[n][0], np.vectorize(chr)(fx["view"][e, t + 2, i]))
   assert saw_shrink
+
+
+def test_step_logger_reproduces_the_reference_csv(tmp_path):
+  """the CSV step log of one island_navigation_ex env, byte for byte against the file the reference wrote
+  for the same action stream (tests/golden/island_L9_steplog.csv, make_fixtures_log.py)."""
+  import os
+  from ai_safety_gridworlds_amd import step_log as SL
+  from ai_safety_gridworlds_amd.environments import BatchedSafetyEnvironment
+  acts = np.load(os.path.join(G.GOLDEN, "island_L9_steplog_actions.npy"))
+  want = open(os.path.join(G.GOLDEN, "island_L9_steplog.csv"), newline='').read()
+  cols = [SL.LOG_TRIAL, SL.LOG_EPISODE, SL.LOG_ITERATION, SL.LOG_REWARD, SL.LOG_SCALAR_REWARD, SL.LOG_CUMULATIVE_REWARD,
+          SL.LOG_AVERAGE_REWARD, SL.LOG_SCALAR_CUMULATIVE_REWARD, SL.LOG_SCALAR_AVERAGE_REWARD, SL.LOG_GINI_INDEX,
+          SL.LOG_CUMULATIVE_GINI_INDEX, SL.LOG_MO_VARIANCE, SL.LOG_CUMULATIVE_MO_VARIANCE, SL.LOG_AVERAGE_MO_VARIANCE, SL.LOG_METRICS]
+  env = BatchedSafetyEnvironment("island_navigation_ex", num_envs=3)        # env 1 replays the stream, 0 and 2 do something else
+  log = SL.StepLogger(env, cols, log_dir=str(tmp_path), log_filename="log.csv", env_indices=[1])
+  ts = env.reset(); log.on_reset(); log.write(ts)
+  ts = env.reset(); log.on_reset(); log.write(ts)
+  for t, a in enumerate(acts):
+    if t == 150:
+      ts = env.reset(); log.on_reset(); log.write(ts)
+    ts = env.step(torch.tensor([(int(a) + 1) % 5, int(a), 0], dtype=torch.int8)); log.write(ts)
+  log.close()
+  got = open(log.path, newline='').read()
+  assert got.splitlines()[0] == want.splitlines()[0]
+  assert len(got.splitlines()) == len(want.splitlines())
+  for ln, (g, w) in enumerate(zip(got.splitlines(), want.splitlines())):
+    assert g == w, "line %d" % ln
+  gz = SL.StepLogger(env, cols[:3], log_dir=str(tmp_path), log_filename="log2.csv", gzip_log=True, env_indices=[0, 2])
+  gz.write(env.step(torch.tensor([1, 1, 1], dtype=torch.int8))); gz.close()
+  import gzip
+  assert gzip.open(gz.path, "rt").read().splitlines()[0] == "trial;episode;iteration"
