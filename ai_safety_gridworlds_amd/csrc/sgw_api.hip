@@ -17,6 +17,7 @@
 #include "sgw_safeint.hpp"
 #include "sgw_sokoban.hpp"
 #include "sgw_tile.hpp"
+#include "sgw_tomato.hpp"
 
 using namespace sgw;
 
@@ -45,6 +46,9 @@ struct sgw_engine {
   const uint8_t* ep_bits;
   int ep_bits_n;
   unsigned long long ep_seed;
+  const double* rand_stream;
+  int rand_n;
+  unsigned long long rand_seed;
   double* acc_dev;         // [n_pad/64][A*K+1] per-wave episodic-return accumulators (lazily allocated)
   int rng_set;
 };
@@ -60,6 +64,7 @@ static int family_words(const sgw_spec& sp) {
     case SGW_TILE_EVENTS: return Tile::words();
     case SGW_SIDE_EFFECTS_SOKOBAN: return Sokoban::words();
     case SGW_CONVEYOR_BELT: return Conveyor::words();
+    case SGW_TOMATO_WATERING: return Tomato::words();
     default: return -1;
   }
 }
@@ -103,7 +108,7 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   e->n_envs = n_envs;
   e->n_pad = (n_envs + SGW_ENV_ALIGN - 1) / SGW_ENV_ALIGN * SGW_ENV_ALIGN;
   e->env_id_base = env_id_base;
-  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0; e->acc_dev = nullptr; e->rng_set = 0;
+  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0; e->rand_stream = nullptr; e->rand_n = 0; e->rand_seed = 0; e->acc_dev = nullptr; e->rng_set = 0;
 
   KSpec& k = e->ks;
   memset(&k, 0, sizeof(k));
@@ -176,6 +181,13 @@ int sgw_set_episode_bits(sgw_engine* e, const uint8_t* bits_dev, int n_per_env, 
   return SGW_OK;
 }
 
+int sgw_set_random_stream(sgw_engine* e, const double* u_dev, int n_per_env, uint64_t seed) {
+  if (!e) return fail(SGW_ERR_ARG, "sgw_set_random_stream: null engine");
+  if (u_dev && n_per_env <= 0) return fail(SGW_ERR_ARG, "sgw_set_random_stream: n_per_env must be positive");
+  e->rand_stream = u_dev; e->rand_n = u_dev ? n_per_env : 0; e->rand_seed = seed;
+  return SGW_OK;
+}
+
 int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev) {
   if (!e || !pcg_state_dev) return fail(SGW_ERR_ARG, "sgw_set_rng_state: null argument");
   if (e->spec.family != SGW_FIREMAKER_EX_MA && e->spec.family != SGW_ISLAND_NAVIGATION_EX_MA)
@@ -209,6 +221,7 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
   a.sp = e->ks; a.tables = e->tables_dev; a.state = e->state_dev;
   a.n_pad = e->n_pad; a.n_envs = e->n_envs; a.env_id_base = e->env_id_base;
   a.ep_bits = e->ep_bits; a.ep_bits_n = e->ep_bits_n; a.ep_seed = e->ep_seed;
+  a.rand_stream = e->rand_stream; a.rand_n = e->rand_n; a.rand_seed = e->rand_seed;
   const dim3 grid((unsigned)(e->n_pad / WAVE));
   const int kind = a.mode == MODE_RESET ? K_RESET : (a.T == 1 ? K_STEP : K_ROLLOUT);
   size_t lds_bytes = 0;
@@ -230,6 +243,7 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
     case SGW_TILE_EVENTS: SGW_LAUNCH(Tile); break;
     case SGW_SIDE_EFFECTS_SOKOBAN: SGW_LAUNCH(Sokoban); break;
     case SGW_CONVEYOR_BELT: SGW_LAUNCH(Conveyor); break;
+    case SGW_TOMATO_WATERING: SGW_LAUNCH(Tomato); break;
     default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
   }
 #undef SGW_LAUNCH

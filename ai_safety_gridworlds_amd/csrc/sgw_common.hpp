@@ -36,6 +36,9 @@ struct KArgs {
   const uint8_t* ep_bits;    // per-episode external bits [n, ep_bits_n] or nullptr
   int ep_bits_n;
   unsigned long long ep_seed;
+  const double* rand_stream; // external in-play random numbers [n, rand_n] (envs that draw from the process-global numpy RNG) or nullptr
+  int rand_n;
+  unsigned long long rand_seed;
   sgw_out out;
   int mode;                  // 0 = step, 1 = reset(mask)
   int T;                     // rollout length (1 for step)
@@ -188,6 +191,19 @@ __device__ inline double episode_uniform(unsigned long long seed, long long env_
                        (uint32_t)seed, (uint32_t)env_id);
   uint64_t bits = ((uint64_t)r.x << 21) | (r.y >> 11);
   return (double)bits * (1.0 / 9007199254740992.0);
+}
+
+// k-th in-play random number of an env: from the caller's stream when one is set (replaying a reference run), otherwise
+// Philox(seed, env id, k).  The counter is part of the env state (it keeps running across episodes, like np.random).
+__device__ inline double next_uniform(const KArgs& a, long long env, long long env_id, uint32_t& counter) {
+  double u;
+  if (a.rand_stream) u = (env < a.n_envs) ? a.rand_stream[env * a.rand_n + (long long)(counter % (uint32_t)a.rand_n)] : 1.0;
+  else {
+    U4 r = philox4x32_10(counter, TAG_EPISODE, 1u, (uint32_t)((uint64_t)env_id >> 32), (uint32_t)a.rand_seed, (uint32_t)env_id);
+    u = (double)(((uint64_t)r.x << 21) | (r.y >> 11)) * (1.0 / 9007199254740992.0);
+  }
+  counter += 1;
+  return u;
 }
 
 // Write-through stores (`sc1`): the bytes leave the XCD's L2 while the kernel is still running instead of sitting

@@ -175,6 +175,17 @@ class BatchedEngine(object):
     N.check(self._lib.sgw_set_episode_bits(self._h, bits.data_ptr(), bits.shape[1], int(seed)),
             "sgw_set_episode_bits")
 
+  def set_random_stream(self, u, seed=0):
+    """In-play random numbers for envs that draw from the process-global numpy RNG while stepping (tomato_watering):
+    float64 [N, n], the k-th draw of env i is u[i, k % n]; None: Philox(seed, env id, k)."""
+    if u is None:
+      N.check(self._lib.sgw_set_random_stream(self._h, None, 0, int(seed)), "sgw_set_random_stream")
+      return
+    u = torch.as_tensor(np.ascontiguousarray(u, dtype=np.float64)).to(self.device).contiguous()
+    assert u.dim() == 2 and u.shape[0] == self.n_envs
+    self._keep.append(u)
+    N.check(self._lib.sgw_set_random_stream(self._h, u.data_ptr(), u.shape[1], int(seed)), "sgw_set_random_stream")
+
   def set_rng_seeds(self, seeds):
     """firemaker_ex_ma / island_navigation_ex_ma: per-env numpy streams Generator(PCG64(SeedSequence(seed))) -- what
     gymnasium.utils.seeding.np_random(seed) builds (safety_game_mo.py:283-291).  seeds: int array [N]."""

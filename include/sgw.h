@@ -48,7 +48,8 @@ enum sgw_family {
   SGW_ISLAND_NAVIGATION_EX_MA = 5, /* environments/island_navigation_ex_ma.py (agents terminate individually) */
   SGW_TILE_EVENTS = 6,             /* island_navigation.py, distributional_shift.py, absent_supervisor.py: one table-driven family */
   SGW_SIDE_EFFECTS_SOKOBAN = 7,    /* environments/side_effects_sokoban.py */
-  SGW_CONVEYOR_BELT = 8            /* environments/conveyor_belt.py */
+  SGW_CONVEYOR_BELT = 8,           /* environments/conveyor_belt.py */
+  SGW_TOMATO_WATERING = 9          /* environments/tomato_watering.py */
 };
 
 enum sgw_step_type { SGW_FIRST = 0, SGW_MID = 1, SGW_LAST = 2, SGW_DEAD = 3 }; /* rl/environment{,_ma}.py */
@@ -129,6 +130,11 @@ int64_t sgw_state_bytes(const sgw_engine* e);
  * uint8 [N, n_per_env]; the k-th episode of env n uses bits[n, k % n_per_env].  NULL => drawn
  * from Philox(seed, env id, episode) <= interruption_probability. */
 int sgw_set_episode_bits(sgw_engine* e, const uint8_t* bits_dev, int n_per_env, uint64_t seed);
+
+/* In-play random numbers for envs that draw from the process-global numpy RNG while stepping (tomato_watering.py:154-156:
+ * np.random.random() per watered tomato and step).  u_dev double [N, n_per_env]: the k-th draw of env i is
+ * u[i][k % n_per_env] (replaying a reference run); NULL: Philox(seed, global env id, k).  The draw counter is env state. */
+int sgw_set_random_stream(sgw_engine* e, const double* u_dev, int n_per_env, uint64_t seed);
 
 /* Multi-agent RNG streams (firemaker): pcg_state_dev is uint64 [N, 4] = numpy PCG64
  * (state_hi, state_lo, inc_hi, inc_lo) per env, as produced by np.random.PCG64(SeedSequence(seed)). */

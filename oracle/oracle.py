@@ -11,10 +11,10 @@ import numpy as np
 
 from . import build as _build
 
-ISLAND_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INT, ISLAND_NAV, DIST_SHIFT, ABSENT_SUP, SOKOBAN, CONVEYOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
+ISLAND_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INT, ISLAND_NAV, DIST_SHIFT, ABSENT_SUP, SOKOBAN, CONVEYOR, TOMATO = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 FAMILY_IDS = {"island_navigation_ex": ISLAND_EX, "boat_race_ex": BOAT_RACE_EX,
               "boat_race": BOAT_RACE, "safe_interruptibility": SAFE_INT, "island_navigation": ISLAND_NAV,
-              "distributional_shift": DIST_SHIFT, "absent_supervisor": ABSENT_SUP, "side_effects_sokoban": SOKOBAN, "conveyor_belt": CONVEYOR}
+              "distributional_shift": DIST_SHIFT, "absent_supervisor": ABSENT_SUP, "side_effects_sokoban": SOKOBAN, "conveyor_belt": CONVEYOR, "tomato_watering": TOMATO}
 CONVEYOR_VARIANTS = ["vase", "sushi", "sushi_goal", "sushi_goal2"]
 MAXCELLS, MAXK, MAXM = 320, 16, 16
 
@@ -88,6 +88,8 @@ def lib():
     L.or_env_step.argtypes = [C.c_void_p, C.c_int, C.POINTER(TimeStep)]
     L.or_run_streams.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_int, C.POINTER(StreamOut), C.c_int]
+    L.or_run_streams_rand.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                      C.POINTER(StreamOut), C.c_int]
     _lib = L
   return _lib
 
@@ -156,7 +158,7 @@ class Env(object):
       self._h = None
 
 
-def run_streams(cfg, actions, interrupt_bits=None, fields=None, nthreads=1):
+def run_streams(cfg, actions, interrupt_bits=None, fields=None, nthreads=1, rand_stream=None):
   """actions int8 [E, T] -> dict of arrays shaped like the golden fixtures ([E, T+1, ...])."""
   actions = np.ascontiguousarray(actions, dtype=np.int8)
   E, T = actions.shape
@@ -178,8 +180,13 @@ def run_streams(cfg, actions, interrupt_bits=None, fields=None, nthreads=1):
     interrupt_bits = np.ascontiguousarray(interrupt_bits, dtype=np.uint8)
     assert interrupt_bits.shape[0] == E
     bits_ptr, n_bits = interrupt_bits.ctypes.data, interrupt_bits.shape[1]
-  rc = lib().or_run_streams(C.byref(cfg), E, T, actions.ctypes.data, bits_ptr, n_bits,
-                            C.byref(so), int(nthreads))
+  rs_ptr, n_rand = None, 0
+  if rand_stream is not None:      # external numbers for envs that draw from the process-global numpy RNG during play
+    rand_stream = np.ascontiguousarray(rand_stream, dtype=np.float64)
+    assert rand_stream.shape[0] == E
+    rs_ptr, n_rand = rand_stream.ctypes.data, rand_stream.shape[1]
+  rc = lib().or_run_streams_rand(C.byref(cfg), E, T, actions.ctypes.data, bits_ptr, n_bits, rs_ptr, n_rand,
+                                 C.byref(so), int(nthreads))
   if rc:
     raise ValueError(lib().or_last_error().decode())
   out.update(d)

@@ -47,7 +47,8 @@ enum or_family {
   OR_DIST_SHIFT = 5,      /* environments/distributional_shift.py (DS) */
   OR_ABSENT_SUP = 6,      /* environments/absent_supervisor.py    (AS) */
   OR_SOKOBAN = 7,         /* environments/side_effects_sokoban.py (SK) */
-  OR_CONVEYOR = 8         /* environments/conveyor_belt.py        (CB) */
+  OR_CONVEYOR = 8,        /* environments/conveyor_belt.py        (CB) */
+  OR_TOMATO = 9           /* environments/tomato_watering.py      (TW) */
 };
 
 enum or_step_type { OR_FIRST = 0, OR_MID = 1, OR_LAST = 2 };   /* rl/environment.py StepType */
@@ -145,6 +146,13 @@ typedef struct {
 int or_run_streams(const or_config* cfg, int E, int T, const int8_t* actions,
                    const uint8_t* interrupt_bits, int n_bits,
                    const or_stream_out* out, int nthreads);
+/* Envs that draw from the process-global numpy RNG during play (tomato_watering: np.random.random() per watered tomato
+ * and step) consume an EXTERNAL stream of those numbers instead: rand_stream [E][n_rand] doubles, the k-th draw of
+ * stream e is rand_stream[e][k % n_rand]. */
+void or_env_set_random_stream(or_env* e, const double* u, int n);
+int or_run_streams_rand(const or_config* cfg, int E, int T, const int8_t* actions,
+                        const uint8_t* interrupt_bits, int n_bits, const double* rand_stream, int n_rand,
+                        const or_stream_out* out, int nthreads);
 
 #ifdef __cplusplus
 }

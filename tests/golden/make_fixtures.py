@@ -85,6 +85,7 @@ CONFIGS = {
     "conveyor_sushi": ("conveyor_belt", dict(variant="sushi", noops=True), 32, 200, 0, 5),
     "conveyor_sushi_goal": ("conveyor_belt", dict(variant="sushi_goal", noops=True, goal_reward=30), 64, 200, 0, 5),
     "conveyor_sushi_goal2": ("conveyor_belt", dict(variant="sushi_goal2", max_iterations=40), 64, 200, 1, 4),
+    "tomato_watering": ("tomato_watering", dict(), 48, 250, 1, 4),
     "sokoban_L3": ("side_effects_sokoban", dict(level=3, noops=True, wall_reward=-3, corner_reward=-7, coin_reward=20), 32, 250, 0, 5),
 }
 
@@ -133,6 +134,9 @@ def make_env(family, kw):
   if family == "absent_supervisor":
     from ai_safety_gridworlds.environments import absent_supervisor as m
     return m.AbsentSupervisorEnvironment(**kw), m
+  if family == "tomato_watering":
+    from ai_safety_gridworlds.environments import tomato_watering as m
+    return m.TomatoWateringEnvironment(**kw), m
   if family == "conveyor_belt":
     from ai_safety_gridworlds.environments import conveyor_belt as m
     return m.ConveyorBeltEnvironment(**kw), m
@@ -158,8 +162,14 @@ def run_config(name, out_dir):
   else:
     acts = philox.actions(SEED, env_ids, np.arange(T), lo, n_act)   # [T, E]
 
-  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor"):
-    np.random.seed(SEED)               # these envs draw one number from the process-global numpy RNG per game build
+  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor", "tomato_watering"):
+    np.random.seed(SEED)               # these envs draw from the process-global numpy RNG
+  draws = None
+  if family == "tomato_watering":      # record every np.random.random() the env draws: the batched engine takes them as input
+    draws, _orig_random = [], np.random.random
+    def _recording_random(*a, **k):
+      v = _orig_random(*a, **k); draws.append(float(v)); return v
+    np.random.random = _recording_random
   env, mod = make_env(family, kw)
 
   ts0 = env.reset()
@@ -254,13 +264,24 @@ def run_config(name, out_dir):
       rec["should_interrupt"][e, t] = bool(env.environment_data["supervisor"])
 
   t0 = time.time()
+  per_stream_draws = []
   for e in range(E):
+    if draws is not None:
+      del draws[:]
     ts = env.reset()
     record(e, 0, ts)
     for t in range(T):
       ts = env.step(int(acts[t, e]))
       record(e, t + 1, ts)
+    if draws is not None:
+      per_stream_draws.append(list(draws))
   dt = time.time() - t0
+  if draws is not None:
+    n = max(len(d) for d in per_stream_draws)
+    rec["rand_stream"] = np.ones((E, n), np.float64)
+    rec["rand_count"] = np.array([len(d) for d in per_stream_draws], np.int64)
+    for e, d in enumerate(per_stream_draws):
+      rec["rand_stream"][e, :len(d)] = d
 
   meta = dict(
       name=name, family=family, kwargs=repr(sorted(kw.items())), E=E, T=T,

@@ -16,12 +16,14 @@ CMP = ["step_type", "reward", "cumulative", "discount", "term_reason", "actual_a
        "board"]
 
 
-def run_engine(spec, actions, bits=None, outputs=ALL_OUTPUTS):
+def run_engine(spec, actions, bits=None, outputs=ALL_OUTPUTS, rand_stream=None):
   """actions int8 [E, T] -> dict of numpy arrays [E, T+1, ...] like the fixtures."""
   E, T = actions.shape
   eng = BatchedEngine(spec, E, device="cuda:0", outputs=outputs)
   if bits is not None:
     eng.set_episode_bits(bits)
+  if rand_stream is not None:
+    eng.set_random_stream(rand_stream)
   acts = torch.from_numpy(np.ascontiguousarray(actions.T)).to("cuda:0")     # [T, E]
   rec = {k: [] for k in outputs}
   o = eng.reset()
@@ -59,7 +61,7 @@ def test_hip_matches_reference_fixture(name):
   assert spec.dim_names == meta["dim_names"] or meta["K"] == 1
   assert (spec.H, spec.W, spec.K) == (meta["H"], meta["W"], meta["K"])
   bits = G.interrupt_bits(fx) if "should_interrupt" in fx.files else None
-  got = run_engine(spec, fx["actions"], bits=bits)
+  got = run_engine(spec, fx["actions"], bits=bits, rand_stream=fx["rand_stream"] if "rand_stream" in fx.files else None)
   compare(name, got, fx, spec.K)
   G.assert_same(name + ".obs_board", got["obs_board"], fx["obs_board"])
   if "metrics" in fx.files:
@@ -87,6 +89,7 @@ ORACLE_CASES = [
     ("side_effects_sokoban", dict(level=3), 1000, 220, 1, 4),
     ("conveyor_belt", dict(variant="vase", noops=True), 2000, 220, 0, 5),
     ("conveyor_belt", dict(variant="sushi_goal2", goal_reward=7), 1000, 220, 1, 4),
+    ("tomato_watering", dict(), 1500, 230, 1, 4),
 ]
 
 
@@ -100,10 +103,13 @@ def test_hip_matches_oracle_fresh_seed(env_name, kw, E, T, lo, n):
   bits = None
   if env_name in ("safe_interruptibility", "distributional_shift", "absent_supervisor"):
     bits = (philox.actions(seed ^ 7, env_ids, np.arange(32), 0, 2).T.copy()).astype(np.uint8)
+  rand = None
+  if env_name == "tomato_watering":
+    rand = np.random.default_rng(11).random((E, 4096))
   cfg = O.make_config(env_name, **kw)
-  want = O.run_streams(cfg, actions, interrupt_bits=bits, nthreads=8)
+  want = O.run_streams(cfg, actions, interrupt_bits=bits, nthreads=8, rand_stream=rand)
   spec = make_spec(env_name, **kw)
-  got = run_engine(spec, actions, bits=bits)
+  got = run_engine(spec, actions, bits=bits, rand_stream=rand)
   compare(env_name, got, want, spec.K)
   if spec.M:
     G.assert_same("metrics", got["metrics"][..., :spec.M], want["metrics"])
