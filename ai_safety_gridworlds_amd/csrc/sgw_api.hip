@@ -11,6 +11,7 @@
 #include "sgw_boat.hpp"
 #include "sgw_conveyor.hpp"
 #include "sgw_firemaker.hpp"
+#include "sgw_friendfoe.hpp"
 #include "sgw_island_ma.hpp"
 #include "sgw_island.hpp"
 #include "sgw_kernels.hpp"
@@ -65,6 +66,7 @@ static int family_words(const sgw_spec& sp) {
     case SGW_SIDE_EFFECTS_SOKOBAN: return Sokoban::words();
     case SGW_CONVEYOR_BELT: return Conveyor::words();
     case SGW_TOMATO_WATERING: return Tomato::words();
+    case SGW_FRIEND_FOE: return FriendFoe::words();
     default: return -1;
   }
 }
@@ -244,6 +246,7 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
     case SGW_SIDE_EFFECTS_SOKOBAN: SGW_LAUNCH(Sokoban); break;
     case SGW_CONVEYOR_BELT: SGW_LAUNCH(Conveyor); break;
     case SGW_TOMATO_WATERING: SGW_LAUNCH(Tomato); break;
+    case SGW_FRIEND_FOE: SGW_LAUNCH(FriendFoe); break;
     default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
   }
 #undef SGW_LAUNCH

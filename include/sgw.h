@@ -49,7 +49,8 @@ enum sgw_family {
   SGW_TILE_EVENTS = 6,             /* island_navigation.py, distributional_shift.py, absent_supervisor.py: one table-driven family */
   SGW_SIDE_EFFECTS_SOKOBAN = 7,    /* environments/side_effects_sokoban.py */
   SGW_CONVEYOR_BELT = 8,           /* environments/conveyor_belt.py */
-  SGW_TOMATO_WATERING = 9          /* environments/tomato_watering.py */
+  SGW_TOMATO_WATERING = 9,         /* environments/tomato_watering.py */
+  SGW_FRIEND_FOE = 10              /* environments/friend_foe.py */
 };
 
 enum sgw_step_type { SGW_FIRST = 0, SGW_MID = 1, SGW_LAST = 2, SGW_DEAD = 3 }; /* rl/environment{,_ma}.py */

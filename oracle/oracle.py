@@ -11,10 +11,11 @@ import numpy as np
 
 from . import build as _build
 
-ISLAND_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INT, ISLAND_NAV, DIST_SHIFT, ABSENT_SUP, SOKOBAN, CONVEYOR, TOMATO = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+ISLAND_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INT, ISLAND_NAV, DIST_SHIFT, ABSENT_SUP, SOKOBAN, CONVEYOR, TOMATO, FRIEND_FOE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 FAMILY_IDS = {"island_navigation_ex": ISLAND_EX, "boat_race_ex": BOAT_RACE_EX,
               "boat_race": BOAT_RACE, "safe_interruptibility": SAFE_INT, "island_navigation": ISLAND_NAV,
-              "distributional_shift": DIST_SHIFT, "absent_supervisor": ABSENT_SUP, "side_effects_sokoban": SOKOBAN, "conveyor_belt": CONVEYOR, "tomato_watering": TOMATO}
+              "distributional_shift": DIST_SHIFT, "absent_supervisor": ABSENT_SUP, "side_effects_sokoban": SOKOBAN, "conveyor_belt": CONVEYOR, "tomato_watering": TOMATO, "friend_foe": FRIEND_FOE}
+BANDIT_TYPES = ["friend", "neutral", "adversary"]
 CONVEYOR_VARIANTS = ["vase", "sushi", "sushi_goal", "sushi_goal2"]
 MAXCELLS, MAXK, MAXM = 320, 16, 16
 
@@ -42,7 +43,7 @@ class Config(C.Structure):
       + [("iterations_penalty", _I32), ("repetition_penalty", _I32),
          ("interruption_probability", _F64), ("is_testing", _I32), ("level_choice", _I32), ("supervisor", _I32)]
       + [(n, _F64) for n in ("sk_movement_reward", "sk_coin_reward", "sk_goal_reward", "sk_wall_reward", "sk_corner_reward")]
-      + [("variant", _I32), ("cb_goal_reward", _F64)])
+      + [("variant", _I32), ("cb_goal_reward", _F64), ("bandit_type", _I32), ("extra_step", _I32)])
 
 
 class TimeStep(C.Structure):
@@ -110,6 +111,8 @@ def make_config(family, **kw):
       k = "sk_" + k
     if k not in names:
       raise KeyError("oracle config has no field %r" % k)
+    if k == "bandit_type":
+      v = -1 if v is None else (BANDIT_TYPES.index(v) if isinstance(v, str) else int(v))
     if k in ("level_choice", "supervisor"):          # None = drawn per game build
       v = -1 if v is None else int(v)
     setattr(cfg, k, v)

@@ -48,7 +48,8 @@ enum or_family {
   OR_ABSENT_SUP = 6,      /* environments/absent_supervisor.py    (AS) */
   OR_SOKOBAN = 7,         /* environments/side_effects_sokoban.py (SK) */
   OR_CONVEYOR = 8,        /* environments/conveyor_belt.py        (CB) */
-  OR_TOMATO = 9           /* environments/tomato_watering.py      (TW) */
+  OR_TOMATO = 9,          /* environments/tomato_watering.py      (TW) */
+  OR_FRIEND_FOE = 10      /* environments/friend_foe.py           (FF) */
 };
 
 enum or_step_type { OR_FIRST = 0, OR_MID = 1, OR_LAST = 2 };   /* rl/environment.py StepType */
@@ -93,6 +94,8 @@ typedef struct {
   /* conveyor_belt (CB:67-80, 262-266): variant 0 vase, 1 sushi, 2 sushi_goal, 3 sushi_goal2 */
   int32_t variant;
   double cb_goal_reward;
+  /* friend_foe (FF:276-290): bandit_type -1 None (drawn per game build), 0 friend, 1 neutral, 2 adversary; extra_step */
+  int32_t bandit_type, extra_step;
 } or_config;
 
 typedef struct {

@@ -86,6 +86,11 @@ CONFIGS = {
     "conveyor_sushi_goal": ("conveyor_belt", dict(variant="sushi_goal", noops=True, goal_reward=30), 64, 200, 0, 5),
     "conveyor_sushi_goal2": ("conveyor_belt", dict(variant="sushi_goal2", max_iterations=40), 64, 200, 1, 4),
     "tomato_watering": ("tomato_watering", dict(), 48, 250, 1, 4),
+    # friend_foe keeps its bandits' policy estimators in environment_data across episodes: one FRESH env per stream
+    "friendfoe_random": ("friend_foe", dict(), 64, 250, 1, 4),
+    "friendfoe_friend": ("friend_foe", dict(bandit_type="friend"), 16, 250, 1, 4),
+    "friendfoe_adversary_extra": ("friend_foe", dict(bandit_type="adversary", extra_step=True), 16, 250, 1, 4),
+    "friendfoe_neutral": ("friend_foe", dict(bandit_type="neutral"), 16, 250, 1, 4),
     "sokoban_L3": ("side_effects_sokoban", dict(level=3, noops=True, wall_reward=-3, corner_reward=-7, coin_reward=20), 32, 250, 0, 5),
 }
 
@@ -137,6 +142,9 @@ def make_env(family, kw):
   if family == "tomato_watering":
     from ai_safety_gridworlds.environments import tomato_watering as m
     return m.TomatoWateringEnvironment(**kw), m
+  if family == "friend_foe":
+    from ai_safety_gridworlds.environments import friend_foe as m
+    return m.FriendFoeEnvironment(**kw), m
   if family == "conveyor_belt":
     from ai_safety_gridworlds.environments import conveyor_belt as m
     return m.ConveyorBeltEnvironment(**kw), m
@@ -162,7 +170,7 @@ def run_config(name, out_dir):
   else:
     acts = philox.actions(SEED, env_ids, np.arange(T), lo, n_act)   # [T, E]
 
-  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor", "tomato_watering"):
+  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor", "tomato_watering", "friend_foe"):
     np.random.seed(SEED)               # these envs draw from the process-global numpy RNG
   draws = None
   if family == "tomato_watering":      # record every np.random.random() the env draws: the batched engine takes them as input
@@ -170,6 +178,13 @@ def run_config(name, out_dir):
     def _recording_random(*a, **k):
       v = _orig_random(*a, **k); draws.append(float(v)); return v
     np.random.random = _recording_random
+  if family == "friend_foe":           # np.random.choice(BANDIT_TYPES) -> (index + 0.5) / 3, np.random.rand() -> its value
+    draws, _orig_choice, _orig_rand = [], np.random.choice, np.random.rand
+    def _recording_choice(a, *args, **k):
+      v = _orig_choice(a, *args, **k); draws.append((list(a).index(v) + 0.5) / len(a)); return v
+    def _recording_rand(*a, **k):
+      v = _orig_rand(*a, **k); draws.append(float(v)); return v
+    np.random.choice, np.random.rand = _recording_choice, _recording_rand
   env, mod = make_env(family, kw)
 
   ts0 = env.reset()
@@ -214,9 +229,9 @@ def run_config(name, out_dir):
     rec["cumulative_mo_variance"] = np.zeros((E, S), np.float64)
     rec["average_mo_variance"] = np.zeros((E, S), np.float64)
     rec["layers"] = np.zeros((NRGB, S, len(layer_chars), H, W), np.bool_)
-  if family in ("island_ex", "island_navigation"):
+  if family in ("island_ex", "island_navigation", "friend_foe"):
     rec["safety"] = np.zeros((E, S), np.int32)
-  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor"):
+  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor", "friend_foe"):
     rec["should_interrupt"] = np.zeros((E, S), np.bool_)       # the per-build random bit of the env
 
   def record(e, t, ts):
@@ -262,10 +277,15 @@ def run_config(name, out_dir):
       rec["should_interrupt"][e, t] = env.environment_data["current_level"] == 2
     if family == "absent_supervisor":
       rec["should_interrupt"][e, t] = bool(env.environment_data["supervisor"])
+    if family == "friend_foe":
+      rec["safety"][e, t] = env.environment_data["current_episode_bandit"]
+      rec["should_interrupt"][e, t] = env.current_game._sprites_and_drapes['A'].level == 1
 
   t0 = time.time()
   per_stream_draws = []
   for e in range(E):
+    if family == "friend_foe":
+      env, mod = make_env(family, kw)
     if draws is not None:
       del draws[:]
     ts = env.reset()

@@ -69,8 +69,10 @@ def test_hip_matches_reference_fixture(name):
     G.assert_same(name + ".metrics", got["metrics"][..., :spec.M], fx["metrics"])
   if "safety" in fx.files:
     G.assert_same(name + ".safety", got["safety"], fx["safety"])
-  if "should_interrupt" in fx.files:
+  if "should_interrupt" in fx.files and "safety" not in fx.files:
     G.assert_same(name + ".should_interrupt", got["safety"], fx["should_interrupt"])
+  if meta["family_name"] == "friend_foe":          # which box holds the reward (the level drawn for the episode)
+    G.assert_same(name + ".level", got["agent_flags"].reshape(fx["should_interrupt"].shape), fx["should_interrupt"])
 
 
 ORACLE_CASES = [
@@ -90,6 +92,8 @@ ORACLE_CASES = [
     ("conveyor_belt", dict(variant="vase", noops=True), 2000, 220, 0, 5),
     ("conveyor_belt", dict(variant="sushi_goal2", goal_reward=7), 1000, 220, 1, 4),
     ("tomato_watering", dict(), 1500, 230, 1, 4),
+    ("friend_foe", dict(), 2000, 230, 1, 4),
+    ("friend_foe", dict(bandit_type="adversary", extra_step=True), 500, 230, 1, 4),
 ]
 
 
@@ -104,7 +108,7 @@ def test_hip_matches_oracle_fresh_seed(env_name, kw, E, T, lo, n):
   if env_name in ("safe_interruptibility", "distributional_shift", "absent_supervisor"):
     bits = (philox.actions(seed ^ 7, env_ids, np.arange(32), 0, 2).T.copy()).astype(np.uint8)
   rand = None
-  if env_name == "tomato_watering":
+  if env_name in ("tomato_watering", "friend_foe"):
     rand = np.random.default_rng(11).random((E, 4096))
   cfg = O.make_config(env_name, **kw)
   want = O.run_streams(cfg, actions, interrupt_bits=bits, nthreads=8, rand_stream=rand)
