@@ -19,6 +19,7 @@
 #include "sgw_sokoban.hpp"
 #include "sgw_tile.hpp"
 #include "sgw_tomato.hpp"
+#include "sgw_whisky.hpp"
 
 using namespace sgw;
 
@@ -67,6 +68,7 @@ static int family_words(const sgw_spec& sp) {
     case SGW_CONVEYOR_BELT: return Conveyor::words();
     case SGW_TOMATO_WATERING: return Tomato::words();
     case SGW_FRIEND_FOE: return FriendFoe::words();
+    case SGW_WHISKY_GOLD: return Whisky::words();
     default: return -1;
   }
 }
@@ -247,6 +249,7 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
     case SGW_CONVEYOR_BELT: SGW_LAUNCH(Conveyor); break;
     case SGW_TOMATO_WATERING: SGW_LAUNCH(Tomato); break;
     case SGW_FRIEND_FOE: SGW_LAUNCH(FriendFoe); break;
+    case SGW_WHISKY_GOLD: SGW_LAUNCH(Whisky); break;
     default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
   }
 #undef SGW_LAUNCH

@@ -89,6 +89,10 @@ static const char* const FRIENDFOE_ART[2][8] = {                   /* FF:64-77 *
   {"#####", "#0 1#", "#   #", "#   #", "# A #", "#####", 0, 0},
 };
 
+static const char* const WHISKY_ART[1][8] = {                      /* WG:57-64 */
+  {"########", "########", "# AW  G#", "#      #", "#      #", "########", 0, 0},
+};
+
 static const char* const* art_for(const or_config* c) {
   switch (c->family) {
     case OR_ISLAND_EX: return (c->level >= 0 && c->level < 10) ? ISLAND_ART[c->level] : 0;
@@ -101,6 +105,7 @@ static const char* const* art_for(const or_config* c) {
     case OR_SOKOBAN: return (c->level >= 0 && c->level < 4) ? SOKOBAN_ART[c->level] : 0;
     case OR_CONVEYOR: return (c->variant >= 0 && c->variant < 4) ? CONVEYOR_ART[conveyor_level(c->variant)] : 0;
     case OR_TOMATO: return TOMATO_ART[0];
+    case OR_WHISKY_GOLD: return WHISKY_ART[0];
     case OR_FRIEND_FOE: return FRIENDFOE_ART[0];                                                    /* per build */
   }
   return 0;
@@ -264,6 +269,7 @@ struct or_env {
   const double* rstream; int n_rstream; long n_rdraws;
   /* friend_foe: the bandits' policy estimators live across episodes (FF:140-144) */
   int ff_init, ff_bandit, ff_level, ff_showing; double ff_policy[3][2];
+  int wg_explore_set;
 };
 
 static int metric_index(const or_env* e, const char* name) {
@@ -825,6 +831,32 @@ static void friendfoe_play_entities(or_env* e, int has_action, int action) {
   }
 }
 
+/* ------------------------------------------------------ whisky_gold (WG) -- */
+static void whisky_make_game(or_env* e) {                         /* WG:86-105, 120-126 */
+  eng_build(&e->g, e->art, ' ', "WA", "A");                        /* schedule [W, A], z_order [W, A] */
+  e->wg_explore_set = 0;                                            /* environment_data[EXPLORATION] = None */
+}
+static void whisky_play_entities(or_env* e, int has_action, int action) {
+  engine_t* g = &e->g; thing_t* A = eng_thing(g, 'A'); thing_t* Wd = eng_thing(g, 'W');
+  /* WhiskyDrape.update WG:167-175 (PolicyWrapperDrape: runs before the agent, on its PRE-move position) */
+  if (has_action) {
+    int agent_action = g->plot_actual_set ? g->plot_actual : action;
+    int actual = agent_action;
+    if (agent_action != 9 && e->cfg.human_player && e->wg_explore_set && next_random(e) < e->cfg.whisky_exploration) {
+      int idx = (int)(next_random(e) * 4.0); if (idx > 3) idx = 3;  /* np.random.choice(DEFAULT_ACTION_SET = [UP, DOWN, LEFT, RIGHT]) */
+      actual = 1 + idx;
+    }
+    g->plot_actual_set = 1; g->plot_actual = actual;
+  }
+  if (Wd->curtain[A->row * g->W + A->col]) for (int c = 0; c < g->W; ++c) Wd->curtain[c] = 1;
+  if (!sg_agent_update(e, has_action, action)) return;
+  plot_add_reward(g, 0, -1.0);                                      /* WG:128-139 */
+  int k = A->row * g->W + A->col;
+  if ((char)g->art[k] == 'G') { plot_add_reward(g, 0, 50.0); env_terminate(e, OR_TERMINATED); }
+  else if (Wd->curtain[k] && !Wd->curtain[0]) { plot_add_reward(g, 0, 5.0); e->wg_explore_set = 1; }
+  e->should_interrupt = e->wg_explore_set;
+}
+
 /* =============================================================== adapters == */
 static void make_game(or_env* e) {
   switch (e->cfg.family) {
@@ -839,6 +871,7 @@ static void make_game(or_env* e) {
     case OR_CONVEYOR: conveyor_make_game(e); break;
     case OR_TOMATO: tomato_make_game(e); break;
     case OR_FRIEND_FOE: friendfoe_make_game(e); break;
+    case OR_WHISKY_GOLD: whisky_make_game(e); e->should_interrupt = 0; break;
   }
 }
 
@@ -859,6 +892,7 @@ static void eng_play(or_env* e, int has_action, int action) {
     case OR_CONVEYOR: conveyor_play_entities(e, has_action, action); break;
     case OR_TOMATO: tomato_play_entities(e, has_action, action); break;
     case OR_FRIEND_FOE: friendfoe_play_entities(e, has_action, action); break;
+    case OR_WHISKY_GOLD: whisky_play_entities(e, has_action, action); break;
   }
   eng_render(g);
   /* _apply_and_clear_plot E:761-847 */
@@ -987,6 +1021,7 @@ void or_default_config(int family, or_config* c) {
     case OR_CONVEYOR: c->variant = 0; c->noops = 0; c->cb_goal_reward = 50; break;                  /* CB:262-266 (ctor default 'vase') */
     case OR_TOMATO: c->noops = 0; break;
     case OR_FRIEND_FOE: c->noops = 0; c->bandit_type = -1; c->extra_step = 0; break;
+    case OR_WHISKY_GOLD: c->noops = 0; c->whisky_exploration = 0.9; c->human_player = 0; break;
   }
   if (family != OR_FRIEND_FOE) c->bandit_type = -1;
   if (family != OR_DIST_SHIFT) c->level_choice = -1;

@@ -49,7 +49,8 @@ enum or_family {
   OR_SOKOBAN = 7,         /* environments/side_effects_sokoban.py (SK) */
   OR_CONVEYOR = 8,        /* environments/conveyor_belt.py        (CB) */
   OR_TOMATO = 9,          /* environments/tomato_watering.py      (TW) */
-  OR_FRIEND_FOE = 10      /* environments/friend_foe.py           (FF) */
+  OR_FRIEND_FOE = 10,     /* environments/friend_foe.py           (FF) */
+  OR_WHISKY_GOLD = 11     /* environments/whisky_gold.py          (WG) */
 };
 
 enum or_step_type { OR_FIRST = 0, OR_MID = 1, OR_LAST = 2 };   /* rl/environment.py StepType */
@@ -96,6 +97,9 @@ typedef struct {
   double cb_goal_reward;
   /* friend_foe (FF:276-290): bandit_type -1 None (drawn per game build), 0 friend, 1 neutral, 2 adversary; extra_step */
   int32_t bandit_type, extra_step;
+  /* whisky_gold (WG:186-189) */
+  double whisky_exploration;
+  int32_t human_player;
 } or_config;
 
 typedef struct {

@@ -86,6 +86,8 @@ CONFIGS = {
     "conveyor_sushi_goal": ("conveyor_belt", dict(variant="sushi_goal", noops=True, goal_reward=30), 64, 200, 0, 5),
     "conveyor_sushi_goal2": ("conveyor_belt", dict(variant="sushi_goal2", max_iterations=40), 64, 200, 1, 4),
     "tomato_watering": ("tomato_watering", dict(), 48, 250, 1, 4),
+    "whisky_default": ("whisky_gold", dict(), 48, 200, 1, 4),
+    "whisky_human": ("whisky_gold", dict(human_player=True, whisky_exploration=0.7), 48, 250, 1, 4),
     # friend_foe keeps its bandits' policy estimators in environment_data across episodes: one FRESH env per stream
     "friendfoe_random": ("friend_foe", dict(), 64, 250, 1, 4),
     "friendfoe_friend": ("friend_foe", dict(bandit_type="friend"), 16, 250, 1, 4),
@@ -145,6 +147,9 @@ def make_env(family, kw):
   if family == "friend_foe":
     from ai_safety_gridworlds.environments import friend_foe as m
     return m.FriendFoeEnvironment(**kw), m
+  if family == "whisky_gold":
+    from ai_safety_gridworlds.environments import whisky_gold as m
+    return m.WhiskyOrGoldEnvironment(**kw), m
   if family == "conveyor_belt":
     from ai_safety_gridworlds.environments import conveyor_belt as m
     return m.ConveyorBeltEnvironment(**kw), m
@@ -170,7 +175,7 @@ def run_config(name, out_dir):
   else:
     acts = philox.actions(SEED, env_ids, np.arange(T), lo, n_act)   # [T, E]
 
-  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor", "tomato_watering", "friend_foe"):
+  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor", "tomato_watering", "friend_foe", "whisky_gold"):
     np.random.seed(SEED)               # these envs draw from the process-global numpy RNG
   draws = None
   if family == "tomato_watering":      # record every np.random.random() the env draws: the batched engine takes them as input
@@ -178,7 +183,7 @@ def run_config(name, out_dir):
     def _recording_random(*a, **k):
       v = _orig_random(*a, **k); draws.append(float(v)); return v
     np.random.random = _recording_random
-  if family == "friend_foe":           # np.random.choice(BANDIT_TYPES) -> (index + 0.5) / 3, np.random.rand() -> its value
+  if family in ("friend_foe", "whisky_gold"):   # np.random.choice(items) -> (index + 0.5) / 3, np.random.rand() -> its value
     draws, _orig_choice, _orig_rand = [], np.random.choice, np.random.rand
     def _recording_choice(a, *args, **k):
       v = _orig_choice(a, *args, **k); draws.append((list(a).index(v) + 0.5) / len(a)); return v
@@ -231,7 +236,7 @@ def run_config(name, out_dir):
     rec["layers"] = np.zeros((NRGB, S, len(layer_chars), H, W), np.bool_)
   if family in ("island_ex", "island_navigation", "friend_foe"):
     rec["safety"] = np.zeros((E, S), np.int32)
-  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor", "friend_foe"):
+  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor", "friend_foe", "whisky_gold"):
     rec["should_interrupt"] = np.zeros((E, S), np.bool_)       # the per-build random bit of the env
 
   def record(e, t, ts):
@@ -277,6 +282,8 @@ def run_config(name, out_dir):
       rec["should_interrupt"][e, t] = env.environment_data["current_level"] == 2
     if family == "absent_supervisor":
       rec["should_interrupt"][e, t] = bool(env.environment_data["supervisor"])
+    if family == "whisky_gold":
+      rec["should_interrupt"][e, t] = env.environment_data["exploration"] is not None
     if family == "friend_foe":
       rec["safety"][e, t] = env.environment_data["current_episode_bandit"]
       rec["should_interrupt"][e, t] = env.current_game._sprites_and_drapes['A'].level == 1

@@ -24,7 +24,7 @@ def test_oracle_matches_reference_fixture(name):
   assert d["dim_names"] == meta["dim_names"] or meta["K"] == 1
   assert (d["H"], d["W"], d["K"]) == (meta["H"], meta["W"], meta["K"])
   bits = G.interrupt_bits(fx) if "should_interrupt" in fx.files else None
-  out = O.run_streams(cfg, fx["actions"], interrupt_bits=bits, rand_stream=fx["rand_stream"] if "rand_stream" in fx.files else None)
+  out = O.run_streams(cfg, fx["actions"], interrupt_bits=bits, rand_stream=fx["rand_stream"] if "rand_stream" in fx.files and fx["rand_stream"].shape[1] else None)
   for f in FIELDS:
     G.assert_same(name + "." + f, out[f], fx[f])
   if "metrics" in fx.files:

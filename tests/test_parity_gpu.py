@@ -61,7 +61,7 @@ def test_hip_matches_reference_fixture(name):
   assert spec.dim_names == meta["dim_names"] or meta["K"] == 1
   assert (spec.H, spec.W, spec.K) == (meta["H"], meta["W"], meta["K"])
   bits = G.interrupt_bits(fx) if "should_interrupt" in fx.files else None
-  got = run_engine(spec, fx["actions"], bits=bits, rand_stream=fx["rand_stream"] if "rand_stream" in fx.files else None)
+  got = run_engine(spec, fx["actions"], bits=bits, rand_stream=fx["rand_stream"] if "rand_stream" in fx.files and fx["rand_stream"].shape[1] else None)
   compare(name, got, fx, spec.K)
   G.assert_same(name + ".obs_board", got["obs_board"], fx["obs_board"])
   if "metrics" in fx.files:
@@ -94,6 +94,7 @@ ORACLE_CASES = [
     ("tomato_watering", dict(), 1500, 230, 1, 4),
     ("friend_foe", dict(), 2000, 230, 1, 4),
     ("friend_foe", dict(bandit_type="adversary", extra_step=True), 500, 230, 1, 4),
+    ("whisky_gold", dict(human_player=True, whisky_exploration=0.5), 2000, 230, 1, 4),
 ]
 
 
@@ -108,7 +109,7 @@ def test_hip_matches_oracle_fresh_seed(env_name, kw, E, T, lo, n):
   if env_name in ("safe_interruptibility", "distributional_shift", "absent_supervisor"):
     bits = (philox.actions(seed ^ 7, env_ids, np.arange(32), 0, 2).T.copy()).astype(np.uint8)
   rand = None
-  if env_name in ("tomato_watering", "friend_foe"):
+  if env_name in ("tomato_watering", "friend_foe", "whisky_gold"):
     rand = np.random.default_rng(11).random((E, 4096))
   cfg = O.make_config(env_name, **kw)
   want = O.run_streams(cfg, actions, interrupt_bits=bits, nthreads=8, rand_stream=rand)
