@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(HERE, "libsgw.so")
 MAX_CELLS, MAX_K, MAX_M, MAX_AGENTS, N_PARAMS, ENV_ALIGN = 320, 16, 16, 4, 48, 64
 ABI_VERSION = 4
 
-ISLAND_NAVIGATION_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INTERRUPTIBILITY, FIREMAKER_EX_MA, ISLAND_NAVIGATION_EX_MA, TILE_EVENTS, SIDE_EFFECTS_SOKOBAN, CONVEYOR_BELT, TOMATO_WATERING, FRIEND_FOE, WHISKY_GOLD = range(12)
+ISLAND_NAVIGATION_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INTERRUPTIBILITY, FIREMAKER_EX_MA, ISLAND_NAVIGATION_EX_MA, TILE_EVENTS, SIDE_EFFECTS_SOKOBAN, CONVEYOR_BELT, TOMATO_WATERING, FRIEND_FOE, WHISKY_GOLD, ROCKS_DIAMONDS = range(13)
 FIRST, MID, LAST, DEAD = 0, 1, 2, 3
 TERM_NONE = 255
 

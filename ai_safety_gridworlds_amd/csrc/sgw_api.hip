@@ -15,6 +15,7 @@
 #include "sgw_island_ma.hpp"
 #include "sgw_island.hpp"
 #include "sgw_kernels.hpp"
+#include "sgw_rocks.hpp"
 #include "sgw_safeint.hpp"
 #include "sgw_sokoban.hpp"
 #include "sgw_tile.hpp"
@@ -69,6 +70,7 @@ static int family_words(const sgw_spec& sp) {
     case SGW_TOMATO_WATERING: return Tomato::words();
     case SGW_FRIEND_FOE: return FriendFoe::words();
     case SGW_WHISKY_GOLD: return Whisky::words();
+    case SGW_ROCKS_DIAMONDS: return Rocks::words();
     default: return -1;
   }
 }
@@ -250,6 +252,7 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
     case SGW_TOMATO_WATERING: SGW_LAUNCH(Tomato); break;
     case SGW_FRIEND_FOE: SGW_LAUNCH(FriendFoe); break;
     case SGW_WHISKY_GOLD: SGW_LAUNCH(Whisky); break;
+    case SGW_ROCKS_DIAMONDS: SGW_LAUNCH(Rocks); break;
     default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
   }
 #undef SGW_LAUNCH

@@ -10,7 +10,10 @@
 // The random numbers are an INPUT here (sgw_set_random_stream, or Philox when none is given): the process-global RNG
 // is shared state of the reference process, not of an env.
 //
-// spec.params: P_NTOMATO, P_DRY_PROB, P_FACTOR, P_NDELUSION, P_INIT_MASK, then the tomato cells in row-major order
+// tomato_crmdp.py (TC) is the same game with P_CRMDP = 1: on 'O' the observed REWARD is the maximum while the board
+// stays truthful (TC:139-144).
+//
+// spec.params: P_NTOMATO, P_DRY_PROB, P_FACTOR, P_NDELUSION, P_INIT_MASK, P_CRMDP, then the tomato cells in row-major order
 // state words: 0 core | 1 watered mask (low 32) + draw counter (high 32) | 2 hidden | 3 cumulative
 #pragma once
 
@@ -22,7 +25,7 @@ struct Tomato {
   static constexpr int NU = 1;
   static constexpr int NMETRIC = 1;
   static constexpr int MAXT = 24;
-  enum P { P_NTOMATO, P_DRY_PROB, P_FACTOR, P_NDELUSION, P_INIT_MASK, P_CELL0, P_COUNT = P_CELL0 + MAXT };
+  enum P { P_NTOMATO, P_DRY_PROB, P_FACTOR, P_NDELUSION, P_INIT_MASK, P_CRMDP, P_CELL0, P_COUNT = P_CELL0 + MAXT };
 
   struct State {
     int row, col, frame, step_type, term, actual;
@@ -112,7 +115,7 @@ struct Tomato {
     auto put = [&](int cell, uint32_t ch) {
       if ((cell >> 2) == i) { const int sh = (cell & 3) * 8; v = (v & ~(0xffu << sh)) | (ch << sh); }
     };
-    if (l.art[acell] == 'O') {
+    if (l.art[acell] == 'O' && p[P_CRMDP] == 0.0) {        // tomato_crmdp corrupts the reward, never the observation (TC:139)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const uint32_t ch = (v >> (8 * k)) & 0xffu;

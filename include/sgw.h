@@ -51,7 +51,8 @@ enum sgw_family {
   SGW_CONVEYOR_BELT = 8,           /* environments/conveyor_belt.py */
   SGW_TOMATO_WATERING = 9,         /* environments/tomato_watering.py */
   SGW_FRIEND_FOE = 10,             /* environments/friend_foe.py */
-  SGW_WHISKY_GOLD = 11             /* environments/whisky_gold.py */
+  SGW_WHISKY_GOLD = 11,            /* environments/whisky_gold.py */
+  SGW_ROCKS_DIAMONDS = 12          /* environments/rocks_diamonds.py */
 };
 
 enum sgw_step_type { SGW_FIRST = 0, SGW_MID = 1, SGW_LAST = 2, SGW_DEAD = 3 }; /* rl/environment{,_ma}.py */

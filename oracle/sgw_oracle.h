@@ -50,7 +50,8 @@ enum or_family {
   OR_CONVEYOR = 8,        /* environments/conveyor_belt.py        (CB) */
   OR_TOMATO = 9,          /* environments/tomato_watering.py      (TW) */
   OR_FRIEND_FOE = 10,     /* environments/friend_foe.py           (FF) */
-  OR_WHISKY_GOLD = 11     /* environments/whisky_gold.py          (WG) */
+  OR_WHISKY_GOLD = 11,    /* environments/whisky_gold.py          (WG) */
+  OR_ROCKS_DIAMONDS = 12  /* environments/rocks_diamonds.py       (RD) */
 };
 
 enum or_step_type { OR_FIRST = 0, OR_MID = 1, OR_LAST = 2 };   /* rl/environment.py StepType */
@@ -100,6 +101,8 @@ typedef struct {
   /* whisky_gold (WG:186-189) */
   double whisky_exploration;
   int32_t human_player;
+  /* tomato_crmdp.py (TC): the tomato_watering mechanics with a corrupt REWARD instead of a corrupt observation */
+  int32_t tomato_crmdp;
 } or_config;
 
 typedef struct {

@@ -86,6 +86,9 @@ CONFIGS = {
     "conveyor_sushi_goal": ("conveyor_belt", dict(variant="sushi_goal", noops=True, goal_reward=30), 64, 200, 0, 5),
     "conveyor_sushi_goal2": ("conveyor_belt", dict(variant="sushi_goal2", max_iterations=40), 64, 200, 1, 4),
     "tomato_watering": ("tomato_watering", dict(), 48, 250, 1, 4),
+    "tomato_crmdp": ("tomato_crmdp", dict(), 32, 250, 1, 4),
+    "rocks_L0": ("rocks_diamonds", dict(level=0), 96, 250, 1, 4),
+    "rocks_L1": ("rocks_diamonds", dict(level=1), 48, 250, 1, 4),
     "whisky_default": ("whisky_gold", dict(), 48, 200, 1, 4),
     "whisky_human": ("whisky_gold", dict(human_player=True, whisky_exploration=0.7), 48, 250, 1, 4),
     # friend_foe keeps its bandits' policy estimators in environment_data across episodes: one FRESH env per stream
@@ -144,6 +147,12 @@ def make_env(family, kw):
   if family == "tomato_watering":
     from ai_safety_gridworlds.environments import tomato_watering as m
     return m.TomatoWateringEnvironment(**kw), m
+  if family == "rocks_diamonds":
+    from ai_safety_gridworlds.environments import rocks_diamonds as m
+    return m.RocksDiamondsEnvironment(**kw), m
+  if family == "tomato_crmdp":
+    from ai_safety_gridworlds.environments import tomato_crmdp as m
+    return m.TomatoCRMDPEnvironment(**kw), m
   if family == "friend_foe":
     from ai_safety_gridworlds.environments import friend_foe as m
     return m.FriendFoeEnvironment(**kw), m
@@ -175,10 +184,10 @@ def run_config(name, out_dir):
   else:
     acts = philox.actions(SEED, env_ids, np.arange(T), lo, n_act)   # [T, E]
 
-  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor", "tomato_watering", "friend_foe", "whisky_gold"):
+  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor", "tomato_watering", "tomato_crmdp", "friend_foe", "whisky_gold"):
     np.random.seed(SEED)               # these envs draw from the process-global numpy RNG
   draws = None
-  if family == "tomato_watering":      # record every np.random.random() the env draws: the batched engine takes them as input
+  if family in ("tomato_watering", "tomato_crmdp"):      # record every np.random.random() the env draws: the batched engine takes them as input
     draws, _orig_random = [], np.random.random
     def _recording_random(*a, **k):
       v = _orig_random(*a, **k); draws.append(float(v)); return v

@@ -92,9 +92,12 @@ ORACLE_CASES = [
     ("conveyor_belt", dict(variant="vase", noops=True), 2000, 220, 0, 5),
     ("conveyor_belt", dict(variant="sushi_goal2", goal_reward=7), 1000, 220, 1, 4),
     ("tomato_watering", dict(), 1500, 230, 1, 4),
+    ("tomato_crmdp", dict(), 700, 230, 1, 4),
     ("friend_foe", dict(), 2000, 230, 1, 4),
     ("friend_foe", dict(bandit_type="adversary", extra_step=True), 500, 230, 1, 4),
     ("whisky_gold", dict(human_player=True, whisky_exploration=0.5), 2000, 230, 1, 4),
+    ("rocks_diamonds", dict(level=0), 3000, 230, 1, 4),
+    ("rocks_diamonds", dict(level=1), 500, 230, 1, 4),
 ]
 
 
@@ -109,7 +112,7 @@ def test_hip_matches_oracle_fresh_seed(env_name, kw, E, T, lo, n):
   if env_name in ("safe_interruptibility", "distributional_shift", "absent_supervisor"):
     bits = (philox.actions(seed ^ 7, env_ids, np.arange(32), 0, 2).T.copy()).astype(np.uint8)
   rand = None
-  if env_name in ("tomato_watering", "friend_foe", "whisky_gold"):
+  if env_name in ("tomato_watering", "tomato_crmdp", "friend_foe", "whisky_gold"):
     rand = np.random.default_rng(11).random((E, 4096))
   cfg = O.make_config(env_name, **kw)
   want = O.run_streams(cfg, actions, interrupt_bits=bits, nthreads=8, rand_stream=rand)

@@ -48,12 +48,12 @@ def test_spec_tables_match_reference_fixture(name):
   sb = np.array(list(table[:spec.H * spec.W]), np.uint8).reshape(spec.H, spec.W).copy()
   r, c = divmod(spec.native.start_cell[0], spec.W)
   sb[r, c] = ord('A')
-  if spec.name in ("side_effects_sokoban", "whisky_gold"):   # boxes / coins / the whisky drape are dynamic entities: the reset board is the level art itself
+  if spec.name in ("side_effects_sokoban", "whisky_gold", "rocks_diamonds"):   # boxes / coins / the whisky drape are dynamic entities: the reset board is the level art itself
     sb = np.array([[ord(ch) for ch in row] for row in spec.art], np.uint8)
   if spec.name == "friend_foe":                   # the floor drape depends on the bandit drawn for the episode
     sb = board[0, 0].copy()
     assert set(np.unique(sb)) <= set(map(ord, "#*AFNB"))
-  if spec.name == "tomato_watering":              # tomatoes are dynamic; some of the initially watered ones dried during its_showtime
+  if spec.name in ("tomato_watering", "tomato_crmdp"):              # tomatoes are dynamic; some of the initially watered ones dried during its_showtime
     sb = board[0, 0].copy()
     assert set(np.unique(sb[(sb != np.array([[ord(ch) for ch in row] for row in spec.art], np.uint8))])) <= {ord('t')}
   if spec.name == "conveyor_belt":               # the belt drape is stretched over its row at construction; the object rides on it
