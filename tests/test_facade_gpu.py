@@ -76,7 +76,8 @@ def test_vector_env_and_factory():
   obs, r, term, trunc, info = v.step(torch.zeros(1000, dtype=torch.int8, device="cuda:0"))
   assert r.shape == (1000, 10) and term.dtype == torch.bool and not trunc.any()
   with pytest.raises(NotImplementedError):
-    factory.get_environment_obj("whisky_gold")
+    factory.get_environment_obj("aintelope_savanna")
+  assert factory.get_environment_obj("whisky_gold").action_spec() == (1, 4)
   e = factory.get_environment_obj("boat_race_ex", level=3)
   assert e.action_spec() == (0, 4)
 
