@@ -14,7 +14,8 @@ from . import build as _build
 ISLAND_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INT, ISLAND_NAV, DIST_SHIFT, ABSENT_SUP, SOKOBAN, CONVEYOR, TOMATO, FRIEND_FOE, WHISKY_GOLD, ROCKS_DIAMONDS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 FAMILY_IDS = {"island_navigation_ex": ISLAND_EX, "boat_race_ex": BOAT_RACE_EX,
               "boat_race": BOAT_RACE, "safe_interruptibility": SAFE_INT, "island_navigation": ISLAND_NAV,
-              "distributional_shift": DIST_SHIFT, "absent_supervisor": ABSENT_SUP, "side_effects_sokoban": SOKOBAN, "conveyor_belt": CONVEYOR, "tomato_watering": TOMATO, "friend_foe": FRIEND_FOE, "whisky_gold": WHISKY_GOLD, "tomato_crmdp": TOMATO, "rocks_diamonds": ROCKS_DIAMONDS}
+              "distributional_shift": DIST_SHIFT, "absent_supervisor": ABSENT_SUP, "side_effects_sokoban": SOKOBAN, "conveyor_belt": CONVEYOR, "tomato_watering": TOMATO, "friend_foe": FRIEND_FOE, "whisky_gold": WHISKY_GOLD, "tomato_crmdp": TOMATO, "rocks_diamonds": ROCKS_DIAMONDS,
+              "conveyor_belt_ex": CONVEYOR, "safe_interruptibility_ex": SAFE_INT}
 BANDIT_TYPES = ["friend", "neutral", "adversary"]
 CONVEYOR_VARIANTS = ["vase", "sushi", "sushi_goal", "sushi_goal2"]
 MAXCELLS, MAXK, MAXM = 320, 16, 16
@@ -44,7 +45,7 @@ class Config(C.Structure):
          ("interruption_probability", _F64), ("is_testing", _I32), ("level_choice", _I32), ("supervisor", _I32)]
       + [(n, _F64) for n in ("sk_movement_reward", "sk_coin_reward", "sk_goal_reward", "sk_wall_reward", "sk_corner_reward")]
       + [("variant", _I32), ("cb_goal_reward", _F64), ("bandit_type", _I32), ("extra_step", _I32),
-         ("whisky_exploration", _F64), ("human_player", _I32), ("tomato_crmdp", _I32)])
+         ("whisky_exploration", _F64), ("human_player", _I32), ("tomato_crmdp", _I32), ("mo_twin", _I32)])
 
 
 class TimeStep(C.Structure):
@@ -103,11 +104,15 @@ def make_config(family, **kw):
   lib().or_default_config(fid, C.byref(cfg))
   if family == "tomato_crmdp":
     cfg.tomato_crmdp = 1
+  if family in ("conveyor_belt_ex", "safe_interruptibility_ex"):
+    cfg.mo_twin = 1
   names = {f[0] for f in Config._fields_}
   for k, v in kw.items():
     k = k.lower()
     if fid == CONVEYOR and k == "goal_reward":
       k = "cb_goal_reward"
+      if isinstance(v, dict):
+        v = list(v.values())[0]
     if fid == CONVEYOR and k == "variant" and isinstance(v, str):
       v = CONVEYOR_VARIANTS.index(v)
     if fid == SOKOBAN and "sk_" + k in names:       # movement_reward / coin_reward / ... (side_effects_sokoban.py:318-325)

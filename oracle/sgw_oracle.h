@@ -103,6 +103,9 @@ typedef struct {
   int32_t human_player;
   /* tomato_crmdp.py (TC): the tomato_watering mechanics with a corrupt REWARD instead of a corrupt observation */
   int32_t tomato_crmdp;
+  /* conveyor_belt_ex.py (CX) / safe_interruptibility_ex.py (SX): the MO twins -- one reward dimension "REWARD", the MO
+   * action enum for the AGENT only, hidden rewards turned into observed ones */
+  int32_t mo_twin;
 } or_config;
 
 typedef struct {

@@ -87,6 +87,13 @@ CONFIGS = {
     "conveyor_sushi_goal2": ("conveyor_belt", dict(variant="sushi_goal2", max_iterations=40), 64, 200, 1, 4),
     "tomato_watering": ("tomato_watering", dict(), 48, 250, 1, 4),
     "tomato_crmdp": ("tomato_crmdp", dict(), 32, 250, 1, 4),
+    # the MO twins of conveyor_belt / safe_interruptibility
+    "conveyorex_vase": ("conveyor_belt_ex", dict(variant="vase", noops=True), 48, 200, 0, 5),
+    "conveyorex_sushi_goal": ("conveyor_belt_ex", dict(variant="sushi_goal"), 48, 200, 1, 4),
+    "conveyorex_sushi_goal2": ("conveyor_belt_ex", dict(variant="sushi_goal2", max_iterations=40), 32, 200, 1, 4),
+    "safeintex_L1": ("safe_interruptibility_ex", dict(level=1), 64, 200, 1, 4),
+    "safeintex_L2": ("safe_interruptibility_ex", dict(level=2, noops=True), 48, 200, 0, 5),
+    "safeintex_L0_p1": ("safe_interruptibility_ex", dict(level=0, interruption_probability=1.0), 32, 200, 1, 4),
     "rocks_L0": ("rocks_diamonds", dict(level=0), 96, 250, 1, 4),
     "rocks_L1": ("rocks_diamonds", dict(level=1), 48, 250, 1, 4),
     "whisky_default": ("whisky_gold", dict(), 48, 200, 1, 4),
@@ -147,6 +154,14 @@ def make_env(family, kw):
   if family == "tomato_watering":
     from ai_safety_gridworlds.environments import tomato_watering as m
     return m.TomatoWateringEnvironment(**kw), m
+  if family == "conveyor_belt_ex":
+    from ai_safety_gridworlds.environments import conveyor_belt_ex as m
+    FLAGS = m.define_flags()
+    return m.ConveyorBeltEnvironmentEx(FLAGS=FLAGS, **kw), m
+  if family == "safe_interruptibility_ex":
+    from ai_safety_gridworlds.environments import safe_interruptibility_ex as m
+    FLAGS = m.define_flags()
+    return m.SafeInterruptibilityEnvironmentEx(FLAGS=FLAGS, seed=SEED, **kw), m
   if family == "rocks_diamonds":
     from ai_safety_gridworlds.environments import rocks_diamonds as m
     return m.RocksDiamondsEnvironment(**kw), m
@@ -176,7 +191,7 @@ def run_config(name, out_dir):
   import numpy as np
   from ai_safety_gridworlds_amd import philox
   family, kw, E, T, lo, n_act = CONFIGS[name]
-  is_mo = family in ("island_ex", "boat_race_ex")
+  is_mo = family in ("island_ex", "boat_race_ex", "conveyor_belt_ex", "safe_interruptibility_ex")
 
   env_ids = np.arange(E, dtype=np.uint64)
   if name.endswith("_lazy"):
@@ -245,7 +260,7 @@ def run_config(name, out_dir):
     rec["layers"] = np.zeros((NRGB, S, len(layer_chars), H, W), np.bool_)
   if family in ("island_ex", "island_navigation", "friend_foe"):
     rec["safety"] = np.zeros((E, S), np.int32)
-  if family in ("safe_interruptibility", "distributional_shift", "absent_supervisor", "friend_foe", "whisky_gold"):
+  if family in ("safe_interruptibility", "safe_interruptibility_ex", "distributional_shift", "absent_supervisor", "friend_foe", "whisky_gold"):
     rec["should_interrupt"] = np.zeros((E, S), np.bool_)       # the per-build random bit of the env
 
   def record(e, t, ts):
@@ -285,7 +300,7 @@ def run_config(name, out_dir):
       rec["cumulative"][e, t, 0] = env.episode_return
     if family in ("island_ex", "island_navigation"):
       rec["safety"][e, t] = env.environment_data["safety"]
-    if family == "safe_interruptibility":
+    if family in ("safe_interruptibility", "safe_interruptibility_ex"):
       rec["should_interrupt"][e, t] = env.environment_data["should_interrupt"]
     if family == "distributional_shift":
       rec["should_interrupt"][e, t] = env.environment_data["current_level"] == 2

@@ -9,7 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 FAMILY_NAMES = {"island_ex": "island_navigation_ex", "boat_race_ex": "boat_race_ex",
                 "boat_race": "boat_race", "safe_interruptibility": "safe_interruptibility"}
-SCALAR_PREFIXES = ["island_", "boat_", "safe_int_", "islnav_", "dshift_", "absent_", "sokoban_", "conveyor_", "tomato_", "friendfoe_", "whisky_", "rocks_"]     # single-agent fixture families
+SCALAR_PREFIXES = ["island_", "boat_", "safe_int_", "islnav_", "dshift_", "absent_", "sokoban_", "conveyor_", "tomato_", "friendfoe_", "whisky_", "rocks_", "conveyorex_", "safeintex_"]     # single-agent fixture families
 
 
 def fixture_names(prefixes=None):

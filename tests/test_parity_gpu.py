@@ -98,6 +98,8 @@ ORACLE_CASES = [
     ("whisky_gold", dict(human_player=True, whisky_exploration=0.5), 2000, 230, 1, 4),
     ("rocks_diamonds", dict(level=0), 3000, 230, 1, 4),
     ("rocks_diamonds", dict(level=1), 500, 230, 1, 4),
+    ("conveyor_belt_ex", dict(variant="sushi_goal", noops=True), 1500, 220, 0, 5),
+    ("safe_interruptibility_ex", dict(level=2), 1500, 150, 1, 4),
 ]
 
 
@@ -109,7 +111,7 @@ def test_hip_matches_oracle_fresh_seed(env_name, kw, E, T, lo, n):
   env_ids = np.arange(E)
   actions = philox.actions(seed, env_ids, np.arange(T), lo, n).T.copy()     # [E, T]
   bits = None
-  if env_name in ("safe_interruptibility", "distributional_shift", "absent_supervisor"):
+  if env_name in ("safe_interruptibility", "safe_interruptibility_ex", "distributional_shift", "absent_supervisor"):
     bits = (philox.actions(seed ^ 7, env_ids, np.arange(32), 0, 2).T.copy()).astype(np.uint8)
   rand = None
   if env_name in ("tomato_watering", "tomato_crmdp", "friend_foe", "whisky_gold"):

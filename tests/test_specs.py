@@ -56,7 +56,7 @@ def test_spec_tables_match_reference_fixture(name):
   if spec.name in ("tomato_watering", "tomato_crmdp"):              # tomatoes are dynamic; some of the initially watered ones dried during its_showtime
     sb = board[0, 0].copy()
     assert set(np.unique(sb[(sb != np.array([[ord(ch) for ch in row] for row in spec.art], np.uint8))])) <= {ord('t')}
-  if spec.name == "conveyor_belt":               # the belt drape is stretched over its row at construction; the object rides on it
+  if spec.name in ("conveyor_belt", "conveyor_belt_ex"):   # the belt drape is stretched over its row at construction; the object rides on it
     orow, ocol = divmod("".join(spec.art).index('O'), spec.W)
     sb[orow, ocol] = ord('O')
   assert np.array_equal(sb, board[0, 0])
