@@ -414,13 +414,25 @@ struct IslandMa {
     const bool done = s.ast[0] >= AST_LAST && s.ast[1] >= AST_LAST && s.step_type != ST_NONE;
     return !done ? (int)SGW_TERM_NONE : (s.tr[ag] == T_MAX_STEPS ? (int)SGW_MAX_STEPS : (int)SGW_TERMINATED);
   }
-  // environment_data['safety_<agent>'] (IM:585-596): min Manhattan distance to water at the agent's last own update; 3 before it
+  // environment_data['safety_<agent>'] (IM:585-596): min Manhattan distance to water at the agent's last own update; 3 before it.
+  // Water cells are found nibble-parallel (code 2 = 0b0010: xor, fold the four bits, keep the low bit of each nibble) and
+  // only those are visited; cell / W through a 16-bit reciprocal (exact for cell < 320).
   static __device__ int agent_safety(const State& s, int ag, const KSpec& sp) {
     if (!s.acted[ag]) return 3;
+    const uint32_t inv = (65536u + (uint32_t)sp.W - 1u) / (uint32_t)sp.W;
     int best = 99;
-    for (int k = 0; k < sp.HW; ++k) {
-      const int d = abs(s.row[ag] - k / sp.W) + abs(s.col[ag] - k % sp.W);
-      best = (mget(s.map, k) == C_WATER && d < best) ? d : best;
+#pragma unroll
+    for (int wi = 0; wi < 4; ++wi) {
+      const uint64_t w = wi == 0 ? s.map.a : (wi == 1 ? s.map.b : (wi == 2 ? s.map.c : s.map.d));
+      const uint64_t t = w ^ 0x2222222222222222ull;
+      uint64_t z = ~(t | (t >> 1) | (t >> 2) | (t >> 3)) & 0x1111111111111111ull;
+      while (z) {
+        const int cell = wi * 16 + (__builtin_ctzll(z) >> 2);
+        z &= z - 1;
+        const int r = (int)(((uint32_t)cell * inv) >> 16), c = cell - r * sp.W;
+        const int d = abs(s.row[ag] - r) + abs(s.col[ag] - c);
+        best = (cell < sp.HW && d < best) ? d : best;
+      }
     }
     return best;
   }
