@@ -165,8 +165,8 @@ struct IslandMa {
 
   // ---- 4-bit map ----------------------------------------------------------------------------------------------
   static __device__ uint64_t mword(const Map4& m, int wi) {        // mask-select (see Firemaker::word_of)
-    return (m.a & (0ull - (uint64_t)(wi == 0))) | (m.b & (0ull - (uint64_t)(wi == 1))) | (m.c & (0ull - (uint64_t)(wi == 2))) |
-           (m.d & (0ull - (uint64_t)(wi == 3)));
+    const uint64_t lo = wi == 0 ? m.a : m.b, hi = wi == 2 ? m.c : m.d;      // the words are register values here, not loads
+    return wi < 2 ? lo : hi;
   }
   static __device__ int mget(const Map4& m, int cell) { return (int)((mword(m, cell >> 4) >> ((cell & 15) * 4)) & 15ull); }
   static __device__ void mset(Map4& m, int cell, int v) {
