@@ -129,18 +129,23 @@ int64_t sgw_n_envs(const sgw_engine* e);
 int64_t sgw_n_pad(const sgw_engine* e);
 int64_t sgw_state_bytes(const sgw_engine* e);
 
-/* Per-episode external inputs (safe_interruptibility should_interrupt bits): bits_dev is
- * uint8 [N, n_per_env]; the k-th episode of env n uses bits[n, k % n_per_env].  NULL => drawn
- * from Philox(seed, env id, episode) <= interruption_probability. */
+/* Per-game-build external inputs: ONE number of the process-global numpy RNG per make_game (safe_interruptibility.py:256-258
+ * should_interrupt; absent_supervisor.py:91-93 supervisor present; distributional_shift.py:93-95 test level 1 or 2).
+ * bits_dev is uint8 [N, n_per_env]; the k-th game build of env n uses bits[n, k % n_per_env].  NULL => drawn from
+ * Philox(seed, env id, build) against the env's probability. */
 int sgw_set_episode_bits(sgw_engine* e, const uint8_t* bits_dev, int n_per_env, uint64_t seed);
 
-/* In-play random numbers for envs that draw from the process-global numpy RNG while stepping (tomato_watering.py:154-156:
- * np.random.random() per watered tomato and step).  u_dev double [N, n_per_env]: the k-th draw of env i is
+/* Random numbers for envs that draw from the process-global numpy RNG an input-dependent number of times (tomato_watering.py:
+ * 154-156 and tomato_crmdp.py: np.random.random() per watered tomato and step; friend_foe.py:145-155: np.random.choice of the
+ * bandit and np.random.rand() per game build; whisky_gold.py:158-163: rand() + choice() per explored step).  A `choice`
+ * among k items is floor(k * u).  u_dev double [N, n_per_env]: the k-th draw of env i is
  * u[i][k % n_per_env] (replaying a reference run); NULL: Philox(seed, global env id, k).  The draw counter is env state. */
 int sgw_set_random_stream(sgw_engine* e, const double* u_dev, int n_per_env, uint64_t seed);
 
-/* Multi-agent RNG streams (firemaker): pcg_state_dev is uint64 [N, 4] = numpy PCG64
- * (state_hi, state_lo, inc_hi, inc_lo) per env, as produced by np.random.PCG64(SeedSequence(seed)). */
+/* Env-owned numpy Generators (environment_data[NP_RANDOM] = seeding.np_random(seed), safety_game_mo.py:283-291): firemaker_ex_ma
+ * (fire spread, agent order) and island_navigation_ex_ma (agent order, map randomisation).  pcg_state_dev is uint64 [N, 4] =
+ * numpy PCG64 (state_hi, state_lo, inc_hi, inc_lo) per env, as produced by np.random.PCG64(SeedSequence(seed)).  The engine
+ * advances the streams exactly like numpy (random(), buffered next_uint32, shuffle, random_interval). */
 int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev);
 
 /* Start a new episode in every env with mask_dev[n] != 0 (NULL = all) and emit the FIRST
