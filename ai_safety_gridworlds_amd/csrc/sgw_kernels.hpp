@@ -235,7 +235,7 @@ __global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
     if (a.ep_acc && leader) {
       acc_any = __ballot(over_now && real) != 0ull;          // wave-uniform
       if (acc_any) {
-        if (lane < C) acc_old = a.ep_acc[(long long)blockIdx.x * C + lane];   // consumed after the output phase
+        if (lane < 16 && lane < C) acc_old = a.ep_acc[(long long)blockIdx.x * C + lane];   // consumed after the output phase
 #pragma unroll
         for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_a, l.trash, lane, C, F::slot(a.sp, u)) = over_now ? s.cum[u] : 0.0;
         l.vec_a[lane * C + C - 1] = over_now ? 1.0 : 0.0;    // made visible by the output phase's LDS fence
@@ -247,20 +247,28 @@ __global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
     SGW_STAMP(a, 3);
     if (acc_any) {
       lds_wave_sync();
-      // lane = part*16 + column: 4 partial sums of 16 rows each (reads batched), combined in a fixed tree
-      const int col = lane & 15, part = lane >> 4;
-      double v[16];
+      // lane = part*16 + column: 4 partial sums of 16 rows each (reads batched), combined in a fixed tree; 16 columns per
+      // pass (one pass for C <= 16: every single-agent family and firemaker; island_navigation_ex_ma has 2K + 1 = 17..25)
+      const int part = lane >> 4;
+      for (int c0 = 0; c0 < C; c0 += 16) {
+        const int col = c0 + (lane & 15);
+        double v[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int row = part * 16 + j;
-        v[j] = (col < C && env0 + row < a.n_envs) ? l.vec_a[row * C + col] : 0.0;
+        for (int j = 0; j < 16; ++j) {
+          const int row = part * 16 + j;
+          v[j] = (col < C && env0 + row < a.n_envs) ? l.vec_a[row * C + col] : 0.0;
+        }
+        double p = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) p += v[j];
+        p += __shfl_xor(p, 16, WAVE);
+        p += __shfl_xor(p, 32, WAVE);
+        if (c0 == 0) {
+          if (lane < 16 && lane < C) a.ep_acc[(long long)blockIdx.x * C + lane] = acc_old + p;
+        } else if (part == 0 && col < C) {
+          a.ep_acc[(long long)blockIdx.x * C + col] += p;
+        }
       }
-      double p = 0.0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) p += v[j];
-      p += __shfl_xor(p, 16, WAVE);
-      p += __shfl_xor(p, 32, WAVE);
-      if (lane < C) a.ep_acc[(long long)blockIdx.x * C + lane] = acc_old + p;
     }
   }
   SGW_STAMP(a, 4);

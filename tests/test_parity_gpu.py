@@ -135,17 +135,31 @@ def test_device_philox_matches_host():
   assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("env_name,kw", [("island_navigation_ex", {}), ("boat_race_ex", dict(level=3)),
-                                         ("safe_interruptibility", {}), ("boat_race", {})])
+def _fresh(spec, n, outs):
+  e = BatchedEngine(spec, n, outputs=outs)
+  e.set_episode_bits(None, seed=5)
+  e.set_random_stream(None, seed=6)
+  if getattr(spec, "needs_rng", False):
+    e.set_rng_seeds(np.arange(n) + 3)
+  e.reset()
+  return e
+
+
+@pytest.mark.parametrize("env_name,kw", [
+    ("island_navigation_ex", {}), ("boat_race_ex", dict(level=3)), ("safe_interruptibility", {}), ("boat_race", {}),
+    ("island_navigation", {}), ("distributional_shift", dict(is_testing=True)), ("absent_supervisor", {}),
+    ("side_effects_sokoban", dict(level=1)), ("conveyor_belt", dict(variant="sushi_goal")), ("rocks_diamonds", {}),
+    ("tomato_watering", {}), ("tomato_crmdp", {}), ("friend_foe", {}), ("whisky_gold", dict(human_player=True)),
+    ("conveyor_belt_ex", dict(variant="vase")), ("safe_interruptibility_ex", {}),
+    ("island_navigation_ex_ma", dict(map_randomization_frequency=3, max_iterations=30)),
+])
 def test_fused_rollout_equals_step_loop(env_name, kw):
   """sgw_rollout (state in registers, in-kernel Philox) == T x sgw_step fed the same stream."""
   spec = make_spec(env_name, **kw)
-  n, T, seed = 5000, 64, 99
+  n, T, seed = 3000, 64, 99
   outs = ("board", "reward", "cumulative", "step_type", "term_reason", "hidden", "frame")
-  a = BatchedEngine(spec, n, outputs=outs)
-  b = BatchedEngine(spec, n, outputs=outs)
-  a.set_episode_bits(None, seed=5); b.set_episode_bits(None, seed=5)
-  a.reset(); b.reset()
+  a = _fresh(spec, n, outs)
+  b = _fresh(spec, n, outs)
   acts = a.fill_actions(T, seed)
   per_step = {k: [] for k in outs}
   for t in range(T):
@@ -157,20 +171,18 @@ def test_fused_rollout_equals_step_loop(env_name, kw):
     assert torch.equal(torch.stack(per_step[k]), ro[k]), k
   assert torch.equal(a.get_state()[:, :n], b.get_state()[:, :n])
   # accumulators: sum of returns of finished episodes + count, vs the step loop's outputs
-  c = BatchedEngine(spec, n, outputs=outs)
-  c.set_episode_bits(None, seed=5)
-  c.reset()
+  c = _fresh(spec, n, outs)
   c.rollout(T, seed, accumulate=True)
   acc = c.read_returns(clear=True)
   assert c.read_returns().abs().sum().item() == 0
-  st = torch.stack(per_step["step_type"]).reshape(T, n)
-  cum = torch.stack(per_step["cumulative"]).reshape(T, n, spec.K)
-  last = st == 2
-  assert acc[spec.K].item() == last.sum().item()
-  assert torch.equal(acc[:spec.K], (cum * last[..., None]).sum(dim=(0, 1)))
-  d = BatchedEngine(spec, n, outputs=outs)
-  d.set_episode_bits(None, seed=5)
-  d.reset()
+  AK = spec.A * spec.K
+  st = torch.stack(per_step["step_type"]).reshape(T, n, spec.A)
+  cum = torch.stack(per_step["cumulative"]).reshape(T, n, AK)
+  prev = torch.cat([torch.zeros_like(st[:1]), st[:-1]])
+  last = (st >= 2).all(dim=2) & ~(prev >= 2).all(dim=2)          # the step at which the episode ended for every agent
+  assert acc[AK].item() == last.sum().item()
+  assert torch.equal(acc[:AK], (cum * last[..., None]).sum(dim=(0, 1)))
+  d = _fresh(spec, n, outs)
   d.step_n(acts, accumulate=True)
   assert torch.equal(d.read_returns(), acc)
 
