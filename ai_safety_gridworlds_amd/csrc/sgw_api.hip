@@ -279,16 +279,17 @@ int sgw_step(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, void*
 
 static void offset_out(sgw_out& o, const sgw_spec& sp, long long n_pad, long long t) {
   const long long HW = sp.H * sp.W, AK = sp.A * sp.K, A = sp.A, M = sp.M, r = t * n_pad;
+  const long long PA = sp.family == SGW_ISLAND_NAVIGATION_EX_MA ? A : 1;   // term_reason / safety are [N_pad, A] there (IslandMa::PER_AGENT)
   if (o.board) o.board += r * HW;
   if (o.obs_board) o.obs_board += r * HW;
   if (o.reward) o.reward += r * AK;
   if (o.cumulative) o.cumulative += r * AK;
   if (o.step_type) o.step_type += r * A;
-  if (o.term_reason) o.term_reason += r;
+  if (o.term_reason) o.term_reason += r * PA;
   if (o.actual_action) o.actual_action += r * A;
   if (o.discount) o.discount += r;
   if (o.hidden) o.hidden += r;
-  if (o.safety) o.safety += r;
+  if (o.safety) o.safety += r * PA;
   if (o.metrics) o.metrics += r * M;
   if (o.frame) o.frame += r;
   if (o.agent_pos) o.agent_pos += r * A * 2;
