@@ -183,7 +183,9 @@ def test_fused_rollout_equals_step_loop(env_name, kw):
   assert acc[AK].item() == last.sum().item()
   assert torch.equal(acc[:AK], (cum * last[..., None]).sum(dim=(0, 1)))
   d = _fresh(spec, n, outs)
-  d.step_n(acts, accumulate=True)
+  every = d.step_n(acts, write_every=True, accumulate=True)       # T launches writing [T, N, ...] == the rollout buffer
+  for k in outs:
+    assert torch.equal(every[k], ro[k]), "step_n " + k
   assert torch.equal(d.read_returns(), acc)
 
 
