@@ -11,6 +11,7 @@
 // spec.aux holds the penalty class of every cell.  performance = hidden reward (SK:369-372).
 //
 // spec.aux   : per cell 0 / 1 (contiguous wall) / 2 (corner) for a box standing there
+// spec.art   : per cell coin index + 1 (0 = no coin) -- the renderer's lookup
 // spec.params: enum P; box start cells, box characters, coin cells
 // state words: 0 core (bits 48-55 coins left, 56-61 penalty class of each box) | 1 box positions | 2 hidden | 3 cumulative
 #pragma once
@@ -119,7 +120,7 @@ struct Sokoban {
     r[0] += p[P_MOVE]; s.hidden += p[P_MOVE];
     const int cell = s.row * W + s.col;
     bool terminated = false;
-    if (l.art[cell] == 'G') { r[0] += p[P_GOAL]; s.hidden += p[P_GOAL]; terminated = true; }
+    if (l.static_board[cell] == 'G') { r[0] += p[P_GOAL]; s.hidden += p[P_GOAL]; terminated = true; }
     bool got = false;
     for (int q = 0; q < nc; ++q) {
       const bool here = ((s.coins >> q) & 1u) && (int)p[P_COINCELL0 + q] == cell;
@@ -153,7 +154,14 @@ struct Sokoban {
     };
 #pragma unroll
     for (int j = 0; j < MAXBOX; ++j) if (j < nb) put(s.brow[j] * sp.W + s.bcol[j], (uint32_t)p[P_BOXCHR0 + j]);
-    for (int q = 0; q < nc; ++q) if ((s.coins >> q) & 1u) put((int)p[P_COINCELL0 + q], (uint32_t)'C');
+    {                                                      // spec.art here: coin index + 1 per cell (0 = none): four lookups per dword
+      const uint32_t idx = reinterpret_cast<const uint32_t*>(l.art)[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t q = (idx >> (8 * k)) & 0xffu;
+        if (q != 0u && ((s.coins >> (q - 1u)) & 1u)) v = (v & ~(0xffu << (8 * k))) | ((uint32_t)'C' << (8 * k));
+      }
+    }
     put(s.row * sp.W + s.col, (uint32_t)'A');
     return v;
   }

@@ -121,9 +121,13 @@ struct Tomato {
         const uint32_t ch = (v >> (8 * k)) & 0xffu;
         if (ch != '#' && ch != 'O' && ch != 0u) v = (v & ~(0xffu << (8 * k))) | ((uint32_t)'T' << (8 * k));
       }
-    } else {
-      const int n = (int)p[P_NTOMATO];
-      for (int q = 0; q < n; ++q) if ((s.watered >> q) & 1u) put((int)p[P_CELL0 + q], (uint32_t)'T');
+    } else {                                               // spec.aux: tomato index + 1 per cell (0 = no tomato): four lookups per dword
+      const uint32_t idx = reinterpret_cast<const uint32_t*>(l.aux)[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t q = (idx >> (8 * k)) & 0xffu;
+        if (q != 0u && ((s.watered >> (q - 1u)) & 1u)) v = (v & ~(0xffu << (8 * k))) | ((uint32_t)'T' << (8 * k));
+      }
     }
     put(acell, (uint32_t)'A');
     return v;

@@ -84,6 +84,20 @@ WORKLOADS = {
     # 2 x K cumulative): 2 + 2*304 + 48 + 128 + 2 + 2 + 8
     "island_navigation_ex_ma": dict(kwargs={}, envs=65536, b_step=798, b_fused=190,
                                     outputs=("board", "reward", "step_type", "term_reason", "safety")),
+    # original-suite families: 1 action + state read + state write + board + reward 8 + step_type 1 + term 1 + hidden 8
+    "island_navigation": dict(kwargs={}, envs=65536, b_step=131, b_fused=67, outputs=("board", "reward", "step_type", "term_reason", "hidden")),
+    "distributional_shift": dict(kwargs=dict(is_testing=True), envs=65536, b_step=146, b_fused=82,
+                                 outputs=("board", "reward", "step_type", "term_reason", "hidden")),
+    "absent_supervisor": dict(kwargs={}, envs=65536, b_step=131, b_fused=67, outputs=("board", "reward", "step_type", "term_reason", "hidden")),
+    "side_effects_sokoban": dict(kwargs=dict(level=1), envs=65536, b_step=183, b_fused=119,
+                                 outputs=("board", "reward", "step_type", "term_reason", "hidden")),
+    "conveyor_belt": dict(kwargs=dict(variant="sushi_goal"), envs=65536, b_step=132, b_fused=68,
+                          outputs=("board", "reward", "step_type", "term_reason", "hidden")),
+    "rocks_diamonds": dict(kwargs={}, envs=65536, b_step=146, b_fused=82, outputs=("board", "reward", "step_type", "term_reason", "hidden")),
+    "tomato_watering": dict(kwargs={}, envs=65536, b_step=146, b_fused=82, outputs=("board", "reward", "step_type", "term_reason", "hidden")),
+    "friend_foe": dict(kwargs={}, envs=65536, b_step=193, b_fused=49, outputs=("board", "reward", "step_type", "term_reason", "hidden")),
+    "whisky_gold": dict(kwargs=dict(human_player=True), envs=65536, b_step=131, b_fused=67,
+                        outputs=("board", "reward", "step_type", "term_reason", "hidden")),
 }
 MIXED = ("island_navigation_ex", "boat_race_ex", "safe_interruptibility")    # BASELINE.json configs[4]
 
@@ -140,8 +154,10 @@ def main():
     eng = BatchedEngine(spec, cnt, device=device, env_id_base=base, outputs=wl["outputs"])
     if fam == "firemaker_ex_ma" or getattr(spec, "needs_rng", False):
       eng.set_rng_seeds(base + np.arange(cnt))
-    if fam == "safe_interruptibility":
+    if fam == "safe_interruptibility" or getattr(spec, "episode_bit", False):
       eng.set_episode_bits(None, seed=SEED)
+    if getattr(spec, "random_stream", False):
+      eng.set_random_stream(None, seed=SEED)
     eng.reset()
     engines.append(dict(fam=fam, spec=spec, eng=eng, n=cnt, wl=wl, acts=eng.fill_actions(W + K, SEED),
                         stream=torch.cuda.Stream(device) if len(parts) > 1 else torch.cuda.current_stream(device)))
@@ -186,8 +202,10 @@ def main():
     eng2 = BatchedEngine(e["spec"], e["n"], device=device, env_id_base=rank * e["n"], outputs=e["wl"]["outputs"])
     if e["fam"] == "firemaker_ex_ma" or getattr(e["spec"], "needs_rng", False):
       eng2.set_rng_seeds(rank * e["n"] + np.arange(e["n"]))
-    if e["fam"] == "safe_interruptibility":
+    if e["fam"] == "safe_interruptibility" or getattr(e["spec"], "episode_bit", False):
       eng2.set_episode_bits(None, seed=SEED)
+    if getattr(e["spec"], "random_stream", False):
+      eng2.set_random_stream(None, seed=SEED)
     eng2.reset()
     Tf = min(K, 512 if e["fam"] != "firemaker_ex_ma" else 128)
     eng2.rollout(Tf, SEED, step0=0, write_every=True)   # untimed: allocates the [Tf, N, ...] outputs, warms the code object
@@ -225,6 +243,11 @@ def main():
             "safe_interruptibility": "safe_interruptibility level 1", "boat_race": "boat_race level 0",
             "firemaker_ex_ma": "firemaker_ex_ma level 0, 3 agents (one env-step = one round)",
             "island_navigation_ex_ma": "island_navigation_ex_ma level 9 default flags, 2 agents (one env-step = one round)",
+            "island_navigation": "island_navigation", "distributional_shift": "distributional_shift (testing)",
+            "absent_supervisor": "absent_supervisor", "side_effects_sokoban": "side_effects_sokoban level 1",
+            "conveyor_belt": "conveyor_belt sushi_goal", "rocks_diamonds": "rocks_diamonds level 0",
+            "tomato_watering": "tomato_watering (Philox drying draws)", "friend_foe": "friend_foe (Philox bandit draws)",
+            "whisky_gold": "whisky_gold, human_player (Philox exploration draws)",
             "mixed": "mixed suite island_navigation_ex + boat_race_ex + safe_interruptibility on 3 streams"}[a.workload]
     line = {
         "metric": "env-steps/sec (whole node), 65 536 batched envs per GPU",
