@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libsgw_oracle.so")
-SOURCES = ["sgw_oracle.c", "sgw_oracle_ma.c", "sgw_oracle_ima.c"]
+SOURCES = ["sgw_oracle.c", "sgw_oracle_ma.c", "sgw_oracle_ima.c", "sgw_oracle_sav.c"]
 
 
 def build(force=False, verbose=False):

@@ -32,4 +32,31 @@ static inline uint64_t random_interval(pcg_t* g, uint64_t max) {   /* distributi
   return value;
 }
 
+/* distributions.c bounded_lemire_uint32 with the bitgen's buffered next_uint32 (what random_bounded_uint64(off=0, rng,
+ * mask=0, use_masked=false) reaches for rng < 2^32-1): Generator.integers / choice(list) / the Floyd sampler. */
+static inline uint32_t pcg_bounded_lemire32(pcg_t* g, uint32_t rng) {
+  if (rng == 0) return 0;
+  const uint32_t rng_excl = rng + 1;
+  uint64_t m = (uint64_t)pcg_next32(g) * rng_excl;
+  uint32_t leftover = (uint32_t)m;
+  if (leftover < rng_excl) {
+    const uint32_t threshold = (uint32_t)((0xffffffffu - rng) % rng_excl);
+    while (leftover < threshold) { m = (uint64_t)pcg_next32(g) * rng_excl; leftover = (uint32_t)m; }
+  }
+  return (uint32_t)(m >> 32);
+}
+/* _generator.pyx Generator.choice(pop, size, replace=False), pop <= 10000: Floyd's algorithm (the hash set only
+ * answers "was val drawn already") followed by _shuffle_int over the picks. */
+static inline void pcg_choice_noreplace(pcg_t* g, int pop, int size, int* idx) {
+  for (int j = pop - size, k = 0; j < pop; ++j, ++k) {
+    int val = (int)pcg_bounded_lemire32(g, (uint32_t)j), seen = 0;
+    for (int q = 0; q < k; ++q) seen |= (idx[q] == val);
+    idx[k] = seen ? j : val;
+  }
+  for (int i = size - 1; i >= 1; --i) {
+    int j = (int)pcg_bounded_lemire32(g, (uint32_t)i);
+    int t = idx[i]; idx[i] = idx[j]; idx[j] = t;
+  }
+}
+
 #endif  /* SGW_PCG_H_ */
