@@ -6,10 +6,10 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsgw.so")
 
-MAX_CELLS, MAX_K, MAX_M, MAX_AGENTS, N_PARAMS, ENV_ALIGN = 320, 16, 16, 4, 48, 64
-ABI_VERSION = 4
+MAX_CELLS, MAX_K, MAX_M, MAX_AGENTS, N_PARAMS, ENV_ALIGN = 320, 16, 32, 4, 72, 64
+ABI_VERSION = 5
 
-ISLAND_NAVIGATION_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INTERRUPTIBILITY, FIREMAKER_EX_MA, ISLAND_NAVIGATION_EX_MA, TILE_EVENTS, SIDE_EFFECTS_SOKOBAN, CONVEYOR_BELT, TOMATO_WATERING, FRIEND_FOE, WHISKY_GOLD, ROCKS_DIAMONDS = range(13)
+ISLAND_NAVIGATION_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INTERRUPTIBILITY, FIREMAKER_EX_MA, ISLAND_NAVIGATION_EX_MA, TILE_EVENTS, SIDE_EFFECTS_SOKOBAN, CONVEYOR_BELT, TOMATO_WATERING, FRIEND_FOE, WHISKY_GOLD, ROCKS_DIAMONDS, AINTELOPE_SAVANNA = range(14)
 FIRST, MID, LAST, DEAD = 0, 1, 2, 3
 TERM_NONE = 255
 
@@ -75,6 +75,8 @@ def lib():
   L.sgw_set_episode_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
   L.sgw_set_rng_state.argtypes = [C.c_void_p, C.c_void_p]
   L.sgw_set_random_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
+  L.sgw_set_family_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+  L.sgw_pow_f64.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
   L.sgw_reset.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Out), C.c_void_p]
   L.sgw_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Out), C.c_void_p]
   L.sgw_step_n.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Out), C.c_int, C.c_void_p]
@@ -106,7 +108,7 @@ def lib():
 EXPORTS = [
     "sgw_abi_version", "sgw_last_error", "sgw_sizeof_spec", "sgw_sizeof_out", "sgw_create",
     "sgw_destroy", "sgw_n_envs", "sgw_n_pad", "sgw_state_bytes", "sgw_set_episode_bits",
-    "sgw_set_rng_state", "sgw_set_random_stream", "sgw_reset", "sgw_step", "sgw_step_n", "sgw_rollout", "sgw_read_returns", "sgw_fill_actions",
+    "sgw_set_rng_state", "sgw_set_random_stream", "sgw_set_family_table", "sgw_pow_f64", "sgw_reset", "sgw_step", "sgw_step_n", "sgw_rollout", "sgw_read_returns", "sgw_fill_actions",
     "sgw_accumulate_returns", "sgw_observe", "sgw_derived_stats", "sgw_observe_layers", "sgw_view_bytes", "sgw_agent_views", "sgw_agent_layer_views", "sgw_state_words", "sgw_get_state", "sgw_set_state"]
 
 

@@ -17,6 +17,7 @@
 #include "sgw_kernels.hpp"
 #include "sgw_rocks.hpp"
 #include "sgw_safeint.hpp"
+#include "sgw_savanna.hpp"
 #include "sgw_sokoban.hpp"
 #include "sgw_tile.hpp"
 #include "sgw_tomato.hpp"
@@ -54,6 +55,8 @@ struct sgw_engine {
   unsigned long long rand_seed;
   double* acc_dev;         // [n_pad/64][A*K+1] per-wave episodic-return accumulators (lazily allocated)
   int rng_set;
+  double* ftable_dev;      // sgw_set_family_table
+  long long ftable_n;
 };
 
 static int family_words(const sgw_spec& sp) {
@@ -71,6 +74,7 @@ static int family_words(const sgw_spec& sp) {
     case SGW_FRIEND_FOE: return FriendFoe::words();
     case SGW_WHISKY_GOLD: return Whisky::words();
     case SGW_ROCKS_DIAMONDS: return Rocks::words();
+    case SGW_AINTELOPE_SAVANNA: return Savanna::words(sp.K);
     default: return -1;
   }
 }
@@ -114,7 +118,7 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   e->n_envs = n_envs;
   e->n_pad = (n_envs + SGW_ENV_ALIGN - 1) / SGW_ENV_ALIGN * SGW_ENV_ALIGN;
   e->env_id_base = env_id_base;
-  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0; e->rand_stream = nullptr; e->rand_n = 0; e->rand_seed = 0; e->acc_dev = nullptr; e->rng_set = 0;
+  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0; e->rand_stream = nullptr; e->rand_n = 0; e->rand_seed = 0; e->acc_dev = nullptr; e->rng_set = 0; e->ftable_dev = nullptr; e->ftable_n = 0;
 
   KSpec& k = e->ks;
   memset(&k, 0, sizeof(k));
@@ -171,6 +175,7 @@ int sgw_destroy(sgw_engine* e) {
   if (e->tables_dev) (void)hipFree(e->tables_dev);
   if (e->state_dev) (void)hipFree(e->state_dev);
   if (e->acc_dev) (void)hipFree(e->acc_dev);
+  if (e->ftable_dev) (void)hipFree(e->ftable_dev);
   delete e;
   return SGW_OK;
 }
@@ -196,14 +201,38 @@ int sgw_set_random_stream(sgw_engine* e, const double* u_dev, int n_per_env, uin
 
 int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev) {
   if (!e || !pcg_state_dev) return fail(SGW_ERR_ARG, "sgw_set_rng_state: null argument");
-  if (e->spec.family != SGW_FIREMAKER_EX_MA && e->spec.family != SGW_ISLAND_NAVIGATION_EX_MA)
+  if (e->spec.family != SGW_FIREMAKER_EX_MA && e->spec.family != SGW_ISLAND_NAVIGATION_EX_MA &&
+      e->spec.family != SGW_AINTELOPE_SAVANNA)
     return fail(SGW_ERR_UNSUPPORTED, "sgw_set_rng_state: this game family has no env-side RNG stream");
   HIP_TRY(hipSetDevice(e->device));
-  hipLaunchKernelGGL(k_set_rng, dim3((unsigned)((e->n_envs + 255) / 256)), dim3(256), 0, 0, e->state_dev, e->n_pad,
+  hipLaunchKernelGGL(k_set_rng, dim3((unsigned)((e->n_pad + 255) / 256)), dim3(256), 0, 0, e->state_dev, e->n_pad,
                      e->n_envs, pcg_state_dev);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(0));
   e->rng_set = 1;
+  return SGW_OK;
+}
+
+int sgw_set_family_table(sgw_engine* e, const double* table_host, int64_t n) {
+  if (!e || !table_host || n <= 0) return fail(SGW_ERR_ARG, "sgw_set_family_table: null / empty argument");
+  if (e->spec.family != SGW_AINTELOPE_SAVANNA)
+    return fail(SGW_ERR_UNSUPPORTED, "sgw_set_family_table: this game family has no lookup table");
+  if (n != 2 * ((int64_t)e->spec.max_iterations + 2))
+    return fail(SGW_ERR_ARG, "sgw_set_family_table: aintelope_savanna expects 2 * (max_iterations + 2) entries");
+  HIP_TRY(hipSetDevice(e->device));
+  if (e->ftable_dev) { (void)hipFree(e->ftable_dev); e->ftable_dev = nullptr; e->ftable_n = 0; }
+  HIP_TRY(hipMalloc((void**)&e->ftable_dev, (size_t)n * 8));
+  HIP_TRY(hipMemcpy(e->ftable_dev, table_host, (size_t)n * 8, hipMemcpyHostToDevice));
+  e->ftable_n = n;
+  return SGW_OK;
+}
+
+int sgw_pow_f64(const double* x_dev, double y, double* out_dev, int64_t n, int device, void* stream) {
+  if (!x_dev || !out_dev || n < 0) return fail(SGW_ERR_ARG, "sgw_pow_f64: null / negative argument");
+  if (n == 0) return SGW_OK;
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_pow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_dev, y, out_dev, (long long)n);
+  HIP_TRY(hipGetLastError());
   return SGW_OK;
 }
 
@@ -223,8 +252,11 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
       (e->spec.flags & (IslandMa::F_SHUFFLE | (3 << IslandMa::F_MRF_SHIFT))))
     return fail(SGW_ERR_ARG, "island_navigation_ex_ma: call sgw_set_rng_state first (action-order shuffle / map randomisation "
                              "draw from a per-env numpy PCG64 stream)");
+  if (e->spec.family == SGW_AINTELOPE_SAVANNA && (!e->rng_set || !e->ftable_dev))
+    return fail(SGW_ERR_ARG, "aintelope_savanna: call sgw_set_rng_state and sgw_set_family_table first (per-env numpy PCG64 "
+                             "stream; host-evaluated gold / silver visit rewards)");
   HIP_TRY(hipSetDevice(e->device));
-  a.sp = e->ks; a.tables = e->tables_dev; a.state = e->state_dev;
+  a.sp = e->ks; a.tables = e->tables_dev; a.state = e->state_dev; a.ftable = e->ftable_dev;
   a.n_pad = e->n_pad; a.n_envs = e->n_envs; a.env_id_base = e->env_id_base;
   a.ep_bits = e->ep_bits; a.ep_bits_n = e->ep_bits_n; a.ep_seed = e->ep_seed;
   a.rand_stream = e->rand_stream; a.rand_n = e->rand_n; a.rand_seed = e->rand_seed;
@@ -253,6 +285,7 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
     case SGW_FRIEND_FOE: SGW_LAUNCH(FriendFoe); break;
     case SGW_WHISKY_GOLD: SGW_LAUNCH(Whisky); break;
     case SGW_ROCKS_DIAMONDS: SGW_LAUNCH(Rocks); break;
+    case SGW_AINTELOPE_SAVANNA: SGW_LAUNCH(Savanna); break;
     default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
   }
 #undef SGW_LAUNCH
@@ -279,7 +312,7 @@ int sgw_step(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, void*
 
 static void offset_out(sgw_out& o, const sgw_spec& sp, long long n_pad, long long t) {
   const long long HW = sp.H * sp.W, AK = sp.A * sp.K, A = sp.A, M = sp.M, r = t * n_pad;
-  const long long PA = sp.family == SGW_ISLAND_NAVIGATION_EX_MA ? A : 1;   // term_reason / safety are [N_pad, A] there (IslandMa::PER_AGENT)
+  const long long PA = (sp.family == SGW_ISLAND_NAVIGATION_EX_MA || sp.family == SGW_AINTELOPE_SAVANNA) ? A : 1;   // term_reason / safety are [N_pad, A] there (IslandMa::PER_AGENT)
   if (o.board) o.board += r * HW;
   if (o.obs_board) o.obs_board += r * HW;
   if (o.reward) o.reward += r * AK;

@@ -16,7 +16,7 @@
 namespace sgw {
 
 constexpr int WAVE = 64;
-constexpr int TABLE_BYTES = 2048;   // 3*320 level tables + 512 value map + 384 params = 1856, padded to 2 x 16 B per lane
+constexpr int TABLE_BYTES = 2048;   // 3*320 level tables + 512 value map + 72*8 params: exactly 2 x 16 B per lane
 
 // ---- kernel arguments (by value => kernarg segment => scalar loads) -------------------------
 struct KSpec {
@@ -39,6 +39,7 @@ struct KArgs {
   const double* rand_stream; // external in-play random numbers [n, rand_n] (envs that draw from the process-global numpy RNG) or nullptr
   int rand_n;
   unsigned long long rand_seed;
+  const double* ftable;      // family lookup table (sgw_set_family_table) or nullptr
   sgw_out out;
   int mode;                  // 0 = step, 1 = reset(mask)
   int T;                     // rollout length (1 for step)

@@ -8,6 +8,7 @@
 #pragma once
 
 #include "sgw_common.hpp"
+#include "sgw_pow.hpp"
 
 namespace sgw {
 
@@ -319,11 +320,19 @@ __global__ void k_accumulate_returns(const double* cumulative, const uint8_t* st
   if ((threadIdx.x & (WAVE - 1)) == 0 && c != 0.0) atomicAdd(&accum[AK], c);
 }
 
+__global__ void k_pow(const double* x, double y, double* out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = sgw_glibc_pow(x[i], y);
+}
+
 // numpy PCG64 streams into the firemaker state (words 3..6), buffered-uint32 flag (word 0 bit 27) cleared
 __global__ void k_set_rng(uint64_t* state, long long n_pad, long long n, const uint64_t* pcg) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  for (int k = 0; k < 4; ++k) state[(3 + k) * n_pad + e] = pcg[e * 4 + k];
+  if (e >= n_pad) return;
+  // padding lanes run the same code as real envs: give them a working stream too (an all-zero PCG state returns 0 for
+  // ever, and Lemire's rejection loop never leaves on a constant 0)
+  const uint64_t pad[4] = {0x9E3779B97F4A7C15ull, (uint64_t)e, 0ull, 1ull};
+  for (int k = 0; k < 4; ++k) state[(3 + k) * n_pad + e] = e < n ? pcg[e * 4 + k] : pad[k];
   state[0 * n_pad + e] &= ~(1ull << 27);
   state[2 * n_pad + e] &= ~0xffffffffull;
 }

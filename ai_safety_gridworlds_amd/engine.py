@@ -60,6 +60,10 @@ class BatchedEngine(object):
     self._out = N.Out()
     self._alloc_outputs(1)
     self._keep = []          # tensors the library holds raw pointers to
+    table = getattr(spec, "family_table", None)
+    if table is not None:    # aintelope_savanna: host-evaluated visit-count rewards (sgw_set_family_table)
+      table = np.ascontiguousarray(table, dtype=np.float64)
+      N.check(self._lib.sgw_set_family_table(self._h, table.ctypes.data, table.size), "sgw_set_family_table")
 
   # -- buffers ----------------------------------------------------------------------------------
   def _alloc_outputs(self, T):

@@ -31,12 +31,12 @@
 extern "C" {
 #endif
 
-#define SGW_ABI_VERSION 4
+#define SGW_ABI_VERSION 5
 #define SGW_MAX_CELLS 320      /* >= 17*17 */
 #define SGW_MAX_K 16           /* reward dimensions per agent */
-#define SGW_MAX_M 16           /* metrics per env */
+#define SGW_MAX_M 32           /* metrics per env */
 #define SGW_MAX_AGENTS 4
-#define SGW_N_PARAMS 48
+#define SGW_N_PARAMS 72
 #define SGW_ENV_ALIGN 64       /* per-env output buffers must hold round_up(N, 64) envs */
 
 enum sgw_family {
@@ -52,7 +52,8 @@ enum sgw_family {
   SGW_TOMATO_WATERING = 9,         /* environments/tomato_watering.py */
   SGW_FRIEND_FOE = 10,             /* environments/friend_foe.py */
   SGW_WHISKY_GOLD = 11,            /* environments/whisky_gold.py */
-  SGW_ROCKS_DIAMONDS = 12          /* environments/rocks_diamonds.py */
+  SGW_ROCKS_DIAMONDS = 12,         /* environments/rocks_diamonds.py */
+  SGW_AINTELOPE_SAVANNA = 13       /* environments/aintelope/aintelope_savanna.py (one or two agents; per-agent outputs are [N, 2]) */
 };
 
 enum sgw_step_type { SGW_FIRST = 0, SGW_MID = 1, SGW_LAST = 2, SGW_DEAD = 3 }; /* rl/environment{,_ma}.py */
@@ -143,10 +144,22 @@ int sgw_set_episode_bits(sgw_engine* e, const uint8_t* bits_dev, int n_per_env, 
 int sgw_set_random_stream(sgw_engine* e, const double* u_dev, int n_per_env, uint64_t seed);
 
 /* Env-owned numpy Generators (environment_data[NP_RANDOM] = seeding.np_random(seed), safety_game_mo.py:283-291): firemaker_ex_ma
- * (fire spread, agent order) and island_navigation_ex_ma (agent order, map randomisation).  pcg_state_dev is uint64 [N, 4] =
+ * (fire spread, agent order), island_navigation_ex_ma (agent order, map randomisation) and aintelope_savanna (map generation,
+ * agent order, predators, tile spawning; also Generator.choice / integers: Lemire bounded draws and Floyd's sampler).  pcg_state_dev is uint64 [N, 4] =
  * numpy PCG64 (state_hi, state_lo, inc_hi, inc_lo) per env, as produced by np.random.PCG64(SeedSequence(seed)).  The engine
  * advances the streams exactly like numpy (random(), buffered next_uint32, shuffle, random_interval). */
 int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev);
+
+/* Family lookup table in device memory, copied from the host: aintelope_savanna's visit-count rewards
+ * [gold_reward[0 .. max_iterations + 1], silver_reward[0 .. max_iterations + 1]], entry v = SCORE * (log(v + 2, base) -
+ * log(v + 1, base)) evaluated by the caller with the reference's own math.log (aintelope_savanna.py:956-983), so the
+ * device adds the reference's doubles instead of re-deriving logarithms.  Required before the first reset of that family. */
+int sgw_set_family_table(sgw_engine* e, const double* table_host, int64_t n);
+
+/* out[i] = pow(x[i], y) exactly as the engine's regrowth computes it: the host C library's (glibc) pow algorithm and tables,
+ * i.e. the arithmetic of the reference's math.pow (island_navigation_ex.py:603-636, aintelope_savanna.py:1251-1254).
+ * x finite, positive, normal; device pointers.  Exposed so that callers and tests can check the device against their libm. */
+int sgw_pow_f64(const double* x_dev, double y, double* out_dev, int64_t n, int device, void* stream);
 
 /* Start a new episode in every env with mask_dev[n] != 0 (NULL = all) and emit the FIRST
  * timestep into `out` for those envs (other rows of `out` are left untouched). */
