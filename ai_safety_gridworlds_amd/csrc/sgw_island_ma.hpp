@@ -34,6 +34,7 @@
 #pragma once
 
 #include "sgw_common.hpp"
+#include "sgw_pow.hpp"
 
 namespace sgw {
 
@@ -328,7 +329,7 @@ struct IslandMa {
       const bool k = (pend & 1) == 0;                          // false: drink, true: food
       const double base = (k ? (s.f_avail + s.f_frac) : (s.d_avail + s.d_frac)) + 1.0;
       const double lim = k ? p[P_F_GROWTH_LIMIT] : p[P_D_GROWTH_LIMIT];
-      const double x = fmin(lim, pow(base, e));
+      const double x = fmin(lim, sgw_glibc_pow(base, e));      // math.pow == libm pow (sgw_pow.hpp)
       const double fl = (double)(long long)x;
       const double frc = x - fl;
       s.f_avail = k ? fl : s.f_avail; s.f_frac = k ? frc : s.f_frac;

@@ -42,7 +42,9 @@ SGW_POW_FN unsigned long long sgw_pow_asu(double x) {
 #endif
 }
 
-SGW_POW_FN double sgw_glibc_pow(double x, double y) {
+// `log_tab` / `exp_tab`: SGW_POW_LOG_TAB / SGW_POW_EXP_TAB or a copy of them (a kernel may stage the 5 KB in LDS: the two
+// lookups are data-dependent per lane, and an LDS read costs a fraction of an L2 round trip)
+SGW_POW_FN double sgw_glibc_pow_t(double x, double y, const unsigned long long* log_tab, const unsigned long long* exp_tab) {
   const unsigned long long OFF = 0x3fe6955500000000ULL;
   const unsigned long long* LH = SGW_POW_LOG_HEAD;
   const unsigned long long* EH = SGW_POW_EXP_HEAD;
@@ -53,8 +55,8 @@ SGW_POW_FN double sgw_glibc_pow(double x, double y) {
   const int k = (int)((long long)tmp >> 52);
   const unsigned long long iz = ix - (tmp & (0xfffULL << 52));
   const double z = sgw_pow_asd(iz), kd = (double)k;
-  const double invc = sgw_pow_asd(SGW_POW_LOG_TAB[3 * i]), logc = sgw_pow_asd(SGW_POW_LOG_TAB[3 * i + 1]),
-               logctail = sgw_pow_asd(SGW_POW_LOG_TAB[3 * i + 2]);
+  const double invc = sgw_pow_asd(log_tab[3 * i]), logc = sgw_pow_asd(log_tab[3 * i + 1]),
+               logctail = sgw_pow_asd(log_tab[3 * i + 2]);
   const double ln2hi = sgw_pow_asd(LH[0]), ln2lo = sgw_pow_asd(LH[1]);
   const double A0 = sgw_pow_asd(LH[2]), A1 = sgw_pow_asd(LH[3]), A2 = sgw_pow_asd(LH[4]), A3 = sgw_pow_asd(LH[5]),
                A4 = sgw_pow_asd(LH[6]), A5 = sgw_pow_asd(LH[7]), A6 = sgw_pow_asd(LH[8]);
@@ -84,10 +86,11 @@ SGW_POW_FN double sgw_glibc_pow(double x, double y) {
   rr += elo;
   const unsigned long long idx = 2 * (ki & 127);
   const unsigned long long top = ki << (52 - 7);
-  const double tl = sgw_pow_asd(SGW_POW_EXP_TAB[idx]);
-  const unsigned long long sbits = SGW_POW_EXP_TAB[idx + 1] + top;
+  const double tl = sgw_pow_asd(exp_tab[idx]);
+  const unsigned long long sbits = exp_tab[idx + 1] + top;
   const double r2 = rr * rr;
   const double tm = fma(r2 * r2, fma(rr, C5, C4), fma(r2, fma(rr, C3, C2), tl + rr));
   const double scale = sgw_pow_asd(sbits);
   return fma(scale, tm, scale);
 }
+SGW_POW_FN double sgw_glibc_pow(double x, double y) { return sgw_glibc_pow_t(x, y, SGW_POW_LOG_TAB, SGW_POW_EXP_TAB); }
