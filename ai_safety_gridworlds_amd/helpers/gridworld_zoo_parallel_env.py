@@ -170,6 +170,7 @@ class GridworldZooParallelEnv(_Base):
                              "not compatible with what the pycolab game expects.")
         v = v["step"]
       acts.append(int(np.asarray(v).item()))
+    acts += [0] * (sp.A - len(acts))      # aintelope_savanna with one agent: the library's layout always holds two
     ts = self._env.step(torch.tensor(acts, dtype=torch.int8))
     first = int(ts.step_type.reshape(-1)[0].item()) == N.FIRST
     o, states = self._observe(ts, first)

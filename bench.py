@@ -98,6 +98,12 @@ WORKLOADS = {
     "friend_foe": dict(kwargs={}, envs=65536, b_step=193, b_fused=49, outputs=("board", "reward", "step_type", "term_reason", "hidden")),
     "whisky_gold": dict(kwargs=dict(human_player=True), envs=65536, b_step=131, b_fused=67,
                         outputs=("board", "reward", "step_type", "term_reason", "hidden")),
+    # one env-step = one ROUND of two agents on the 13x13 savanna; 68 of the 84 state words move per step (the cached
+    # initial layers only when an episode begins): 2 + 2*544 + 169 + 2*11*8 + 2 + 2 + 8
+    "aintelope_savanna": dict(kwargs=dict(amount_agents=2, amount_predators=2, amount_water_tiles=3, amount_gold_deposits=2,
+                                          amount_silver_deposits=2, amount_small_food_patches=2, amount_drink_holes=2,
+                                          amount_small_drink_holes=1, sustainability_challenge=True, penalise_oversatiation=True),
+                              envs=65536, b_step=1447, b_fused=357, outputs=("board", "reward", "step_type", "term_reason", "safety")),
 }
 MIXED = ("island_navigation_ex", "boat_race_ex", "safe_interruptibility")    # BASELINE.json configs[4]
 
@@ -248,6 +254,8 @@ def main():
             "conveyor_belt": "conveyor_belt sushi_goal", "rocks_diamonds": "rocks_diamonds level 0",
             "tomato_watering": "tomato_watering (Philox drying draws)", "friend_foe": "friend_foe (Philox bandit draws)",
             "whisky_gold": "whisky_gold, human_player (Philox exploration draws)",
+            "aintelope_savanna": "aintelope_savanna level 0, 2 agents, predators / water / gold / silver / small tiles, sustainability "
+                                 "challenge (one env-step = one round)",
             "mixed": "mixed suite island_navigation_ex + boat_race_ex + safe_interruptibility on 3 streams"}[a.workload]
     line = {
         "metric": "env-steps/sec (whole node), 65 536 batched envs per GPU",

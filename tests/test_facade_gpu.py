@@ -76,7 +76,7 @@ def test_vector_env_and_factory():
   obs, r, term, trunc, info = v.step(torch.zeros(1000, dtype=torch.int8, device="cuda:0"))
   assert r.shape == (1000, 10) and term.dtype == torch.bool and not trunc.any()
   with pytest.raises(NotImplementedError):
-    factory.get_environment_obj("aintelope_savanna")
+    factory.get_environment_obj("no_such_environment")
   assert factory.get_environment_obj("whisky_gold").action_spec() == (1, 4)
   e = factory.get_environment_obj("boat_race_ex", level=3)
   assert e.action_spec() == (0, 4)
@@ -158,6 +158,40 @@ def test_island_ma_through_the_zoo_parallel_facade():
       if n in obs:
         assert np.array_equal(obs[n][0], np.vectorize(chr)(fx["view"][e, t + 2, i]))
   assert saw_shrink
+
+
+@pytest.mark.parametrize("fixture", ["sav_rich2_sust", "sav_rich1_prop"])
+def test_savanna_through_the_zoo_parallel_facade(fixture):
+  """aintelope_savanna (two agents / one agent) via the Zoo parallel API, replaying a reference fixture stream: boards
+  with spawning tiles and walking predators, rotated agent views, per-agent reward vectors, all agents LAST together."""
+  from ai_safety_gridworlds_amd.helpers.gridworld_zoo_parallel_env import GridworldZooParallelEnv
+  fx, meta = G.load(fixture)
+  e = 3
+  env = GridworldZooParallelEnv("aintelope_savanna", seed=int(fx["seeds"][e]), **meta["kwargs"])
+  A = meta["kwargs"].get("amount_agents", 1)
+  assert env.possible_agents == ["agent_0", "agent_1"][:A]
+  obs, infos = env.reset()
+  obs, infos = env.reset()
+  assert np.array_equal(env.state[0], np.vectorize(chr)(fx["board"][e, 1]))
+  lasts = 0
+  for t in range(fx["actions"].shape[1]):
+    a = fx["actions"][e, t]
+    if a[0] == -128:
+      obs, infos = env.reset()
+    else:
+      obs, rewards, terms, truncs, infos = env.step({n: int(a[i]) for i, n in enumerate(env.possible_agents)})
+      st = fx["step_type"][e, t + 2]
+      for i, n in enumerate(env.possible_agents):
+        if n in terms:
+          assert terms[n] == (st[i] in (2, 3))
+          lasts += bool(terms[n])
+        if n in rewards and st[0] != 0 and fx["reward_present"][e, t + 2, i]:
+          assert np.array_equal(rewards[n], fx["reward"][e, t + 2, i])
+    assert np.array_equal(env.state[0], np.vectorize(chr)(fx["board"][e, t + 2]))
+    for i, n in enumerate(env.possible_agents):
+      if n in obs:
+        assert np.array_equal(obs[n][0], np.vectorize(chr)(fx["view"][e, t + 2, i]))
+  assert lasts >= A
 
 
 def test_step_logger_reproduces_the_reference_csv(tmp_path):

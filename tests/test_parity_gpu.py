@@ -152,6 +152,10 @@ def _fresh(spec, n, outs):
     ("tomato_watering", {}), ("tomato_crmdp", {}), ("friend_foe", {}), ("whisky_gold", dict(human_player=True)),
     ("conveyor_belt_ex", dict(variant="vase")), ("safe_interruptibility_ex", {}),
     ("island_navigation_ex_ma", dict(map_randomization_frequency=3, max_iterations=30)),
+    ("aintelope_savanna", dict(amount_agents=2, amount_predators=2, amount_water_tiles=3, amount_gold_deposits=2,
+                               amount_silver_deposits=2, amount_small_food_patches=2, amount_drink_holes=2,
+                               amount_small_drink_holes=1, sustainability_challenge=True, penalise_oversatiation=True,
+                               max_iterations=40)),
 ])
 def test_fused_rollout_equals_step_loop(env_name, kw):
   """sgw_rollout (state in registers, in-kernel Philox) == T x sgw_step fed the same stream."""

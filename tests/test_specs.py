@@ -90,6 +90,24 @@ def test_spec_errors_mirror_the_reference():
   assert set(environment_names()) >= {"island_navigation_ex", "boat_race_ex", "boat_race", "safe_interruptibility"}
 
 
+def test_savanna_spec_mirrors_the_reference_constructor():
+  from tests import golden_util as G
+  for name in G.fixture_names(["sav_"]):
+    fx, meta = G.load(name)
+    sp = make_spec("aintelope_savanna", **meta["kwargs"])
+    assert sp.dim_names == meta["dim_names"] and sp.metric_names == meta["metric_labels"], name
+    assert (sp.H, sp.W) == fx["board"].shape[2:]
+  with pytest.raises(NotImplementedError, match="NameError"):       # safety_game_moma.py:1636
+    make_spec("aintelope_savanna", thirst_hunger_death=True)
+  with pytest.raises(RuntimeError, match="ObservationToArray"):     # fixed level-0 map holds '1' but one agent has no value for it
+    make_spec("aintelope_savanna", map_randomization_frequency=0)
+  with pytest.raises(ValueError, match="is not enabled"):           # drink / gold / ... tiles stay on a fixed map while their amount is 0
+    make_spec("aintelope_savanna", amount_agents=2, map_randomization_frequency=0)
+  t = make_spec("aintelope_savanna", amount_gold_deposits=1, max_iterations=10).family_table
+  import math
+  assert len(t) == 24 and t[0] == 40 * (math.log(2, 1.5) - math.log(1, 1.5)) and t[12 + 3] == 30 * (math.log(5, 1.5) - math.log(4, 1.5))
+
+
 def test_shard_ranges_partition_the_env_ids():
   for n, w in [(65536, 8), (262144, 8), (10, 3), (7, 8)]:
     spans = [parallel.shard_range(n, r, w) for r in range(w)]

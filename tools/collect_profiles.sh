@@ -16,7 +16,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- $B > $OUT/pmc_sq.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- $B > $OUT/pmc_sq2.log 2>&1 || exit 1
-for wl in boat_race_ex safe_interruptibility boat_race firemaker_ex_ma island_navigation_ex_ma mixed island_navigation distributional_shift absent_supervisor side_effects_sokoban conveyor_belt rocks_diamonds tomato_watering friend_foe whisky_gold; do
+for wl in boat_race_ex safe_interruptibility boat_race firemaker_ex_ma island_navigation_ex_ma mixed island_navigation distributional_shift absent_supervisor side_effects_sokoban conveyor_belt rocks_diamonds tomato_watering friend_foe whisky_gold aintelope_savanna; do
   python3 $R/bench.py --workload $wl --steps 1000 --warmup 100 --no-cpu-baseline > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err || exit 1
 done
 for n in 131072 262144 1048576; do
