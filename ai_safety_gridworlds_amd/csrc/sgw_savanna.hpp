@@ -78,7 +78,7 @@ struct Savanna {
   static constexpr bool COOPERATIVE = false;
   static constexpr bool PER_AGENT = true;
   struct Ctx {};
-  static __device__ void init_ctx(Ctx&, const Lds&) {}
+  static __device__ __forceinline__ void init_ctx(Ctx&, const Lds&) {}
 
   enum { COOP, DRINK, DRINK_DEF, DRINK_OVER, FINAL, FOOD, FOOD_DEF, FOOD_OVER, GOLD, INJURY, MOVEMENT, SILVER, DEATH };
   enum { F_SUSTAIN = 1, F_OVERSAT = 4, F_PROP = 8, F_SHUFFLE = 16, F_ADIR = 32, F_ODIR = 64, F_TWO = 128, F_MRF_SHIFT = 8,
@@ -116,10 +116,10 @@ struct Savanna {
 
   static constexpr int W_STATIC = 19, W_DYN = 31, W_CUM = 46;
   static __host__ __device__ int words(int K) { return W_CUM + 2 * K + 16; }
-  static __device__ int w_init(const KSpec& sp) { return W_CUM + 2 * sp.K; }
-  static __device__ int slot(const KSpec& sp, int u) { return sp.dim_slot[u / NUA][u % NUA]; }
+  static __device__ __forceinline__ int w_init(const KSpec& sp) { return W_CUM + 2 * sp.K; }
+  static __device__ __forceinline__ int slot(const KSpec& sp, int u) { return sp.dim_slot[u / NUA][u % NUA]; }
 
-  static __device__ void load(State& s, const KArgs& a, long long env) {
+  static __device__ __forceinline__ void load(State& s, const KArgs& a, long long env) {
     Cursor c(a, env);
     const uint64_t w0 = c.get(), w1 = c.get(), w2 = c.get();
     s.frame = (int)(w0 & 0xffff);
@@ -152,7 +152,7 @@ struct Savanna {
     for (int u = 0; u < NU; ++u) s.cum[u] = c.getf_if(slot(a.sp, u) >= 0, a.state + env, 0.0);   // slots ascend with u
   }
 
-  static __device__ void store(const State& s, const KArgs& a, long long env) {
+  static __device__ __forceinline__ void store(const State& s, const KArgs& a, long long env) {
     const uint64_t w0 = (uint64_t)(s.frame & 0xffff) | ((uint64_t)(s.ast & 7) << 16) | ((uint64_t)(s.acted[0] & 1) << 26) |
                         ((uint64_t)(s.rng_has32 & 1) << 27) | ((uint64_t)(s.adir[0] & 3) << 28) | ((uint64_t)(s.adir[1] & 3) << 30) |
                         ((uint64_t)(s.step_type & 0xf) << 32) | ((uint64_t)(s.term & 0xf) << 36) | ((uint64_t)(s.odir[0] & 3) << 40) |
@@ -231,7 +231,7 @@ struct Savanna {
     for (int i = size - 1; i >= 1; --i) lemire(s, (uint32_t)i);
     return ch;
   }
-  static __device__ B3 valid_mask(int HW) {
+  static __device__ __forceinline__ B3 valid_mask(int HW) {
     B3 v;
     v.a = HW >= 64 ? ~0ull : ((1ull << HW) - 1ull);
     v.b = HW >= 128 ? ~0ull : (HW > 64 ? ((1ull << (HW - 64)) - 1ull) : 0ull);
@@ -239,7 +239,7 @@ struct Savanna {
     return v;
   }
 
-  static __device__ void pre_autoreset(State& s, const KArgs& a) {   // the all-LAST round still shuffles its (discarded) actions
+  static __device__ __forceinline__ void pre_autoreset(State& s, const KArgs& a) {   // the all-LAST round still shuffles its (discarded) actions
     if ((a.sp.flags & F_SHUFFLE) && (a.sp.flags & F_TWO) && s.step_type == ST_LAST) interval(s, 1);
   }
 
@@ -408,14 +408,14 @@ struct Savanna {
   }
 
   // MA:566-606 (mode-1 tables), Directions L=0 R=1 U=2 D=3, Actions NOOP=0 L=1 R=2 U=3 D=4
-  static __device__ int rotate_dir(int action, int cur) {
+  static __device__ __forceinline__ int rotate_dir(int action, int cur) {
     const int back = cur ^ 1;
     const int left = cur == D_UP ? D_LEFT : (cur == D_DOWN ? D_RIGHT : (cur == D_LEFT ? D_DOWN : D_UP));
     const int right = left ^ 1;
     return action == 3 ? cur : (action == 4 ? back : (action == 1 ? left : (action == 2 ? right : cur)));
   }
 
-  static __device__ int min_distance(const B3& m, int row, int col, int W) {
+  static __device__ __forceinline__ int min_distance(const B3& m, int row, int col, int W) {
     int best = 99;
 #pragma unroll
     for (int wi = 0; wi < 3; ++wi) {
@@ -431,7 +431,7 @@ struct Savanna {
   }
 
   // shared consume step of SV:872-954 for the acting agent
-  static __device__ void consume(double& avail, double& sat, double& r_own, double& r_other_coop, bool on, bool two, bool oversat,
+  static __device__ __forceinline__ void consume(double& avail, double& sat, double& r_own, double& r_other_coop, bool on, bool two, bool oversat,
                                  double score, double rate, double over_limit, double coop) {
     const bool has = on && avail > 0.0;
     r_own += has ? score : 0.0;
@@ -572,7 +572,7 @@ struct Savanna {
 
   // rendered board: seven bit planes of the top character of every cell (z-order W P D F d f G S, agents on top), four
   // cells per dword
-  static __device__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds& l, int i) {
+  static __device__ __forceinline__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds& l, int i) {
     const int wi = i >> 4, sh = (i & 15) * 4;
     const uint64_t wall = b3_word(s.wall, wi), wW = b3_word(s.water, wi), wP = b3_word(s.dyn[L_P], wi), wD = b3_word(s.dyn[L_D], wi),
                    wF = b3_word(s.dyn[L_F], wi), wd = b3_word(s.dyn[L_SD], wi), wf = b3_word(s.dyn[L_SF], wi),
@@ -607,9 +607,9 @@ struct Savanna {
     }
     return v;
   }
-  static __device__ const uint8_t* board_layers(const State&, const KSpec&, const Lds& l, int (&)[2], uint8_t (&)[2]) { return l.static_board; }
+  static __device__ __forceinline__ const uint8_t* board_layers(const State&, const KSpec&, const Lds& l, int (&)[2], uint8_t (&)[2]) { return l.static_board; }
 
-  static __device__ double metric(const State& s, int id) {
+  static __device__ __forceinline__ double metric(const State& s, int id) {
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     if (id >= 26) return nan;
     const int ag = id >= 13 ? 1 : 0, m = id - 13 * ag;
@@ -632,16 +632,16 @@ struct Savanna {
     }
     return is_vis ? (v > 0u ? (double)v : nan) : f;
   }
-  static __device__ double hidden(const State&) { return 0.0; }
-  static __device__ int safety(const State&) { return 0; }
-  static __device__ int actual(const State&, int) { return -1; }
-  static __device__ void agent_pos(const State& s, int ag, int& r, int& c) { r = s.row[ag]; c = s.col[ag]; }
-  static __device__ int agent_flags(const State& s, int ag) { return (s.adir[ag] << 1) | (s.odir[ag] << 3); }
-  static __device__ int agent_step_type(const State& s, int) { return s.step_type == ST_NONE ? (int)ST_NONE : s.ast; }
-  static __device__ int agent_term(const State& s, int) {
+  static __device__ __forceinline__ double hidden(const State&) { return 0.0; }
+  static __device__ __forceinline__ int safety(const State&) { return 0; }
+  static __device__ __forceinline__ int actual(const State&, int) { return -1; }
+  static __device__ __forceinline__ void agent_pos(const State& s, int ag, int& r, int& c) { r = s.row[ag]; c = s.col[ag]; }
+  static __device__ __forceinline__ int agent_flags(const State& s, int ag) { return (s.adir[ag] << 1) | (s.odir[ag] << 3); }
+  static __device__ __forceinline__ int agent_step_type(const State& s, int) { return s.step_type == ST_NONE ? (int)ST_NONE : s.ast; }
+  static __device__ __forceinline__ int agent_term(const State& s, int) {
     return (s.step_type != ST_NONE && s.ast >= AST_LAST) ? (int)SGW_MAX_STEPS : (int)SGW_TERM_NONE;
   }
-  static __device__ int agent_safety(const State& s, int ag, const KSpec&) { return s.saf[ag]; }
+  static __device__ __forceinline__ int agent_safety(const State& s, int ag, const KSpec&) { return s.saf[ag]; }
 };
 
 }  // namespace sgw
