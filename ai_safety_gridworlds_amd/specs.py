@@ -1255,6 +1255,47 @@ _BUILDERS = {
 }
 
 
+# ---- experiment presets (reference ai_safety_gridworlds/experiments/**: subclasses that only override flags) ------------
+# experiment_presets.json is data recorded from the reference's init_experiment_flags() (tests/golden/make_experiment_presets.py).
+def _load_presets():
+  import json, os
+  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiment_presets.json")
+  with open(path) as f:
+    raw = json.load(f)
+  def value(v):
+    return dict(v["__mo_reward__"]) if isinstance(v, dict) and "__mo_reward__" in v else v
+  return {name: (p["base"], p["package"], {k: value(v) for k, v in p["flags"].items()}) for name, p in raw.items()}
+
+
+EXPERIMENT_PRESETS = _load_presets()
+
+
+def _preset_builder(base, flags):
+  def build(kwargs):
+    merged = dict(flags)
+    merged.update(kwargs)                      # explicit keyword arguments override the preset (override_flags semantics)
+    sp = _BUILDERS[base](merged)
+    return sp
+  return build
+
+
+def _register_aliases():
+  """helpers/factory.py:148-170 registers every class under its module name, `<parent dir>.<module>`,
+  `<dirs below the package>.<module>` and `<package>.<dirs>.<module>`."""
+  pkg = "ai_safety_gridworlds"
+  for name in list(_BUILDERS):
+    d = "environments.aintelope" if name == "aintelope_savanna" else "environments"
+    for alias in (d.split(".")[-1] + "." + name, d + "." + name, pkg + "." + d + "." + name):
+      _BUILDERS.setdefault(alias, _BUILDERS[name])
+  for name, (base, package, flags) in EXPERIMENT_PRESETS.items():
+    b = _preset_builder(base, flags)
+    for alias in (name, package.split(".")[-1] + "." + name, package + "." + name, pkg + "." + package + "." + name):
+      _BUILDERS.setdefault(alias, b)
+
+
+_register_aliases()
+
+
 def environment_names():
   return sorted(_BUILDERS)
 

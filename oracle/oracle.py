@@ -115,6 +115,14 @@ def make_config(family, **kw):
         v = list(v.values())[0]
     if fid == CONVEYOR and k == "variant" and isinstance(v, str):
       v = CONVEYOR_VARIANTS.index(v)
+    if k == "gap_reward" and isinstance(v, dict):     # island: {DRINK_REWARD: x, FOOD_REWARD: y, ...} -> gap_reward_<dim>
+      for dim, val in v.items():
+        setattr(cfg, "gap_reward_" + dim.lower().replace("_reward", ""), float(val))
+      continue
+    if isinstance(v, dict) and k in names:            # a mo_reward flag {its own dimension: value}
+      if len(v) != 1:
+        raise ValueError("flag %r: the oracle keeps each event on its own dimension" % k)
+      (v,) = v.values()
     if fid == SOKOBAN and "sk_" + k in names:       # movement_reward / coin_reward / ... (side_effects_sokoban.py:318-325)
       k = "sk_" + k
     if k not in names:

@@ -70,6 +70,10 @@ def make_config(**kw):
       for dim, val in v.items():
         setattr(cfg, "gap_score_" + dim.lower(), float(val))
       continue
+    if isinstance(v, dict):                       # a mo_reward flag given as {dimension: value}: one dimension per flag
+      if len(v) != 1:
+        raise ValueError("flag %r: the oracle keeps each event on its own dimension" % k)
+      (v,) = v.values()
     if k == "observation_radius" and not isinstance(v, int):
       if len(set(v)) != 1:
         raise ValueError("the oracle covers square views")

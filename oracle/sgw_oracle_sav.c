@@ -619,15 +619,22 @@ or_sav_env* or_sav_create(const or_sav_config* cfg, const uint64_t rng_state[4],
   const uint8_t* L = e->level_art;
   int D = map_contains(L, n, 'D') && cfg->amount_drink_holes > 0, d = map_contains(L, n, 'd') && cfg->amount_small_drink_holes > 0;
   int F = map_contains(L, n, 'F') && cfg->amount_food_patches > 0, f = map_contains(L, n, 'f') && cfg->amount_small_food_patches > 0;
-  e->enabled[U_MOVEMENT] = 1;
-  e->enabled[U_FINAL] = map_contains(L, n, 'U');
-  e->enabled[U_DRINK_DEF] = D || d; e->enabled[U_DRINK_OVER] = (D || d) && cfg->penalise_oversatiation; e->enabled[U_DRINK] = D || d;
-  e->enabled[U_FOOD_DEF] = F || f; e->enabled[U_FOOD_OVER] = (F || f) && cfg->penalise_oversatiation; e->enabled[U_FOOD] = F || f;
-  e->enabled[U_GOLD] = map_contains(L, n, 'G') && cfg->amount_gold_deposits > 0;
-  e->enabled[U_SILVER] = map_contains(L, n, 'S') && cfg->amount_silver_deposits > 0;
-  e->enabled[U_INJURY] = (map_contains(L, n, 'W') && cfg->amount_water_tiles > 0) || (map_contains(L, n, 'P') && cfg->amount_predators > 0);
-  e->enabled[U_COOP] = cfg->amount_agents > 1 && (cfg->amount_food_patches > 0 || cfg->amount_drink_holes > 0 ||
-                                                  cfg->amount_small_food_patches > 0 || cfg->amount_small_drink_holes > 0);
+  /* a dimension is enabled when an enabled flag has a NON-ZERO unit on it (mo_reward.py:131-135 drops zero units) */
+  e->enabled[U_MOVEMENT] = cfg->movement_score != 0;
+  e->enabled[U_FINAL] = map_contains(L, n, 'U') && cfg->final_score != 0;
+  e->enabled[U_DRINK_DEF] = (D || d) && cfg->drink_deficiency_score != 0;
+  e->enabled[U_DRINK_OVER] = (D || d) && cfg->penalise_oversatiation && cfg->drink_oversatiation_score != 0;
+  e->enabled[U_DRINK] = (D && cfg->drink_score != 0) || (d && cfg->small_drink_score != 0);
+  e->enabled[U_FOOD_DEF] = (F || f) && cfg->food_deficiency_score != 0;
+  e->enabled[U_FOOD_OVER] = (F || f) && cfg->penalise_oversatiation && cfg->food_oversatiation_score != 0;
+  e->enabled[U_FOOD] = (F && cfg->food_score != 0) || (f && cfg->small_food_score != 0);
+  e->enabled[U_GOLD] = map_contains(L, n, 'G') && cfg->amount_gold_deposits > 0 && cfg->gold_score != 0;
+  e->enabled[U_SILVER] = map_contains(L, n, 'S') && cfg->amount_silver_deposits > 0 && cfg->silver_score != 0;
+  e->enabled[U_INJURY] = (map_contains(L, n, 'W') && cfg->amount_water_tiles > 0 && cfg->danger_tile_score != 0) ||
+                         (map_contains(L, n, 'P') && cfg->amount_predators > 0 && cfg->predator_npc_score != 0);
+  e->enabled[U_COOP] = cfg->amount_agents > 1 &&
+                       (((cfg->amount_food_patches > 0 || cfg->amount_drink_holes > 0) && cfg->cooperation_score != 0) ||
+                        ((cfg->amount_small_food_patches > 0 || cfg->amount_small_drink_holes > 0) && cfg->small_cooperation_score != 0));
   for (int k = 0; k < SV_NU; ++k) e->K += e->enabled[k];
   e->episode_no = 1;
   return e;

@@ -55,6 +55,10 @@ CONFIGS = {
     # a "lazy" stream (mostly NOOP) exercises regrowth/pow and max_iterations
     "island_L9_lazy": ("island_ex", dict(level=9), 64, 300, 0, 5),
     "island_L6_lazy": ("island_ex", dict(level=6), 64, 300, 0, 5),
+    # experiments/ presets (flag overrides only); the tests take the flag values from experiment_presets.json
+    "island_exp_bounded_gold_silver": ("island_ex", dict(experiment="food_drink_bounded_gold_silver"), 48, 200, 0, 5),
+    "island_exp_bounded_death_gold": ("island_ex", dict(experiment="food_drink_bounded_death_gold"), 48, 200, 0, 5),
+    "island_exp_food_bounded": ("island_ex", dict(experiment="food_bounded"), 32, 150, 0, 5),
     # BASELINE.json configs[2]
     "boat_ex_L3": ("boat_race_ex", dict(level=3), 256, 200, 0, 5),
     "boat_ex_L2": ("boat_race_ex", dict(level=2), 64, 200, 0, 5),
@@ -127,6 +131,12 @@ def _lazy_actions(np, philox, seed, env_ids, steps, lo, n):
 
 
 def make_env(family, kw):
+  if family == "island_ex" and "experiment" in kw:      # an experiments/ preset: the subclass that only overrides flags
+    import importlib
+    from ai_safety_gridworlds.environments import island_navigation_ex as m
+    kw = dict(kw)
+    x = importlib.import_module("ai_safety_gridworlds.experiments." + kw.pop("experiment"))
+    return x.IslandNavigationEnvironmentExExperiment(**kw), m
   if family == "island_ex":
     from ai_safety_gridworlds.environments import island_navigation_ex as m
     args = dict(ISLAND_FLAG_DEFAULTS)

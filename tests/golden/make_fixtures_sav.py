@@ -44,6 +44,10 @@ CONFIGS = {
                               penalise_oversatiation=True, use_satiation_proportional_reward=True,
                               action_direction_mode=0, observation_direction_mode=0, max_iterations=60,
                               observation_radius=R2), 8, 80, ()),
+    # experiments/aintelope presets (flag overrides only); the tests take the flag values from experiment_presets.json
+    "sav_exp_predators_gold_silver": (dict(experiment="food_drink_homeostasis_predators_gold_silver", max_iterations=60), 12, 120, (45,)),
+    "sav_exp_demo": (dict(experiment="savanna_demo", max_iterations=80), 12, 110, (50, 51)),
+    "sav_exp_sharing": (dict(experiment="food_sharing", max_iterations=60), 8, 90, ()),
     "sav_L3_tiny": (dict(level=3, amount_food_patches=1, sustainability_challenge=True, penalise_oversatiation=True,
                          max_iterations=30, observation_radius=R2), 8, 70, (20,)),
     "sav_L14_metric_only": (dict(level=14, amount_agents=2, amount_food_patches=1, amount_drink_holes=1,
@@ -82,9 +86,18 @@ def main():
   for name in only:
     kw, E, T, reset_ticks = CONFIGS[name]
     S = T + 2
-    A = kw.get('amount_agents', 1)
+    ctor = m.AIntelopeSavannaEnvironmentMa
+    ctor_kw = dict(kw)
+    eff = dict(kw)
+    if "experiment" in kw:
+      import importlib
+      x = importlib.import_module("ai_safety_gridworlds.experiments.aintelope." + ctor_kw.pop("experiment"))
+      ctor = x.AIntelopeSavannaEnvironmentMaExperiment
+      f = x.init_experiment_flags()
+      eff = dict(amount_agents=f.amount_agents, observation_radius=f.observation_radius); eff.update(kw)
+    A = eff.get('amount_agents', 1)
     AGENTS = ['0', '1'][:A]
-    VS = 2 * kw.get('observation_radius', [10])[0] + 1
+    VS = 2 * eff.get('observation_radius', [10])[0] + 1
     acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(2)], axis=-1)  # [T,E,2]
     acts = np.transpose(acts, (1, 0, 2)).astype(np.int8).copy()     # [E, T, A]
     for t in reset_ticks:
@@ -96,11 +109,11 @@ def main():
     # The very first construction of the class in a process re-seeds environment_data[NP_RANDOM] AFTER the constructor's
     # reset drew the map (class attribute env_layout_seed still -1, safety_game_moma.py:353-390); every later one does
     # not.  A batch has no "first": the streams are recorded as later constructions.
-    m.AIntelopeSavannaEnvironmentMa(seed=1, **kw)
+    ctor(seed=1, **ctor_kw)
     for e in range(E):
       seed = 2000 + e
       seeded = seeding.np_random(seed)[0].bit_generator.state
-      env = m.AIntelopeSavannaEnvironmentMa(seed=seed, **kw)
+      env = ctor(seed=seed, **ctor_kw)
       art0 = env.environment_data['ascii_art']
       H, W = len(art0), len(art0[0])
       if rec is None:

@@ -24,6 +24,13 @@ def load(name):
   meta = {k[5:]: (fx[k].item() if fx[k].ndim == 0 else fx[k]) for k in fx.files if k.startswith("meta_")}
   meta["family_name"] = FAMILY_NAMES.get(meta["family"], meta["family"])
   meta["kwargs"] = dict(ast.literal_eval(meta["kwargs"]))
+  if "experiment" in meta["kwargs"]:      # an experiments/ preset: the flag values come from the package's preset table,
+    from ai_safety_gridworlds_amd.specs import EXPERIMENT_PRESETS   # so the fixture (made by the reference's subclass) pins them
+    kw = dict(meta["kwargs"])
+    meta["experiment"] = kw.pop("experiment")
+    merged = dict(EXPERIMENT_PRESETS[meta["experiment"]][2])
+    merged.update(kw)
+    meta["kwargs"] = merged
   meta["dim_names"] = [s for s in meta.get("dim_names", "").split("|") if s]
   meta["metric_labels"] = [s for s in meta.get("metric_labels", "").split("|") if s]
   return fx, meta

@@ -114,3 +114,29 @@ def test_shard_ranges_partition_the_env_ids():
     assert spans[0][0] == 0 and spans[-1][1] == n
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def test_experiment_presets_and_factory_aliases():
+  """helpers/factory.py:148-170 name forms; experiments/** presets = base env + recorded flag overrides
+  (tests/golden/make_experiment_presets.py).  Four island presets put one event's reward on several dimensions, which the
+  island kernel does not implement."""
+  from ai_safety_gridworlds_amd.specs import EXPERIMENT_PRESETS
+  assert len(EXPERIMENT_PRESETS) == 24
+  refused = []
+  for name, (base, package, flags) in EXPERIMENT_PRESETS.items():
+    try:
+      sp = make_spec(name)
+    except NotImplementedError:
+      refused.append(name)
+      continue
+    assert sp.name == base
+    assert make_spec(package + "." + name).native.params[:] == sp.native.params[:]
+    assert make_spec("ai_safety_gridworlds." + package + "." + name, max_iterations=7).max_iterations == 7   # kwargs override the preset
+  assert sorted(refused) == ["food_drink_rolf", "food_drink_rolf_gold_as_gap", "food_drink_rolf_gold_as_resource",
+                             "food_drink_rolf_gold_as_resource_scaled"]
+  assert make_spec("environments.boat_race_ex").name == "boat_race_ex"
+  assert make_spec("aintelope.aintelope_savanna").name == "aintelope_savanna"
+  assert make_spec("ai_safety_gridworlds.environments.aintelope.aintelope_savanna").name == "aintelope_savanna"
+  sd = make_spec("savanna_demo")
+  assert sd.n_agents == 2 and sd.view_shapes[0] == (9, 9) and sd.max_iterations == 100
+
