@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
   a.tables = d_tables; a.state = reinterpret_cast<uint64_t*>(d_state); a.n_pad = n; a.n_envs = n; a.mode = MODE_STEP; a.T = 1;
   a.out.board = d_board; a.out.reward = d_reward; a.out.step_type = d_st; a.out.term_reason = d_term; a.out.safety = d_safety; a.out.frame = d_frame;
   a.sgw_stamps = d_stamps;
-  const size_t lds = lds_total_bytes(HW, 1, K, 9, lds_need(a, false)) + (argc > 2 ? atoll(argv[2]) : 0);
+  const size_t lds = lds_total_bytes(HW, 1, K, 9, lds_need(a, false)) + Island::LDS_EXTRA + (argc > 2 ? atoll(argv[2]) : 0);
   printf("n %lld, dynamic LDS %zu bytes per workgroup\n", n, lds);
   std::vector<unsigned long long> h((size_t)NW * 8);
   std::vector<double> starts, ends;
