@@ -267,6 +267,11 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
   do {                                                                                                 \
     lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, lds_need(a, F::LDS_SCRATCH_M)) + F::LDS_EXTRA; \
     const dim3 block(F::WAVES * WAVE);                                                                 \
+    if (lds_bytes > 65536) {   /* above the default dynamic-LDS cap (aintelope_savanna with every output staged) */ \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, K_STEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, K_ROLLOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, K_RESET>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+    }                                                                                                  \
     if (kind == K_STEP) hipLaunchKernelGGL((k_engine<F, K_STEP>), grid, block, lds_bytes, st, a);   \
     else if (kind == K_ROLLOUT) hipLaunchKernelGGL((k_engine<F, K_ROLLOUT>), grid, block, lds_bytes, st, a); \
     else hipLaunchKernelGGL((k_engine<F, K_RESET>), grid, block, lds_bytes, st, a);                 \

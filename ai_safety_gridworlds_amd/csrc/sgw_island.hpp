@@ -194,8 +194,7 @@ struct Island {
 #ifdef SGW_EXP_NOPOW   // diagnostic probe only: how much of `play` is the regrowth pow?
       const double x = fmin(lim, base * e);
 #else
-      const double x = fmin(lim, sgw_glibc_pow_t(base, e, reinterpret_cast<const unsigned long long*>(l.extra),
-                                                  reinterpret_cast<const unsigned long long*>(l.extra) + 128 * 3));   // math.pow == libm pow (sgw_pow.hpp)
+      const double x = fmin(lim, sgw_glibc_pow_lds(base, e, l.extra));   // math.pow == libm pow (sgw_pow.hpp)
 #endif
       const double fl = (double)(long long)x;                  // int()
       const double fr = x - fl;
@@ -213,18 +212,10 @@ struct Island {
   static constexpr bool PER_AGENT = false;
   static __device__ int slot(const KSpec& sp, int u) { return sp.dim_slot[0][u]; }
   static constexpr bool LDS_SCRATCH_M = false;   // borrows the metrics staging rows as per-lane scratch
-  static constexpr int WAVES = 1, LDS_EXTRA = (128 * 3 + 256) * 8;   // the pow tables (sgw_pow.hpp), staged when regrowth is on
+  static constexpr int WAVES = 1, LDS_EXTRA = SGW_POW_LDS_BYTES;   // the pow tables (sgw_pow.hpp)
   static constexpr bool COOPERATIVE = false;
   struct Ctx {};
-  // 5 KB of pow tables -> LDS, five 16-byte loads per lane issued behind the state loads (same memory round trip)
-  static __device__ void init_ctx(Ctx&, const Lds& l) {
-    uint4* dst = reinterpret_cast<uint4*>(l.extra);
-    const uint4* lg = reinterpret_cast<const uint4*>(SGW_POW_LOG_TAB);
-    const uint4* ex = reinterpret_cast<const uint4*>(SGW_POW_EXP_TAB);
-    const int lane = threadIdx.x;
-    const uint4 t0 = lg[lane], t1 = lg[lane + 64], t2 = lg[lane + 128], t3 = ex[lane], t4 = ex[lane + 64];
-    dst[lane] = t0; dst[lane + 64] = t1; dst[lane + 128] = t2; dst[lane + 192] = t3; dst[lane + 256] = t4;
-  }
+  static __device__ void init_ctx(Ctx&, const Lds& l) { sgw_pow_stage_lds(l.extra); }   // behind the state loads: same memory round trip
   static __device__ void pre_autoreset(State&, const KArgs&) {}
   static __device__ uint32_t board_dword(const State&, const KSpec&, const Lds&, int) { return 0; }
   static __device__ int actual(const State& s, int) { return s.actual; }

@@ -94,3 +94,23 @@ SGW_POW_FN double sgw_glibc_pow_t(double x, double y, const unsigned long long* 
   return fma(scale, tm, scale);
 }
 SGW_POW_FN double sgw_glibc_pow(double x, double y) { return sgw_glibc_pow_t(x, y, SGW_POW_LOG_TAB, SGW_POW_EXP_TAB); }
+
+#if defined(__HIPCC__)
+// One wave copies both tables (3 KB + 2 KB) into `lds` (16-byte aligned): five 16-byte loads per lane, all L2 hits.  Every
+// lane of the wave must call it (k_engine's init_ctx is such a place); the reader passes `lds` and `lds + 128 * 3` to
+// sgw_glibc_pow_t.
+constexpr int SGW_POW_LDS_BYTES = (128 * 3 + 256) * 8;
+__device__ inline void sgw_pow_stage_lds(void* lds) {
+  uint4* dst = reinterpret_cast<uint4*>(lds);
+  const uint4* lg = reinterpret_cast<const uint4*>(SGW_POW_LOG_TAB);
+  const uint4* ex = reinterpret_cast<const uint4*>(SGW_POW_EXP_TAB);
+  const int lane = threadIdx.x & 63;
+  const uint4 t0 = lg[lane], t1 = lg[lane + 64], t2 = lg[lane + 128], t3 = ex[lane], t4 = ex[lane + 64];
+  dst[lane] = t0; dst[lane + 64] = t1; dst[lane + 128] = t2; dst[lane + 192] = t3; dst[lane + 256] = t4;
+}
+__device__ inline double sgw_glibc_pow_lds(double x, double y, const void* lds) {
+  const unsigned long long* t = reinterpret_cast<const unsigned long long*>(lds);
+  return sgw_glibc_pow_t(x, y, t, t + 128 * 3);
+}
+#endif
+
