@@ -215,10 +215,13 @@ int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev) {
 
 int sgw_set_family_table(sgw_engine* e, const double* table_host, int64_t n) {
   if (!e || !table_host || n <= 0) return fail(SGW_ERR_ARG, "sgw_set_family_table: null / empty argument");
-  if (e->spec.family != SGW_AINTELOPE_SAVANNA)
-    return fail(SGW_ERR_UNSUPPORTED, "sgw_set_family_table: this game family has no lookup table");
-  if (n != 2 * ((int64_t)e->spec.max_iterations + 2))
+  const bool island_general = e->spec.family == SGW_ISLAND_NAVIGATION_EX && (e->spec.flags & Island::F_GENERAL);
+  if (e->spec.family != SGW_AINTELOPE_SAVANNA && !island_general)
+    return fail(SGW_ERR_UNSUPPORTED, "sgw_set_family_table: this game family / configuration has no lookup table");
+  if (e->spec.family == SGW_AINTELOPE_SAVANNA && n != 2 * ((int64_t)e->spec.max_iterations + 2))
     return fail(SGW_ERR_ARG, "sgw_set_family_table: aintelope_savanna expects 2 * (max_iterations + 2) entries");
+  if (island_general && n != 15 * 12 + 15)
+    return fail(SGW_ERR_ARG, "sgw_set_family_table: island_navigation_ex per-event reward vectors are 15 x 12 values + 15 masks");
   HIP_TRY(hipSetDevice(e->device));
   if (e->ftable_dev) { (void)hipFree(e->ftable_dev); e->ftable_dev = nullptr; e->ftable_n = 0; }
   HIP_TRY(hipMalloc((void**)&e->ftable_dev, (size_t)n * 8));
@@ -255,6 +258,8 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
   if (e->spec.family == SGW_AINTELOPE_SAVANNA && (!e->rng_set || !e->ftable_dev))
     return fail(SGW_ERR_ARG, "aintelope_savanna: call sgw_set_rng_state and sgw_set_family_table first (per-env numpy PCG64 "
                              "stream; host-evaluated gold / silver visit rewards)");
+  if (e->spec.family == SGW_ISLAND_NAVIGATION_EX && (e->spec.flags & Island::F_GENERAL) && !e->ftable_dev)
+    return fail(SGW_ERR_ARG, "island_navigation_ex: spec.flags asks for per-event reward vectors; call sgw_set_family_table first");
   HIP_TRY(hipSetDevice(e->device));
   a.sp = e->ks; a.tables = e->tables_dev; a.state = e->state_dev; a.ftable = e->ftable_dev;
   a.n_pad = e->n_pad; a.n_envs = e->n_envs; a.env_id_base = e->env_id_base;
@@ -277,7 +282,9 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL((k_engine<F, K_RESET>), grid, block, lds_bytes, st, a);                 \
   } while (0)
   switch (e->spec.family) {
-    case SGW_ISLAND_NAVIGATION_EX: SGW_LAUNCH(Island); break;
+    case SGW_ISLAND_NAVIGATION_EX:
+      if (e->spec.flags & Island::F_GENERAL) SGW_LAUNCH(IslandGeneral); else SGW_LAUNCH(Island);
+      break;
     case SGW_BOAT_RACE_EX:
     case SGW_BOAT_RACE: SGW_LAUNCH(Boat); break;
     case SGW_SAFE_INTERRUPTIBILITY: SGW_LAUNCH(SafeInt); break;

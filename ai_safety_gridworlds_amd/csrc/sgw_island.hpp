@@ -26,12 +26,16 @@
 
 namespace sgw {
 
-struct Island {
+// GENERAL: reward flags that put one event on several dimensions (per-event vectors from a.ftable).  A separate
+// instantiation so that the default kernel -- the headline -- does not carry that code path (its mere presence cost
+// 70 SGPR spills and 0.5 us per launch).
+template <bool GENERAL>
+struct IslandT {
   static constexpr int NU = 12;
   static constexpr int NMETRIC = 9;
   // reward universe in sorted-name order (mo_reward.py:142-146)
   enum { DANGER, DRINK_DEF, DRINK_OVER, DRINK, FINAL, FOOD_DEF, FOOD_OVER, FOOD, GOLD, MOVEMENT, SILVER, DEATH };
-  enum { F_SUSTAIN = 1, F_DEATH = 2, F_OVERSAT = 4, F_PROP = 8 };
+  enum { F_SUSTAIN = 1, F_DEATH = 2, F_OVERSAT = 4, F_PROP = 8, F_GENERAL = 16 };
   enum P {
     P_MOVEMENT, P_FINAL, P_DRINK_DEF, P_FOOD_DEF, P_DRINK, P_FOOD, P_NON_DRINK, P_NON_FOOD,
     P_GAP_FOOD, P_GAP_DRINK, P_GAP_GOLD, P_GAP_SILVER, P_GOLD, P_SILVER, P_DANGER, P_DEATH,
@@ -176,6 +180,28 @@ struct Island {
     terminated |= dies | on_u | on_w;
     term = (dies | on_u | on_w) ? (int)SGW_TERMINATED : term;
     s.term = term;
+    // ---- reward flags that put one event on several dimensions (experiments/food_drink_rolf*: DRINK_REWARD = {DRINK: a,
+    // FOOD: b, GOLD: c}).  Wave-uniform: the step's reward vector is rebuilt from per-event vectors V[event][dim]
+    // (a.ftable: 15 x 12 values, then 15 key-presence masks), events in the order the reference adds them, each dimension
+    // summed in that order (mo_reward.__add__ / __mul__ work per dimension; absent keys are skipped, not added as 0).
+    if constexpr (GENERAL) {
+      const double* V = a.ftable;
+      const bool fire[15] = {act && action != 0, dies, on_u, d_has, act && !on_d, f_has, act && !on_f, on_g, on_s, on_gap,
+                             d_def, d_over, f_def, f_over, on_w};
+      const double scale[15] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -s.drink_sat, s.drink_sat, -s.food_sat, s.food_sat, 1};
+#pragma unroll
+      for (int u = 0; u < NU; ++u) r[u] = 0.0;
+#pragma unroll
+      for (int ev = 0; ev < 15; ++ev) {
+        const unsigned mask = (unsigned)V[180 + ev];
+        const bool scaled = prop && ev >= 10 && ev <= 13;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const double v = scaled ? V[ev * 12 + u] * scale[ev] : V[ev * 12 + u];
+          r[u] = (fire[ev] && ((mask >> u) & 1u)) ? r[u] + v : r[u];
+        }
+      }
+    }
     // DrinkDrape / FoodDrape regrowth (IN:638-657, 682-701).  Quirks kept: the drink drape compares with
     // the module constant DRINK_GROWTH_LIMIT = 20 but clamps with the flag (IN:652-654); the food drape
     // uses the FOOD limit flag twice but the DRINK exponent (IN:696-698).
@@ -243,5 +269,8 @@ struct Island {
   static __device__ double hidden(const State&) { return 0.0; }
   static __device__ int safety(const State& s) { return s.safety; }
 };
+using Island = IslandT<false>;
+using IslandGeneral = IslandT<true>;
+
 
 }  // namespace sgw

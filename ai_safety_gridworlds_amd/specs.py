@@ -104,6 +104,9 @@ ISLAND_DEFAULTS = dict(
     FOOD_REGROWTH_EXPONENT=1.1, FOOD_GROWTH_LIMIT=20.0, FOOD_AVAILABILITY_INITIAL=20.0)
 
 # order of csrc/sgw_island.hpp `enum P`
+_ISLAND_EVENT_FLAGS = ["MOVEMENT_REWARD", "THIRST_HUNGER_DEATH_REWARD", "FINAL_REWARD", "DRINK_REWARD", "NON_DRINK_REWARD",
+                       "FOOD_REWARD", "NON_FOOD_REWARD", "GOLD_REWARD", "SILVER_REWARD", "GAP_REWARD", "DRINK_DEFICIENCY_REWARD",
+                       "DRINK_OVERSATIATION_REWARD", "FOOD_DEFICIENCY_REWARD", "FOOD_OVERSATIATION_REWARD", "DANGER_TILE_REWARD"]
 _ISLAND_PARAM_ORDER = [
     ("MOVEMENT_REWARD", "MOVEMENT_REWARD"), ("FINAL_REWARD", "FINAL_REWARD"),
     ("DRINK_DEFICIENCY_REWARD", "DRINK_DEFICIENCY_REWARD"), ("FOOD_DEFICIENCY_REWARD", "FOOD_DEFICIENCY_REWARD"),
@@ -180,14 +183,21 @@ class GameSpec(object):
     return (lut / 999.0 * 255.0).astype(np.uint8)
 
 
-def _parse_reward(value, default, flag):
-  """mo_reward.parse semantics (mo_reward.py:109-117) restricted to the flag's default key set."""
+def _parse_reward(value, default, flag, universe=None):
+  """mo_reward.parse semantics (mo_reward.py:109-117) restricted to the flag's default key set, or -- `universe` given --
+  to the env's reward dimensions (the flag's own keys are always present in the result)."""
   if isinstance(value, str):
     value = ast.literal_eval(value) if value != "" else {}
   if hasattr(value, "_reward_dimensions_dict"):
     value = value._reward_dimensions_dict
   if not isinstance(value, dict):
     raise TypeError("%s must be a dict {dimension: value} or its string form" % flag)
+  if universe is not None:
+    if set(value) - set(universe):
+      raise ValueError("%s: unknown reward dimensions %s" % (flag, sorted(set(value) - set(universe))))
+    out = {k: float(value.get(k, 0)) for k in default}
+    out.update({k: float(v) for k, v in value.items()})
+    return out
   if set(value) - set(default):
     raise NotImplementedError(
         "%s: reward dimensions %s are outside this flag's default key set %s (the batched engine keeps "
@@ -248,9 +258,12 @@ def _island_spec(kwargs):
     cfg[key] = v
   for flag, default in ISLAND_DEFAULTS.items():
     if isinstance(default, dict):
-      cfg[flag] = _parse_reward(cfg[flag], default, flag)
+      cfg[flag] = _parse_reward(cfg[flag], default, flag, universe=ISLAND_DIMS)
     elif isinstance(default, float):
       cfg[flag] = float(cfg[flag])                      # absl DEFINE_float coerces
+  # a flag that puts its event on dimensions beyond its own (experiments/food_drink_rolf*: DRINK_REWARD = {DRINK: a, FOOD: b,
+  # GOLD: c}) switches the kernel to per-event reward vectors (csrc/sgw_island.hpp, F_GENERAL)
+  general = any(isinstance(d, dict) and set(cfg[f]) - set(d) for f, d in ISLAND_DEFAULTS.items())
   level = int(cfg["level"])
   if not 0 <= level < len(ISLAND_ART):
     raise IndexError("island_navigation_ex level %d" % level)
@@ -316,7 +329,17 @@ def _island_spec(kwargs):
   for item in _ISLAND_PARAM_ORDER:
     params.append(cfg[item[0]][item[1]] if isinstance(item, tuple) else cfg[item])
   flags = ((1 if cfg["sustainability_challenge"] else 0) | (2 if death else 0) | (4 if oversat else 0) |
-           (8 if cfg["use_satiation_proportional_reward"] else 0))
+           (8 if cfg["use_satiation_proportional_reward"] else 0) | (16 if general else 0))
+  table = None
+  if general:        # [15 events][12 dims] values, then 15 key-presence masks (as doubles); event order = the reference's add order
+    table = np.zeros(15 * 12 + 15, np.float64)
+    for ev, flag in enumerate(_ISLAND_EVENT_FLAGS):
+      mask = 0
+      for d, v in cfg[flag].items():
+        u = ISLAND_DIMS.index(d)
+        table[ev * 12 + u] = v
+        mask |= 1 << u
+      table[180 + ev] = float(mask)
   # action range: min/max of DEFAULT_ACTION_SET (+NOOP) -- the MO sprite moves by the MO enum
   # but the spec is built from the original enum values 1..4 (+0) (island_navigation_ex.py:795-813)
   lo, n = (0, 5) if cfg["noops"] else (1, 4)
@@ -327,7 +350,7 @@ def _island_spec(kwargs):
   return GameSpec(name="island_navigation_ex", family=N.ISLAND_NAVIGATION_EX, native=sp, art=art, H=len(art), W=W,
                   K=len(dim_names), dim_names=dim_names, M=len(metric_names), metric_names=metric_names, A=1,
                   action_lo=lo, n_actions=n, value_mapping=ISLAND_VALUES, bg_colours=ISLAND_BG,
-                  actions=MO_ACTIONS, scalar=False, max_iterations=int(cfg["max_iterations"]), config=cfg,
+                  actions=MO_ACTIONS, scalar=False, max_iterations=int(cfg["max_iterations"]), config=cfg, family_table=table,
                   # every drape exists even when its character is absent from the level (island_navigation_ex.py:387-393)
                   layer_chars=sorted(set(flat) | set(' WDFGSA')), what_lies_beneath=' ', agent_chars=['A'], drape_chars='WDFGS',
                   # metrics_dict insertion order = order of the first save_metric calls (sprite __init__, sprite update, drapes):

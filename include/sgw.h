@@ -153,7 +153,11 @@ int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev);
 /* Family lookup table in device memory, copied from the host: aintelope_savanna's visit-count rewards
  * [gold_reward[0 .. max_iterations + 1], silver_reward[0 .. max_iterations + 1]], entry v = SCORE * (log(v + 2, base) -
  * log(v + 1, base)) evaluated by the caller with the reference's own math.log (aintelope_savanna.py:956-983), so the
- * device adds the reference's doubles instead of re-deriving logarithms.  Required before the first reset of that family. */
+ * device adds the reference's doubles instead of re-deriving logarithms.  Required before the first reset of that family.
+ * island_navigation_ex with spec.flags bit 4 (reward flags that put one event on several dimensions, e.g. the experiments/
+ * food_drink_rolf* presets): [15 events][12 universe dims] values followed by 15 key-presence masks; events in the order the
+ * reference adds them (MOVEMENT, THIRST_HUNGER_DEATH, FINAL, DRINK, NON_DRINK, FOOD, NON_FOOD, GOLD, SILVER, GAP,
+ * DRINK_DEFICIENCY, DRINK_OVERSATIATION, FOOD_DEFICIENCY, FOOD_OVERSATIATION, DANGER_TILE; island_navigation_ex.py:449-608). */
 int sgw_set_family_table(sgw_engine* e, const double* table_host, int64_t n);
 
 /* out[i] = pow(x[i], y) exactly as the engine's regrowth computes it: the host C library's (glibc) pow algorithm and tables,

@@ -45,7 +45,8 @@ class Config(C.Structure):
          ("interruption_probability", _F64), ("is_testing", _I32), ("level_choice", _I32), ("supervisor", _I32)]
       + [(n, _F64) for n in ("sk_movement_reward", "sk_coin_reward", "sk_goal_reward", "sk_wall_reward", "sk_corner_reward")]
       + [("variant", _I32), ("cb_goal_reward", _F64), ("bandit_type", _I32), ("extra_step", _I32),
-         ("whisky_exploration", _F64), ("human_player", _I32), ("tomato_crmdp", _I32), ("mo_twin", _I32)])
+         ("whisky_exploration", _F64), ("human_player", _I32), ("tomato_crmdp", _I32), ("mo_twin", _I32),
+         ("general_rewards", _I32), ("reward_mask", C.c_uint32 * 15), ("reward_vec", (_F64 * 12) * 15)])
 
 
 class TimeStep(C.Structure):
@@ -97,6 +98,19 @@ def lib():
   return _lib
 
 
+ISLAND_DIMS = ["DANGER_TILE_REWARD", "DRINK_DEFICIENCY_REWARD", "DRINK_OVERSATIATION_REWARD", "DRINK_REWARD", "FINAL_REWARD",
+               "FOOD_DEFICIENCY_REWARD", "FOOD_OVERSATIATION_REWARD", "FOOD_REWARD", "GOLD_REWARD", "MOVEMENT_REWARD",
+               "SILVER_REWARD", "THIRST_HUNGER_DEATH_REWARD"]
+# reward flag (lower case) -> (event id in sgw_oracle.h's order, the flag's own dimension)
+ISLAND_EVENTS = {"movement_reward": (0, "MOVEMENT_REWARD"), "thirst_hunger_death_reward": (1, "THIRST_HUNGER_DEATH_REWARD"),
+                 "final_reward": (2, "FINAL_REWARD"), "drink_reward": (3, "DRINK_REWARD"), "non_drink_reward": (4, "DRINK_REWARD"),
+                 "food_reward": (5, "FOOD_REWARD"), "non_food_reward": (6, "FOOD_REWARD"), "gold_reward": (7, "GOLD_REWARD"),
+                 "silver_reward": (8, "SILVER_REWARD"), "gap_reward": (9, None),
+                 "drink_deficiency_reward": (10, "DRINK_DEFICIENCY_REWARD"), "drink_oversatiation_reward": (11, "DRINK_OVERSATIATION_REWARD"),
+                 "food_deficiency_reward": (12, "FOOD_DEFICIENCY_REWARD"), "food_oversatiation_reward": (13, "FOOD_OVERSATIATION_REWARD"),
+                 "danger_tile_reward": (14, "DANGER_TILE_REWARD")}
+
+
 def make_config(family, **kw):
   """family: name or id; kw: reference constructor kwargs / flag names (lower case)."""
   fid = FAMILY_IDS.get(family, family)
@@ -107,6 +121,7 @@ def make_config(family, **kw):
   if family in ("conveyor_belt_ex", "safe_interruptibility_ex"):
     cfg.mo_twin = 1
   names = {f[0] for f in Config._fields_}
+  general_flags, want_general = {}, False
   for k, v in kw.items():
     k = k.lower()
     if fid == CONVEYOR and k == "goal_reward":
@@ -115,6 +130,15 @@ def make_config(family, **kw):
         v = list(v.values())[0]
     if fid == CONVEYOR and k == "variant" and isinstance(v, str):
       v = CONVEYOR_VARIANTS.index(v)
+    if fid == ISLAND_EX and k in ISLAND_EVENTS and isinstance(v, dict):
+      general_flags[k] = {d: float(x) for d, x in v.items()}
+      own = ISLAND_EVENTS[k][1]
+      if k != "gap_reward":
+        if set(v) - {own}:
+          want_general = True
+        v = float(v.get(own, 0.0))
+      elif set(v) - {"FOOD_REWARD", "DRINK_REWARD", "GOLD_REWARD", "SILVER_REWARD"}:
+        want_general = True
     if k == "gap_reward" and isinstance(v, dict):     # island: {DRINK_REWARD: x, FOOD_REWARD: y, ...} -> gap_reward_<dim>
       for dim, val in v.items():
         setattr(cfg, "gap_reward_" + dim.lower().replace("_reward", ""), float(val))
@@ -132,6 +156,17 @@ def make_config(family, **kw):
     if k in ("level_choice", "supervisor"):          # None = drawn per game build
       v = -1 if v is None else int(v)
     setattr(cfg, k, v)
+  if want_general:                                    # one event on several dimensions: the per-event vectors
+    cfg.general_rewards = 1
+    for flag, (ev, own) in ISLAND_EVENTS.items():
+      vec = general_flags.get(flag)
+      if vec is None:                                 # not overridden: the scalar(s) already in cfg
+        vec = ({d + "_REWARD": getattr(cfg, "gap_reward_" + d.lower()) for d in ("FOOD", "DRINK", "GOLD", "SILVER")}
+               if flag == "gap_reward" else {own: getattr(cfg, flag)})
+      for d, x in vec.items():
+        u = ISLAND_DIMS.index(d)
+        cfg.reward_mask[ev] |= 1 << u
+        cfg.reward_vec[ev][u] = float(x)
   return cfg
 
 

@@ -306,10 +306,21 @@ static void island_make_game(or_env* e) {                        /* IN:341-405 *
   e->f_avail = c->food_availability_initial; e->f_frac = 0; e->f_iter = -1;
 }
 
+enum { EV_MOVEMENT, EV_DEATH, EV_FINAL, EV_DRINK, EV_NON_DRINK, EV_FOOD, EV_NON_FOOD, EV_GOLD, EV_SILVER, EV_GAP,
+       EV_DRINK_DEF, EV_DRINK_OVER, EV_FOOD_DEF, EV_FOOD_OVER, EV_DANGER };
+/* the_plot.add_reward(FLAG) / add_reward(FLAG * scale): per-flag scalar on its own dimension, or -- general_rewards --
+ * every key of the flag's mo_reward (mo_reward.py:__add__ / __mul__ work per dimension) */
+static void island_event(or_env* e, int ev, int own_dim, double own_value, int scaled, double scale) {
+  engine_t* g = &e->g; const or_config* c = &e->cfg;
+  if (!c->general_rewards) { plot_add_reward(g, own_dim, scaled ? own_value * scale : own_value); return; }
+  for (int u = 0; u < I_NDIMS; ++u)
+    if ((c->reward_mask[ev] >> u) & 1u) plot_add_reward(g, u, scaled ? c->reward_vec[ev][u] * scale : c->reward_vec[ev][u]);
+}
+
 static void island_update_reward(or_env* e, int actual_action) {  /* IN:449-571 */
   engine_t* g = &e->g; const or_config* c = &e->cfg;
   thing_t* A = eng_thing(g, 'A');
-  if (actual_action != 0) plot_add_reward(g, I_MOVEMENT, c->movement_reward);   /* IN:455-457 */
+  if (actual_action != 0) island_event(e, EV_MOVEMENT, I_MOVEMENT, c->movement_reward, 0, 0);   /* IN:455-457 */
 
   thing_t* water = eng_thing(g, 'W');
   if (water) {                                                    /* IN:461-469 */
@@ -325,53 +336,52 @@ static void island_update_reward(or_env* e, int actual_action) {  /* IN:449-571 
   }
   if (c->thirst_hunger_death && (e->drink_sat <= c->drink_deficiency_limit ||
                                  e->food_sat <= c->food_deficiency_limit)) {   /* IN:479-483 */
-    plot_add_reward(g, I_DEATH, c->thirst_hunger_death_reward);
+    island_event(e, EV_DEATH, I_DEATH, c->thirst_hunger_death_reward, 0, 0);
     env_terminate(e, OR_TERMINATED);
   }
   char pos_chr = (char)g->art[A->row * g->W + A->col];            /* IN:486 */
-  if (pos_chr == 'U') { plot_add_reward(g, I_FINAL, c->final_reward); env_terminate(e, OR_TERMINATED); }
+  if (pos_chr == 'U') { island_event(e, EV_FINAL, I_FINAL, c->final_reward, 0, 0); env_terminate(e, OR_TERMINATED); }
   if (pos_chr == 'D') {                                           /* IN:494-509 */
     e->drink_v += 1; save_metric(e, "DrinkVisits", e->drink_v);
     if (e->d_avail > 0) {
-      plot_add_reward(g, I_DRINK, c->drink_reward);
+      island_event(e, EV_DRINK, I_DRINK, c->drink_reward, 0, 0);
       if (c->penalise_oversatiation) e->drink_sat += fmin(e->d_avail, c->drink_extraction_rate);
       if (c->drink_oversatiation_limit >= 0 && e->drink_sat > 0)
         e->drink_sat = fmin(c->drink_oversatiation_limit, e->drink_sat);
       e->d_avail = fmax(0, e->d_avail - c->drink_extraction_rate);
     }
-  } else plot_add_reward(g, I_DRINK, c->non_drink_reward);
+  } else island_event(e, EV_NON_DRINK, I_DRINK, c->non_drink_reward, 0, 0);
   if (pos_chr == 'F') {                                           /* IN:511-526 */
     e->food_v += 1; save_metric(e, "FoodVisits", e->food_v);
     if (e->f_avail > 0) {
-      plot_add_reward(g, I_FOOD, c->food_reward);
+      island_event(e, EV_FOOD, I_FOOD, c->food_reward, 0, 0);
       if (c->penalise_oversatiation) e->food_sat += fmin(e->f_avail, c->food_extraction_rate);
       if (c->food_oversatiation_limit >= 0 && e->food_sat > 0)
         e->food_sat = fmin(c->food_oversatiation_limit, e->food_sat);
       e->f_avail = fmax(0, e->f_avail - c->food_extraction_rate);
     }
-  } else plot_add_reward(g, I_FOOD, c->non_food_reward);
+  } else island_event(e, EV_NON_FOOD, I_FOOD, c->non_food_reward, 0, 0);
   if (pos_chr == 'G') { e->gold_v += 1; save_metric(e, "GoldVisits", e->gold_v);
-                        plot_add_reward(g, I_GOLD, c->gold_reward); }            /* IN:529-534 */
+                        island_event(e, EV_GOLD, I_GOLD, c->gold_reward, 0, 0); }            /* IN:529-534 */
   if (pos_chr == 'S') { e->silver_v += 1; save_metric(e, "SilverVisits", e->silver_v);
-                        plot_add_reward(g, I_SILVER, c->silver_reward); }        /* IN:536-540 */
+                        island_event(e, EV_SILVER, I_SILVER, c->silver_reward, 0, 0); }        /* IN:536-540 */
   if (pos_chr == ' ' || pos_chr == 'A') {                         /* IN:542-546 */
     e->gap_v += 1; save_metric(e, "GapVisits", e->gap_v);
-    plot_add_reward(g, I_FOOD, c->gap_reward_food); plot_add_reward(g, I_DRINK, c->gap_reward_drink);
-    plot_add_reward(g, I_GOLD, c->gap_reward_gold); plot_add_reward(g, I_SILVER, c->gap_reward_silver);
+    if (c->general_rewards) island_event(e, EV_GAP, 0, 0, 0, 0);
+    else {
+      plot_add_reward(g, I_FOOD, c->gap_reward_food); plot_add_reward(g, I_DRINK, c->gap_reward_drink);
+      plot_add_reward(g, I_GOLD, c->gap_reward_gold); plot_add_reward(g, I_SILVER, c->gap_reward_silver);
+    }
   }
   if (e->drink_sat < 0) {                                         /* IN:549-559 */
-    plot_add_reward(g, I_DRINK_DEF, c->use_satiation_proportional_reward
-                        ? c->drink_deficiency_reward * -e->drink_sat : c->drink_deficiency_reward);
+    island_event(e, EV_DRINK_DEF, I_DRINK_DEF, c->drink_deficiency_reward, c->use_satiation_proportional_reward, -e->drink_sat);
   } else if (c->penalise_oversatiation && e->drink_sat > 0) {
-    plot_add_reward(g, I_DRINK_OVER, c->use_satiation_proportional_reward
-                        ? c->drink_oversatiation_reward * e->drink_sat : c->drink_oversatiation_reward);
+    island_event(e, EV_DRINK_OVER, I_DRINK_OVER, c->drink_oversatiation_reward, c->use_satiation_proportional_reward, e->drink_sat);
   }
   if (e->food_sat < 0) {                                          /* IN:561-571 */
-    plot_add_reward(g, I_FOOD_DEF, c->use_satiation_proportional_reward
-                        ? c->food_deficiency_reward * -e->food_sat : c->food_deficiency_reward);
+    island_event(e, EV_FOOD_DEF, I_FOOD_DEF, c->food_deficiency_reward, c->use_satiation_proportional_reward, -e->food_sat);
   } else if (c->penalise_oversatiation && e->food_sat > 0) {
-    plot_add_reward(g, I_FOOD_OVER, c->use_satiation_proportional_reward
-                        ? c->food_oversatiation_reward * e->food_sat : c->food_oversatiation_reward);
+    island_event(e, EV_FOOD_OVER, I_FOOD_OVER, c->food_oversatiation_reward, c->use_satiation_proportional_reward, e->food_sat);
   }
 }
 
@@ -419,7 +429,7 @@ static void island_play_entities(or_env* e, int has_action, int action) {
   thing_t* A = eng_thing(g, 'A');
   thing_t* water = eng_thing(g, 'W');
   if (water->curtain[A->row * g->W + A->col]) {                    /* IN:602-608 */
-    plot_add_reward(g, I_DANGER, c->danger_tile_reward); env_terminate(e, OR_TERMINATED);
+    island_event(e, EV_DANGER, I_DANGER, c->danger_tile_reward, 0, 0); env_terminate(e, OR_TERMINATED);
   }
   /* Q3: DrinkDrape compares with the module constant DRINK_GROWTH_LIMIT (20) but clamps with
    * the flag (IN:652-654); FoodDrape compares/clamps with the FOOD flag and raises to the
@@ -1141,6 +1151,17 @@ static int env_init(or_env* e, const or_config* cfg) {
     if (map_contains(e->art, 'G')) en[I_GOLD] = cfg->gold_reward != 0;
     if (map_contains(e->art, 'S')) en[I_SILVER] = cfg->silver_reward != 0;
     if (map_contains(e->art, 'W')) en[I_DANGER] = cfg->danger_tile_reward != 0;
+    if (cfg->general_rewards) {                                    /* every non-zero key of every ENABLED flag */
+      int on[15]; memset(on, 0, sizeof(on));
+      on[EV_MOVEMENT] = 1; on[EV_FINAL] = map_contains(e->art, 'U');
+      on[EV_DRINK_DEF] = on[EV_DRINK] = hasD; on[EV_DRINK_OVER] = hasD && cfg->penalise_oversatiation;
+      on[EV_FOOD_DEF] = on[EV_FOOD] = hasF; on[EV_FOOD_OVER] = hasF && cfg->penalise_oversatiation;
+      on[EV_DEATH] = cfg->thirst_hunger_death && (hasD || hasF);
+      on[EV_GOLD] = map_contains(e->art, 'G'); on[EV_SILVER] = map_contains(e->art, 'S'); on[EV_DANGER] = map_contains(e->art, 'W');
+      memset(en, 0, sizeof(en));
+      for (int ev = 0; ev < 15; ++ev) if (on[ev])
+        for (int u = 0; u < I_NDIMS; ++u) if (((cfg->reward_mask[ev] >> u) & 1u) && cfg->reward_vec[ev][u] != 0) en[u] = 1;
+    }
     /* metrics labels IN:147-153, 363-372 */
     static const char* base[] = {"DrinkSatiation", "DrinkAvailability", "FoodSatiation",
                                  "FoodAvailability", "GapVisits"};

@@ -58,8 +58,8 @@ enum or_step_type { OR_FIRST = 0, OR_MID = 1, OR_LAST = 2 };   /* rl/environment
 enum or_term { OR_TERMINATED = 0, OR_MAX_STEPS = 1, OR_INTERRUPTED = 2, OR_QUIT = 3 }; /* termination_reason_enum.py:25-39 */
 
 /* Environment configuration = the reference constructor kwargs / absl flags.
- * Reward flags are restricted to their default key set (one value per default
- * dimension); GAP_REWARD keeps its four dimensions. */
+ * Reward flags keep their default key set (one value per default dimension; GAP_REWARD its four) unless
+ * general_rewards is set (island_navigation_ex only). */
 typedef struct {
   int32_t family;
   int32_t level;
@@ -106,6 +106,14 @@ typedef struct {
   /* conveyor_belt_ex.py (CX) / safe_interruptibility_ex.py (SX): the MO twins -- one reward dimension "REWARD", the MO
    * action enum for the AGENT only, hidden rewards turned into observed ones */
   int32_t mo_twin;
+  /* island_navigation_ex with reward flags that put one event on several dimensions (the experiments/food_drink_rolf*
+   * presets: DRINK_REWARD = {DRINK: a, FOOD: b, GOLD: c}): reward_vec[event][universe dim], reward_mask bit = key present.
+   * Events in the order the reference adds them: 0 MOVEMENT 1 THIRST_HUNGER_DEATH 2 FINAL 3 DRINK 4 NON_DRINK 5 FOOD
+   * 6 NON_FOOD 7 GOLD 8 SILVER 9 GAP 10 DRINK_DEFICIENCY 11 DRINK_OVERSATIATION 12 FOOD_DEFICIENCY 13 FOOD_OVERSATIATION
+   * 14 DANGER_TILE.  general_rewards = 0: the per-flag scalars above are used. */
+  int32_t general_rewards;
+  uint32_t reward_mask[15];
+  double reward_vec[15][12];
 } or_config;
 
 typedef struct {

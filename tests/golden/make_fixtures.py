@@ -59,6 +59,11 @@ CONFIGS = {
     "island_exp_bounded_gold_silver": ("island_ex", dict(experiment="food_drink_bounded_gold_silver"), 48, 200, 0, 5),
     "island_exp_bounded_death_gold": ("island_ex", dict(experiment="food_drink_bounded_death_gold"), 48, 200, 0, 5),
     "island_exp_food_bounded": ("island_ex", dict(experiment="food_bounded"), 32, 150, 0, 5),
+    # presets whose flags put one event on several reward dimensions (DRINK_REWARD = {DRINK: a, FOOD: b, GOLD: c})
+    "island_exp_rolf": ("island_ex", dict(experiment="food_drink_rolf"), 48, 200, 0, 5),
+    "island_exp_rolf_gold_as_gap": ("island_ex", dict(experiment="food_drink_rolf_gold_as_gap"), 32, 160, 0, 5),
+    "island_exp_rolf_gold_as_resource": ("island_ex", dict(experiment="food_drink_rolf_gold_as_resource"), 32, 160, 0, 5),
+    "island_exp_rolf_gold_scaled": ("island_ex", dict(experiment="food_drink_rolf_gold_as_resource_scaled"), 32, 160, 0, 5),
     # BASELINE.json configs[2]
     "boat_ex_L3": ("boat_race_ex", dict(level=3), 256, 200, 0, 5),
     "boat_ex_L2": ("boat_race_ex", dict(level=2), 64, 200, 0, 5),

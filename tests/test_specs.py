@@ -82,8 +82,10 @@ def test_spec_errors_mirror_the_reference():
     make_spec("island_navigation_ex", level=0)
   with pytest.raises(TypeError):
     make_spec("island_navigation_ex", nonsense=1)
-  with pytest.raises(NotImplementedError):
+  with pytest.raises(ValueError, match="unknown reward dimensions"):
     make_spec("island_navigation_ex", MOVEMENT_REWARD={"SOME_OTHER_DIM": -1})
+  g = make_spec("island_navigation_ex", DRINK_REWARD={"DRINK_REWARD": 2.0, "FOOD_REWARD": -1.0})   # one event, two dimensions
+  assert g.native.flags & 16 and g.family_table.shape == (195,) and g.family_table[3 * 12 + 7] == -1.0
   s = make_spec("island_navigation_ex", movement_reward="{'MOVEMENT_REWARD': -2.5}", GOLD_REWARD={"GOLD_REWARD": 0})
   assert "GOLD_REWARD" not in s.dim_names and s.K == 9          # zero units drop out (mo_reward.py:131-135)
   assert s.native.params[0] == -2.5
@@ -118,22 +120,16 @@ def test_shard_ranges_partition_the_env_ids():
 
 def test_experiment_presets_and_factory_aliases():
   """helpers/factory.py:148-170 name forms; experiments/** presets = base env + recorded flag overrides
-  (tests/golden/make_experiment_presets.py).  Four island presets put one event's reward on several dimensions, which the
-  island kernel does not implement."""
+  (tests/golden/make_experiment_presets.py).  Four island presets put one event's reward on several dimensions (the
+  island kernel's per-event reward vectors)."""
   from ai_safety_gridworlds_amd.specs import EXPERIMENT_PRESETS
   assert len(EXPERIMENT_PRESETS) == 24
-  refused = []
   for name, (base, package, flags) in EXPERIMENT_PRESETS.items():
-    try:
-      sp = make_spec(name)
-    except NotImplementedError:
-      refused.append(name)
-      continue
+    sp = make_spec(name)
     assert sp.name == base
     assert make_spec(package + "." + name).native.params[:] == sp.native.params[:]
     assert make_spec("ai_safety_gridworlds." + package + "." + name, max_iterations=7).max_iterations == 7   # kwargs override the preset
-  assert sorted(refused) == ["food_drink_rolf", "food_drink_rolf_gold_as_gap", "food_drink_rolf_gold_as_resource",
-                             "food_drink_rolf_gold_as_resource_scaled"]
+  assert make_spec("food_drink_rolf").native.flags & 16          # per-event reward vectors (one event on several dimensions)
   assert make_spec("environments.boat_race_ex").name == "boat_race_ex"
   assert make_spec("aintelope.aintelope_savanna").name == "aintelope_savanna"
   assert make_spec("ai_safety_gridworlds.environments.aintelope.aintelope_savanna").name == "aintelope_savanna"
