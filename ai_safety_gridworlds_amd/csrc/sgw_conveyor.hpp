@@ -132,7 +132,7 @@ struct Conveyor {
   static constexpr bool COOPERATIVE = false;
   struct Ctx {};
   static __device__ void init_ctx(Ctx&, const Lds&) {}
-  static __device__ void pre_autoreset(State&, const KArgs&) {}
+  template <class Acts> static __device__ void pre_autoreset(State&, const KArgs&, const Acts&) {}
   static __device__ uint32_t board_dword(const State&, const KSpec&, const Lds&, int) { return 0; }
   static __device__ const uint8_t* board_layers(const State& s, const KSpec& sp, const Lds& l, int (&cells)[2], uint8_t (&chars)[2]) {
     cells[0] = s.orow * sp.W + s.ocol; chars[0] = s.ended ? (uint8_t)':' : (uint8_t)'O';   // the end drape is painted over the object

@@ -165,7 +165,7 @@ struct Firemaker {
   }
 
   // The step after LAST still shuffles the (discarded) actions before it resets (PM:177-180, 211-221)
-  static __device__ void pre_autoreset(State& s, const KArgs& a) {
+  static __device__ void pre_autoreset(State& s, const KArgs& a, const int (&)[NA]) {
     if ((a.sp.flags & F_SHUFFLE) && s.step_type == ST_LAST) { interval(s, 2); interval(s, 1); }
   }
 

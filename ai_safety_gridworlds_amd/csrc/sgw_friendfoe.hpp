@@ -129,7 +129,7 @@ struct FriendFoe {
   static constexpr bool COOPERATIVE = false;
   struct Ctx {};
   static __device__ void init_ctx(Ctx&, const Lds&) {}
-  static __device__ void pre_autoreset(State&, const KArgs&) {}
+  template <class Acts> static __device__ void pre_autoreset(State&, const KArgs&, const Acts&) {}
   static __device__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds& l, int i) {
     uint32_t v = reinterpret_cast<const uint32_t*>(l.static_board)[i];
     const uint32_t tile = s.bandit == 0 ? 'F' : (s.bandit == 1 ? 'N' : 'B');

@@ -242,7 +242,7 @@ struct IslandT {
   static constexpr bool COOPERATIVE = false;
   struct Ctx {};
   static __device__ void init_ctx(Ctx&, const Lds& l) { sgw_pow_stage_lds(l.extra); }   // behind the state loads: same memory round trip
-  static __device__ void pre_autoreset(State&, const KArgs&) {}
+  template <class Acts> static __device__ void pre_autoreset(State&, const KArgs&, const Acts&) {}
   static __device__ uint32_t board_dword(const State&, const KSpec&, const Lds&, int) { return 0; }
   static __device__ int actual(const State& s, int) { return s.actual; }
   static __device__ void agent_pos(const State& s, int, int& r, int& c) { r = s.row; c = s.col; }

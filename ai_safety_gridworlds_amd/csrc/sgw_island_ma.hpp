@@ -180,8 +180,10 @@ struct IslandMa {
   static __device__ uint64_t pword(const Lds& l, int i) { return (uint64_t)__double_as_longlong(l.params[i]); }
 
   // The step after every agent is done still shuffles the (discarded) actions when both were submitted (all LAST)
-  static __device__ void pre_autoreset(State& s, const KArgs& a) {
-    if ((a.sp.flags & F_SHUFFLE) && s.step_type == ST_LAST && s.ast[0] != AST_DEAD && s.ast[1] != AST_DEAD) interval(s, 1);
+  // (an action < 0 = the agent did not submit one: EnvironmentMa.step with a subset of the agents, the AEC wrapper's way)
+  static __device__ void pre_autoreset(State& s, const KArgs& a, const int (&actions)[2]) {
+    if ((a.sp.flags & F_SHUFFLE) && s.step_type == ST_LAST && s.ast[0] != AST_DEAD && s.ast[1] != AST_DEAD &&
+        actions[0] >= 0 && actions[1] >= 0) interval(s, 1);
   }
 
   // make_game + its_showtime (IM:420-512, MB:949-1120, MM:868-900).  Explicit resets (sgw_reset) advance the episode
@@ -348,12 +350,14 @@ struct IslandMa {
       const double2 v = reinterpret_cast<const double2*>(l.params)[i];
       p[2 * i] = v.x; p[2 * i + 1] = v.y;
     }
-    const bool alive0 = s.ast[0] < AST_LAST, alive1 = s.ast[1] < AST_LAST;       // at least one is (k_engine resets otherwise)
+    // submitted = alive (at least one is: k_engine resets otherwise) and an action >= 0 was given; a round may carry a
+    // subset of the agents (PM:173-246 iterates over the submitted dict), down to none
+    const bool alive0 = s.ast[0] < AST_LAST && actions[0] >= 0, alive1 = s.ast[1] < AST_LAST && actions[1] >= 0;
     int first = alive0 ? 0 : 1;
     const int n = (alive0 ? 1 : 0) + (alive1 ? 1 : 0);
     if (n == 2 && (sp.flags & F_SHUFFLE)) first = interval(s, 1) == 0 ? 1 : 0;     // Generator.shuffle of 2: swap when j == 0
-    double discount = 1.0;
-    discount = play_one(s, first, first == 0 ? actions[0] : actions[1], sp, p, r);
+    double discount = (s.tr[0] != T_UNSET && s.tr[1] != T_UNSET) ? 0.0 : 1.0;      // no play: the last discount stands
+    if (n >= 1) discount = play_one(s, first, first == 0 ? actions[0] : actions[1], sp, p, r);
     if (n == 2) discount = play_one(s, first ^ 1, first == 0 ? actions[1] : actions[0], sp, p, r);
     // per-agent game_over -> StepType (PM:223-233)
     const bool all_over = s.frame >= sp.max_iterations;

@@ -183,18 +183,19 @@ __global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
     double discount = __longlong_as_double(0x7ff8000000000000LL);   // None at FIRST
     bool over_now = false;
     if constexpr (!F::COOPERATIVE) {
+      int action[F::NA];
+#pragma unroll
+      for (int ag = 0; ag < F::NA; ++ag) {
+        if (a.actions) action[ag] = (t == 0) ? action0[ag]
+                                             : (real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0);
+        else action[ag] = synth_action(a.seed, env_id, a.step0 + t, ag, a.sp.action_lo, a.sp.n_actions);
+      }
       if (s.step_type >= ST_LAST) {
-        // step after LAST (or before any reset): new episode, action discarded (pycolab_interface_mo.py:175-178)
-        F::pre_autoreset(s, a);
+        // step after LAST (or before any reset): new episode, action discarded (pycolab_interface_mo.py:175-178); the
+        // multi-agent adapters still shuffle the discarded actions when more than one was submitted
+        F::pre_autoreset(s, a, action);
         F::begin_episode(s, a, l, env, env_id);
       } else {
-        int action[F::NA];
-#pragma unroll
-        for (int ag = 0; ag < F::NA; ++ag) {
-          if (a.actions) action[ag] = (t == 0) ? action0[ag]
-                                               : (real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0);
-          else action[ag] = synth_action(a.seed, env_id, a.step0 + t, ag, a.sp.action_lo, a.sp.n_actions);
-        }
         discount = F::play(s, action, a, l, r, env);
         const bool over = (discount == 0.0) || (s.frame >= a.sp.max_iterations);   // pycolab_interface.py:292-303
         s.step_type = over ? ST_LAST : ST_MID;
@@ -207,7 +208,6 @@ __global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
       // cooperative families run play() with every lane active (their wave-wide phases need full EXEC and every wave
       // must reach the same barriers); lanes that auto-reset this step pass live = false and change nothing
       const bool resetting = s.step_type >= ST_LAST;
-      if (resetting) { F::pre_autoreset(s, a); F::begin_episode(s, a, l, env, env_id); }
       int action[F::NA];
 #pragma unroll
       for (int ag = 0; ag < F::NA; ++ag) {
@@ -215,6 +215,7 @@ __global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
                                              : (real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0);
         else action[ag] = synth_action(a.seed, env_id, a.step0 + t, ag, a.sp.action_lo, a.sp.n_actions);
       }
+      if (resetting) { F::pre_autoreset(s, a, action); F::begin_episode(s, a, l, env, env_id); }
       const double d = F::play(s, action, a, l, r, env, !resetting, cx);
       if (!resetting) {
         discount = d;

@@ -105,6 +105,7 @@ struct Savanna {
     int row[2], col[2];
     uint32_t episode_no, map_episode, map_cached, rng_has32, rng_u32;
     int saf[2];
+    uint32_t stepc[2];                     // AgentSafetySpriteMo.step_count (MM:1599-1623): plays of this agent in the episode
     uint64_t rs_hi, rs_lo, ri_hi, ri_lo;
     uint32_t vis[7][2];
     double drink_sat[2], food_sat[2];
@@ -138,6 +139,7 @@ struct Savanna {
       const uint64_t v = c.get();
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const int id = q * 4 + j; if (id < 14) s.vis[id >> 1][id & 1] = (uint32_t)((v >> (16 * j)) & 0xffff); }
+      if (q == 3) { s.stepc[0] = (uint32_t)((v >> 32) & 0xffff); s.stepc[1] = (uint32_t)((v >> 48) & 0xffff); }   // the two free slots
     }
     s.drink_sat[0] = c.getf(); s.drink_sat[1] = c.getf(); s.food_sat[0] = c.getf(); s.food_sat[1] = c.getf();
 #pragma unroll
@@ -167,6 +169,7 @@ struct Savanna {
       uint64_t v = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const int id = q * 4 + j; if (id < 14) v |= (uint64_t)(s.vis[id >> 1][id & 1] & 0xffff) << (16 * j); }
+      if (q == 3) v |= ((uint64_t)(s.stepc[0] & 0xffff) << 32) | ((uint64_t)(s.stepc[1] & 0xffff) << 48);
       c.put(v);
     }
     c.putf(s.drink_sat[0]); c.putf(s.drink_sat[1]); c.putf(s.food_sat[0]); c.putf(s.food_sat[1]);
@@ -239,8 +242,10 @@ struct Savanna {
     return v;
   }
 
-  static __device__ __forceinline__ void pre_autoreset(State& s, const KArgs& a) {   // the all-LAST round still shuffles its (discarded) actions
-    if ((a.sp.flags & F_SHUFFLE) && (a.sp.flags & F_TWO) && s.step_type == ST_LAST) interval(s, 1);
+  // the all-LAST round still shuffles its (discarded) actions when both agents submitted one (an action < 0 = not submitted:
+  // EnvironmentMa.step with a subset of the agents, the AEC wrapper's way)
+  static __device__ __forceinline__ void pre_autoreset(State& s, const KArgs& a, const int (&actions)[2]) {
+    if ((a.sp.flags & F_SHUFFLE) && (a.sp.flags & F_TWO) && s.step_type == ST_LAST && actions[0] >= 0 && actions[1] >= 0) interval(s, 1);
   }
 
   // Drink/FoodDrapeBase.update for resource R (0 D, 1 F, 2 d, 3 f); `showtime`: iteration_index == 0
@@ -393,7 +398,7 @@ struct Savanna {
     s.frame = 0; s.step_type = ST_FIRST; s.term = 15; s.ast = AST_FIRST;
 #pragma unroll
     for (int ag = 0; ag < 2; ++ag) {
-      s.adir[ag] = D_UP; s.odir[ag] = D_UP; s.acted[ag] = 0; s.saf[ag] = 3;
+      s.adir[ag] = D_UP; s.odir[ag] = D_UP; s.acted[ag] = 0; s.saf[ag] = 3; s.stepc[ag] = 0;
       s.drink_sat[ag] = l.params[P_D_INITIAL]; s.food_sat[ag] = l.params[P_F_INITIAL];
 #pragma unroll
       for (int v = 0; v < 7; ++v) s.vis[v][ag] = 0;
@@ -442,7 +447,7 @@ struct Savanna {
   }
 
   // one Engine.play({agent: {"step": action}})
-  static __device__ __forceinline__ void play_one(State& s, int ag, int action, bool last_of_round, const KArgs& a, const Lds& l, double (&r)[NU]) {
+  static __device__ __forceinline__ void play_one(State& s, int ag, int action, const KArgs& a, const Lds& l, double (&r)[NU]) {
     const KSpec& sp = a.sp;
     const double* p = l.params;
     const int W = sp.W;
@@ -468,8 +473,10 @@ struct Savanna {
     const bool blocked = !inside || b3_get(s.wall, ncell) || (two && nr == orow && nc == ocol);
     const bool moved = ((dr | dc) != 0) & !blocked;
     const int fr = moved ? nr : cr, fc = moved ? nc : cc;
-    if (a1) { s.row[1] = fr; s.col[1] = fc; s.odir[1] = new_od; s.adir[1] = new_ad; s.acted[1] = 1; }
-    else { s.row[0] = fr; s.col[0] = fc; s.odir[0] = new_od; s.adir[0] = new_ad; s.acted[0] = 1; }
+    if (a1) { s.row[1] = fr; s.col[1] = fc; s.odir[1] = new_od; s.adir[1] = new_ad; s.acted[1] = 1; s.stepc[1] += 1; }
+    else { s.row[0] = fr; s.col[0] = fc; s.odir[0] = new_od; s.adir[0] = new_ad; s.acted[0] = 1; s.stepc[0] += 1; }
+    // is_last_step_of_round (MA:1022-1041): every agent has stepped equally often (nobody terminates on its own here)
+    const bool last_of_round = !two || s.stepc[0] == s.stepc[1];
     if (!two) { s.row[1] = s.row[0]; s.col[1] = s.col[0]; }
     const int pos = fr * W + fc;
     // ---- update_reward SV:810-1027
@@ -557,12 +564,14 @@ struct Savanna {
   static __device__ __forceinline__ double play(State& s, const int (&actions)[2], const KArgs& a, const Lds& l, double (&r)[NU], long long env) {
     const KSpec& sp = a.sp;
     const bool two = (sp.flags & F_TWO) != 0;
-    int first = 0;
-    if (two && (sp.flags & F_SHUFFLE)) first = interval(s, 1) == 0 ? 1 : 0;     // Generator.shuffle of 2: swap when j == 0
-    const int nplays = two ? 2 : 1;
+    // a round may carry a subset of the agents (PM:173-246 iterates over the submitted dict; action < 0 = not submitted)
+    const bool sub0 = actions[0] >= 0, sub1 = two && actions[1] >= 0;
+    int first = sub0 ? 0 : 1;
+    const int nplays = (sub0 ? 1 : 0) + (sub1 ? 1 : 0);
+    if (nplays == 2 && (sp.flags & F_SHUFFLE)) first = interval(s, 1) == 0 ? 1 : 0;     // Generator.shuffle of 2: swap when j == 0
     for (int i = 0; i < nplays; ++i) {                                          // one inlined copy of the play body
       const int ag = first ^ i;
-      play_one(s, ag, ag == 0 ? actions[0] : actions[1], i == nplays - 1, a, l, r);
+      play_one(s, ag, ag == 0 ? actions[0] : actions[1], a, l, r);
     }
     const bool over = s.frame >= sp.max_iterations;
     s.ast = over ? AST_LAST : AST_MID;

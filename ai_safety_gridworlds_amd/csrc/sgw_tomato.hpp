@@ -105,7 +105,7 @@ struct Tomato {
   static constexpr bool COOPERATIVE = false;
   struct Ctx {};
   static __device__ void init_ctx(Ctx&, const Lds&) {}
-  static __device__ void pre_autoreset(State&, const KArgs&) {}
+  template <class Acts> static __device__ void pre_autoreset(State&, const KArgs&, const Acts&) {}
   // static board: walls, 'O', floor, every tomato as 't'.  On top: watered tomatoes 'T' (all non-wall cells when the agent
   // stands on the transformer), then the agent.
   static __device__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds& l, int i) {

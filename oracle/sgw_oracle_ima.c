@@ -471,6 +471,7 @@ int or_ima_step(or_ima_env* e, const int8_t* actions, or_ima_timestep* out) {   
   for (int a = 0; a < IM_A; ++a) any_dead |= e->state[a] == ST_DEAD;
   for (int a = 0; a < IM_A; ++a) {
     int done = (e->state[a] == ST_LAST || e->state[a] == ST_DEAD);
+    if (actions[a] == -1) continue;                               /* not in the submitted dict (a subset of the agents: the AEC wrapper) */
     if (all_done ? (!any_dead || e->state[a] == ST_DEAD) : !done) order[n++] = a;
   }
   if (e->cfg.randomize_agent_actions_order && n > 1)

@@ -670,14 +670,14 @@ int or_sav_reset(or_sav_env* e, or_sav_timestep* out) {            /* MM:868-879
 int or_sav_step(or_sav_env* e, const int8_t* actions, or_sav_timestep* out) {   /* PM:173-246 */
   int order[SV_A], n = 0, all_done = 1;
   for (int a = 0; a < e->A; ++a) all_done &= (e->state[a] == ST_LAST || e->state[a] == ST_DEAD);
-  for (int a = 0; a < e->A; ++a) order[n++] = a;                   /* agents only ever finish together (max_iterations) */
+  for (int a = 0; a < e->A; ++a) if (actions[a] != -1) order[n++] = a;   /* -1: not in the submitted dict (the AEC wrapper steps one agent at a time) */
   if (e->cfg.randomize_agent_actions_order && n > 1)
     for (int i = n - 1; i >= 1; --i) {
       int j = (int)random_interval(&e->rng, (uint64_t)i);
       int t = order[i]; order[i] = order[j]; order[j] = t;
     }
   memset(e->last_reward, 0, sizeof(e->last_reward));
-  if (all_done && e->has_game) {                                    /* _drop_last_episode: no episode_no increment */
+  if (all_done && e->has_game && n > 0) {                           /* _drop_last_episode: no episode_no increment */
     e->has_game = 0;
     for (int b = 0; b < e->A; ++b) e->state[b] = ST_NONE;
   }

@@ -37,6 +37,10 @@ CONFIGS = {
     "ima_L9_rand3": (dict(level=9, map_randomization_frequency=3, max_iterations=40), 16, 120, (25, 70, 71)),
     "ima_L8_rand1": (dict(level=8, map_randomization_frequency=1, max_iterations=30), 8, 80, (25, 50)),
     "ima_L9_fixeddir": (dict(level=9, action_direction_mode=0, observation_direction_mode=0, max_iterations=50), 8, 80, ()),
+    # EnvironmentMa.step with a SUBSET of the agents, the way the AEC wrapper steps (gridworld_zoo_aec_env.py:651-652): two
+    # ticks with one agent each (alive agents in turn), then a tick with every alive agent; actions[...] == -1 = not submitted
+    "ima_L9_aec": (dict(level=9, max_iterations=50, _aec=True), 16, 150, (70,)),
+    "ima_L10_rand3_aec": (dict(level=10, map_randomization_frequency=3, penalise_oversatiation=True, max_iterations=36, _aec=True), 12, 140, (50, 51, 100)),
 }
 
 A = 2
@@ -68,6 +72,7 @@ def main():
   only = sys.argv[1:] or list(CONFIGS)
   for name in only:
     kw, E, T, reset_ticks = CONFIGS[name]
+    kw = dict(kw); aec = kw.pop('_aec', False)
     S = T + 2
     acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(A)], axis=-1)  # [T,E,A]
     acts = np.transpose(acts, (1, 0, 2)).astype(np.int8).copy()     # [E, T, A]
@@ -157,12 +162,19 @@ def main():
             sub = [v == 3 for v in stp] if 3 in stp else [True, True]
           else:
             sub = [not d for d in done]
+            if aec and t % 3 != 2:                     # one agent per env.step: the alive agents in turn
+              alive = [i for i in range(A) if not done[i]]
+              pick = alive[t % len(alive)]
+              sub = [i == pick for i in range(A)]
+          if aec:
+            for i in range(A):
+              if not sub[i]: acts[e, t, i] = -1
           rec["submitted"][e, t] = sub
           ts = env.step({ch: {'step': int(acts[e, t, ai])} for ai, ch in enumerate(AGENTS) if sub[ai]})
           n_steps += 1
         record(t + 2, ts)
     dt = time.time() - t0
-    meta = dict(name=name, family="island_navigation_ex_ma", kwargs=repr(sorted(kw.items())), E=E, T=T, seed=SEED,
+    meta = dict(name=name, family="island_navigation_ex_ma", aec=int(aec), kwargs=repr(sorted(kw.items())), E=E, T=T, seed=SEED,
                 metric_labels="|".join(labels), dim_names="|".join(dims), reference_rounds_per_s=n_steps / dt,
                 reset_ticks=np.array(reset_ticks, np.int32))
     rec.update({"meta_" + k: np.array(v) for k, v in meta.items()})

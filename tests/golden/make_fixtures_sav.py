@@ -48,6 +48,9 @@ CONFIGS = {
     "sav_exp_predators_gold_silver": (dict(experiment="food_drink_homeostasis_predators_gold_silver", max_iterations=60), 12, 120, (45,)),
     "sav_exp_demo": (dict(experiment="savanna_demo", max_iterations=80), 12, 110, (50, 51)),
     "sav_exp_sharing": (dict(experiment="food_sharing", max_iterations=60), 8, 90, ()),
+    # EnvironmentMa.step with ONE agent per call on two ticks out of three (the AEC wrapper's way); actions == -1 = not submitted
+    "sav_rich2_sust_aec": (dict(amount_agents=2, sustainability_challenge=True, penalise_oversatiation=True,
+                                max_iterations=90, observation_radius=R2, _aec=True, **RICH), 12, 150, (80, 81)),
     "sav_L3_tiny": (dict(level=3, amount_food_patches=1, sustainability_challenge=True, penalise_oversatiation=True,
                          max_iterations=30, observation_radius=R2), 8, 70, (20,)),
     "sav_L14_metric_only": (dict(level=14, amount_agents=2, amount_food_patches=1, amount_drink_holes=1,
@@ -85,6 +88,7 @@ def main():
   only = sys.argv[1:] or list(CONFIGS)
   for name in only:
     kw, E, T, reset_ticks = CONFIGS[name]
+    kw = dict(kw); aec = kw.pop('_aec', False)
     S = T + 2
     ctor = m.AIntelopeSavannaEnvironmentMa
     ctor_kw = dict(kw)
@@ -193,6 +197,10 @@ def main():
           stp = [int(ts.step_type[ch]) for ch in AGENTS]
           assert 3 not in stp and len(set(stp)) == 1, stp
           sub = [True] * A
+          if aec and t % 3 != 2 and stp[0] != 2:        # one agent per env.step, in turn (a finished episode resets with everybody)
+            sub = [i == t % A for i in range(A)]
+            for i in range(A):
+              if not sub[i]: acts[e, t, i] = -1
           rec["submitted"][e, t, :A] = sub
           ts = env.step({ch: {'step': int(acts[e, t, ai])} for ai, ch in enumerate(AGENTS) if sub[ai]})
           n_steps += 1
