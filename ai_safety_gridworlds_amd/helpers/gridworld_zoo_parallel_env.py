@@ -163,6 +163,9 @@ class GridworldZooParallelEnv(_Base):
           raise ValueError("Agent %s is done" % self.agent_name_mapping[a])      # pycolab_interface_ma.py:218
         acts.append(0)
         continue
+      if a not in actions and getattr(sp, "per_agent", False):
+        acts.append(-1)                    # not in the submitted dict: the agent does not play this round (PM:173-246)
+        continue
       v = actions.get(a, 0)
       if isinstance(v, dict):
         if "step" not in v:                                                     # pycolab_interface_ma.py:202-207

@@ -170,7 +170,9 @@ int sgw_pow_f64(const double* x_dev, double y, double* out_dev, int64_t n, int d
 int sgw_reset(sgw_engine* e, const uint8_t* mask_dev, const sgw_out* out, void* stream);
 
 /* One env.step() per env: actions_dev int8 [N, A].  Envs whose previous step was LAST are
- * auto-reset instead (action discarded, FIRST emitted) exactly like the reference adapter. */
+ * auto-reset instead (action discarded, FIRST emitted) exactly like the reference adapter.
+ * island_navigation_ex_ma / aintelope_savanna: an action < 0 = that agent is not in the submitted dict and does not play
+ * this round (EnvironmentMa.step with a subset of the agents, pycolab_interface_ma.py:173-246; the AEC wrapper's way). */
 int sgw_step(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, void* stream);
 
 /* T consecutive sgw_step launches (one kernel launch per step, host loop in C): actions_dev int8

@@ -194,6 +194,58 @@ def test_savanna_through_the_zoo_parallel_facade(fixture):
   assert lasts == int((fx["step_type"][e, 2:] >= 2).sum())
 
 
+def test_savanna_through_the_zoo_aec_facade():
+  """One agent per step (the AEC wrapper submits {agent: action} alone): boards, windows and the acting agent's reward
+  against the oracle fed the same single-agent rounds; cumulative rewards collect what the OTHER agent's steps gave
+  (cooperation) until the agent acts again; the dead step of a finished agent removes it from `.agents`."""
+  from ai_safety_gridworlds_amd.helpers.gridworld_zoo_aec_env import GridworldZooAecEnv
+  from oracle import oracle_ma as OM
+  from oracle import oracle_sav as OS
+  kw = dict(amount_agents=2, amount_predators=2, amount_water_tiles=2, amount_gold_deposits=2, amount_drink_holes=2,
+            sustainability_challenge=True, penalise_oversatiation=True, max_iterations=40, observation_radius=[2, 2, 2, 2])
+  seed, T = 4321, 40                                   # 40 plays = max_iterations: the episode ends inside the loop
+  rnd = np.random.default_rng(3)
+  plan = rnd.integers(0, 5, size=T)
+  actions = np.full((1, T, 2), -1, np.int8)
+  for t in range(T):
+    actions[0, t, t % 2] = plan[t]
+  want = OS.run_streams(OS.make_config(**kw), actions, np.stack([OM.rng_state_words(seed)]))
+  env = GridworldZooAecEnv("aintelope_savanna", seed=seed, **kw)
+  env.reset(); env.reset()
+  assert env.agents == ["agent_0", "agent_1"] and env.agent_selection == "agent_0"
+  t = 0
+  pending = {"agent_0": 0.0, "agent_1": 0.0}
+  for agent in env.agent_iter():
+    if t == T:
+      break
+    obs, cum, term, trunc, info = env.last()
+    i = env.possible_agents.index(agent)
+    assert not term and not trunc and i == t % 2
+    assert np.array_equal(obs[0], np.vectorize(chr)(want["view"][0, t + 1, i]))     # the window before this step
+    env.step(int(plan[t]))
+    assert np.array_equal(env.state[0], np.vectorize(chr)(want["board"][0, t + 2]))
+    r = want["reward"][0, t + 2]                       # [agent, K] of this single-agent round
+    assert np.array_equal(env.rewards[agent], r[i])
+    other = env.possible_agents[1 - i]
+    pending[agent] = r[i]
+    pending[other] = pending[other] + r[1 - i]
+    got = env._cumulative_rewards
+    assert np.array_equal(np.asarray(got[agent]), np.asarray(pending[agent]))
+    assert np.array_equal(np.asarray(got[other]), np.asarray(pending[other]))
+    t += 1
+  assert (want["step_type"][0, T + 1] == 2).all()      # the episode ended with the last play ...
+  last_actor = env.possible_agents[(T - 1) % 2]
+  assert t == T and env.terminations[last_actor] is True              # ... which flags the agent that made it (zoo_aec.py:784-797)
+  assert env.agent_selection == env.possible_agents[T % 2]            # the other one is flagged when it steps next
+  env._next_agent = last_actor                                         # its "dead step": only None is accepted, the agent leaves
+  with pytest.raises(ValueError, match="only valid action is None"):
+    env.step(1)
+  env.step(None)
+  assert env.agents == [env.possible_agents[T % 2]] and last_actor not in env.rewards
+  with pytest.raises(NotImplementedError):
+    GridworldZooAecEnv("firemaker_ex_ma", amount_agents=3)
+
+
 def test_step_logger_reproduces_the_reference_csv(tmp_path):
   """the CSV step log of one island_navigation_ex env, byte for byte against the file the reference wrote
   for the same action stream (tests/golden/island_L9_steplog.csv, make_fixtures_log.py)."""
