@@ -99,14 +99,15 @@ struct Savanna {
   enum { L_P = 0, L_D = 1, L_F = 2, L_SD = 3, L_SF = 4 };     // dynamic layers; resources are L_D + {0: D, 1: F, 2: d, 3: f}
   enum { V_GAP, V_DRINK, V_FOOD, V_SDRINK, V_SFOOD, V_GOLD, V_SILVER };
 
+  struct Rng { uint64_t rs_hi, rs_lo, ri_hi, ri_lo; uint32_t has32, u32; };
   struct State {
     int frame, step_type, term;
     int ast, adir[2], odir[2], acted[2];
     int row[2], col[2];
-    uint32_t episode_no, map_episode, map_cached, rng_has32, rng_u32;
+    uint32_t episode_no, map_episode, map_cached;
+    Rng g;                                 // the env's numpy PCG64 (state, inc, buffered uint32)
     int saf[2];
     uint32_t stepc[2];                     // AgentSafetySpriteMo.step_count (MM:1599-1623): plays of this agent in the episode
-    uint64_t rs_hi, rs_lo, ri_hi, ri_lo;
     uint32_t vis[7][2];
     double drink_sat[2], food_sat[2];
     double avail[4];                       // D F d f
@@ -125,15 +126,15 @@ struct Savanna {
     const uint64_t w0 = c.get(), w1 = c.get(), w2 = c.get();
     s.frame = (int)(w0 & 0xffff);
     s.ast = (int)((w0 >> 16) & 7);
-    s.acted[0] = (int)((w0 >> 26) & 1); s.rng_has32 = (uint32_t)((w0 >> 27) & 1);
+    s.acted[0] = (int)((w0 >> 26) & 1); s.g.has32 = (uint32_t)((w0 >> 27) & 1);
     s.adir[0] = (int)((w0 >> 28) & 3); s.adir[1] = (int)((w0 >> 30) & 3);
     s.step_type = (int)((w0 >> 32) & 0xf); s.term = (int)((w0 >> 36) & 0xf);   // same place in every family (sgw_create)
     s.odir[0] = (int)((w0 >> 40) & 3); s.odir[1] = (int)((w0 >> 42) & 3);
     s.acted[1] = (int)((w0 >> 44) & 1); s.map_cached = (uint32_t)((w0 >> 45) & 1);
     s.row[0] = (int)(w1 & 0xff); s.col[0] = (int)((w1 >> 8) & 0xff); s.row[1] = (int)((w1 >> 16) & 0xff); s.col[1] = (int)((w1 >> 24) & 0xff);
     s.episode_no = (uint32_t)((w1 >> 32) & 0xffff); s.map_episode = (uint32_t)((w1 >> 48) & 0xffff);
-    s.rng_u32 = (uint32_t)w2; s.saf[0] = (int)((w2 >> 32) & 0xff); s.saf[1] = (int)((w2 >> 40) & 0xff);
-    s.rs_hi = c.get(); s.rs_lo = c.get(); s.ri_hi = c.get(); s.ri_lo = c.get();
+    s.g.u32 = (uint32_t)w2; s.saf[0] = (int)((w2 >> 32) & 0xff); s.saf[1] = (int)((w2 >> 40) & 0xff);
+    s.g.rs_hi = c.get(); s.g.rs_lo = c.get(); s.g.ri_hi = c.get(); s.g.ri_lo = c.get();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                                     // 14 visit counters, 16 bits each, 4 per word
       const uint64_t v = c.get();
@@ -156,14 +157,14 @@ struct Savanna {
 
   static __device__ __forceinline__ void store(const State& s, const KArgs& a, long long env) {
     const uint64_t w0 = (uint64_t)(s.frame & 0xffff) | ((uint64_t)(s.ast & 7) << 16) | ((uint64_t)(s.acted[0] & 1) << 26) |
-                        ((uint64_t)(s.rng_has32 & 1) << 27) | ((uint64_t)(s.adir[0] & 3) << 28) | ((uint64_t)(s.adir[1] & 3) << 30) |
+                        ((uint64_t)(s.g.has32 & 1) << 27) | ((uint64_t)(s.adir[0] & 3) << 28) | ((uint64_t)(s.adir[1] & 3) << 30) |
                         ((uint64_t)(s.step_type & 0xf) << 32) | ((uint64_t)(s.term & 0xf) << 36) | ((uint64_t)(s.odir[0] & 3) << 40) |
                         ((uint64_t)(s.odir[1] & 3) << 42) | ((uint64_t)(s.acted[1] & 1) << 44) | ((uint64_t)(s.map_cached & 1) << 45);
     const uint64_t w1 = (uint64_t)(s.row[0] & 0xff) | ((uint64_t)(s.col[0] & 0xff) << 8) | ((uint64_t)(s.row[1] & 0xff) << 16) |
                         ((uint64_t)(s.col[1] & 0xff) << 24) | ((uint64_t)(s.episode_no & 0xffff) << 32) | ((uint64_t)(s.map_episode & 0xffff) << 48);
     Cursor c(a, env);
-    c.put(w0); c.put(w1); c.put((uint64_t)s.rng_u32 | ((uint64_t)(s.saf[0] & 0xff) << 32) | ((uint64_t)(s.saf[1] & 0xff) << 40));
-    c.put(s.rs_hi); c.put(s.rs_lo); c.put(s.ri_hi); c.put(s.ri_lo);
+    c.put(w0); c.put(w1); c.put((uint64_t)s.g.u32 | ((uint64_t)(s.saf[0] & 0xff) << 32) | ((uint64_t)(s.saf[1] & 0xff) << 40));
+    c.put(s.g.rs_hi); c.put(s.g.rs_lo); c.put(s.g.ri_hi); c.put(s.g.ri_lo);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       uint64_t v = 0;
@@ -186,52 +187,52 @@ struct Savanna {
   }
 
   // ---- numpy PCG64 ------------------------------------------------------------------------------------------------
-  static __device__ __forceinline__ uint64_t next64(State& s) {
+  static __device__ __forceinline__ uint64_t next64(Rng& g) {
     const uint64_t MH = 0x2360ED051FC65DA4ULL, ML = 0x4385DF649FCCF645ULL;
-    uint64_t lo = s.rs_lo * ML;
-    uint64_t hi = __umul64hi(s.rs_lo, ML) + s.rs_hi * ML + s.rs_lo * MH;
-    uint64_t nlo = lo + s.ri_lo;
-    hi += s.ri_hi + (nlo < lo ? 1ull : 0ull);
-    s.rs_lo = nlo; s.rs_hi = hi;
+    uint64_t lo = g.rs_lo * ML;
+    uint64_t hi = __umul64hi(g.rs_lo, ML) + g.rs_hi * ML + g.rs_lo * MH;
+    uint64_t nlo = lo + g.ri_lo;
+    hi += g.ri_hi + (nlo < lo ? 1ull : 0ull);
+    g.rs_lo = nlo; g.rs_hi = hi;
     uint64_t x = hi ^ nlo;
     unsigned rot = (unsigned)(hi >> 58);
     return (x >> rot) | (x << ((64u - rot) & 63u));
   }
-  static __device__ __forceinline__ uint32_t next32(State& s) {
-    if (s.rng_has32) { s.rng_has32 = 0; return s.rng_u32; }
-    uint64_t n = next64(s);
-    s.rng_has32 = 1; s.rng_u32 = (uint32_t)(n >> 32);
+  static __device__ __forceinline__ uint32_t next32(Rng& g) {
+    if (g.has32) { g.has32 = 0; return g.u32; }
+    uint64_t n = next64(g);
+    g.has32 = 1; g.u32 = (uint32_t)(n >> 32);
     return (uint32_t)n;
   }
-  static __device__ __forceinline__ int interval(State& s, uint32_t max) {        // distributions.c random_interval (Generator.shuffle)
+  static __device__ __forceinline__ int interval(Rng& g, uint32_t max) {        // distributions.c random_interval (Generator.shuffle)
     uint32_t mask = max;
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
     uint32_t v;
     int guard = 0;
-    do { v = next32(s) & mask; } while (v > max && ++guard < 1024);     // p(reject) < 1/2 per draw
+    do { v = next32(g) & mask; } while (v > max && ++guard < 1024);     // p(reject) < 1/2 per draw
     return (int)(v > max ? max : v);
   }
-  static __device__ __forceinline__ int lemire(State& s, uint32_t rng) {          // distributions.c bounded_lemire_uint32 (integers / choice)
+  static __device__ __forceinline__ int lemire(Rng& g, uint32_t rng) {          // distributions.c bounded_lemire_uint32 (integers / choice)
     if (rng == 0u) return 0;
     const uint32_t ex = rng + 1u;
-    uint64_t m = (uint64_t)next32(s) * ex;
+    uint64_t m = (uint64_t)next32(g) * ex;
     uint32_t left = (uint32_t)m;
     if (left < ex) {
       const uint32_t thr = (0xffffffffu - rng) % ex;
       // a live stream leaves after ~1 draw (thr / 2^32 < 2^-24 here); the cap keeps a wave with a dead stream from spinning
-      for (int guard = 0; left < thr && guard < 64; ++guard) { m = (uint64_t)next32(s) * ex; left = (uint32_t)m; }
+      for (int guard = 0; left < thr && guard < 64; ++guard) { m = (uint64_t)next32(g) * ex; left = (uint32_t)m; }
     }
     return (int)(m >> 32);
   }
   // Generator.choice(pop, size, replace=False), pop <= 10000: Floyd's sampler, then _shuffle_int over the picks (their
   // order never matters here, the draws do).  Returns the picked ranks as a bitmap.
-  static __device__ __forceinline__ B3 choose(State& s, int pop, int size) {
+  static __device__ __forceinline__ B3 choose(Rng& g, int pop, int size) {
     B3 ch{0ull, 0ull, 0ull};
     for (int j = pop - size; j < pop; ++j) {
-      const int val = lemire(s, (uint32_t)j);
+      const int val = lemire(g, (uint32_t)j);
       b3_set(ch, b3_get(ch, val) ? j : val);
     }
-    for (int i = size - 1; i >= 1; --i) lemire(s, (uint32_t)i);
+    for (int i = size - 1; i >= 1; --i) lemire(g, (uint32_t)i);
     return ch;
   }
   static __device__ __forceinline__ B3 valid_mask(int HW) {
@@ -245,7 +246,7 @@ struct Savanna {
   // the all-LAST round still shuffles its (discarded) actions when both agents submitted one (an action < 0 = not submitted:
   // EnvironmentMa.step with a subset of the agents, the AEC wrapper's way)
   static __device__ __forceinline__ void pre_autoreset(State& s, const KArgs& a, const int (&actions)[2]) {
-    if ((a.sp.flags & F_SHUFFLE) && (a.sp.flags & F_TWO) && s.step_type == ST_LAST && actions[0] >= 0 && actions[1] >= 0) interval(s, 1);
+    if ((a.sp.flags & F_SHUFFLE) && (a.sp.flags & F_TWO) && s.step_type == ST_LAST && actions[0] >= 0 && actions[1] >= 0) interval(s.g, 1);
   }
 
   // Drink/FoodDrapeBase.update for resource R (0 D, 1 F, 2 d, 3 f); `showtime`: iteration_index == 0
@@ -284,7 +285,7 @@ struct Savanna {
         if (cnt == 0) {
           cur = B3{0ull, 0ull, 0ull};                                  // `curtain[()] = False`
         } else {
-          const B3 ch = choose(s, len, cnt);
+          const B3 ch = choose(s.g, len, cnt);
 #pragma unroll
           for (int wi = 0; wi < 3; ++wi) {
             uint64_t z = b3_word(ch, wi);
@@ -302,7 +303,7 @@ struct Savanna {
       if (len > 0) {
         int cnt = (int)(avail_int - visible);
         cnt = cnt < len ? cnt : len;                 // the reference raises ValueError beyond len (specs.py rejects such configs)
-        const B3 ch = choose(s, len, cnt);
+        const B3 ch = choose(s.g, len, cnt);
 #pragma unroll
         for (int wi = 0; wi < 3; ++wi) {
           uint64_t z = b3_word(ch, wi);
@@ -325,7 +326,7 @@ struct Savanna {
         const uint8_t type_chr = t < 8 ? (uint8_t)(ORDER_LO >> (8 * t)) : (uint8_t)('0' + (t - 8));
         const int num = (int)l.params[P_NUM0 + t], rem = num - (int)l.params[P_MAX0 + t];
         if (rem > 0) {
-          const B3 ch = choose(s, num, rem);
+          const B3 ch = choose(s.g, num, rem);
           int rank = 0;
           for (int k = 0; k < HW; ++k) {
             const bool is = cells[k] == type_chr;
@@ -336,7 +337,7 @@ struct Savanna {
       }
       const int w = W - 2, n = (sp.H - 2) * w;                       // MA:1224-1241
       for (int i = n - 1; i >= 1; --i) {
-        const int j = interval(s, (uint32_t)i);
+        const int j = interval(s.g, (uint32_t)i);
         const int ci = (i / w + 1) * W + i % w + 1, cj = (j / w + 1) * W + j % w + 1;
         const uint8_t vi = cells[ci], vj = cells[cj];
         cells[ci] = vj; cells[cj] = vi;
@@ -535,9 +536,9 @@ struct Savanna {
           const int cell = wi * 64 + __builtin_ctzll(z); z &= z - 1;
           if (cell == p0 || (two && cell == p1)) { injury += (cell == pos) ? p[P_PREDATOR] : 0.0; continue; }
           if (!last_of_round) continue;
-          const double u = (double)(next64(s) >> 11) * (1.0 / 9007199254740992.0);
+          const double u = (double)(next64(s.g) >> 11) * (1.0 / 9007199254740992.0);
           if (u >= p[P_PRED_PROB]) continue;
-          const int ch = lemire(s, 3u);                                 // UP DOWN LEFT RIGHT
+          const int ch = lemire(s.g, 3u);                                 // UP DOWN LEFT RIGHT
           int rr = cell / W, qq = cell - rr * W;
           if (ch == 0) rr = rr - 1 < 0 ? 0 : rr - 1;
           else if (ch == 1) rr = rr + 1 > sp.H - 1 ? sp.H - 1 : rr + 1;
@@ -568,7 +569,7 @@ struct Savanna {
     const bool sub0 = actions[0] >= 0, sub1 = two && actions[1] >= 0;
     int first = sub0 ? 0 : 1;
     const int nplays = (sub0 ? 1 : 0) + (sub1 ? 1 : 0);
-    if (nplays == 2 && (sp.flags & F_SHUFFLE)) first = interval(s, 1) == 0 ? 1 : 0;     // Generator.shuffle of 2: swap when j == 0
+    if (nplays == 2 && (sp.flags & F_SHUFFLE)) first = interval(s.g, 1) == 0 ? 1 : 0;     // Generator.shuffle of 2: swap when j == 0
     for (int i = 0; i < nplays; ++i) {                                          // one inlined copy of the play body
       const int ag = first ^ i;
       play_one(s, ag, ag == 0 ? actions[0] : actions[1], a, l, r);
