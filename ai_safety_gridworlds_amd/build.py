@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 def _deps():
   out = [os.path.join(HERE, "..", "include", "sgw.h")]
   for f in os.listdir(CSRC):
-    if f.endswith((".hip", ".hpp", ".h")):
+    if f.endswith((".hip", ".hpp", ".h", ".inc")):
       out.append(os.path.join(CSRC, f))
   return out
 
@@ -34,10 +34,24 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
   if not os.path.exists(HIPCC):
     raise RuntimeError("hipcc not found at %s: libsgw.so cannot be built (no CPU fallback exists)" % HIPCC)
-  cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-  if verbose:
-    print(" ".join(cmd))
-  subprocess.check_call(cmd)
+  # several ranks of one node may get here at once (torchrun): one compiles, the others wait for it and reuse the
+  # result; the library appears atomically
+  import fcntl
+  with open(LIB + ".lock", "w") as lock:
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    if (not force and os.path.exists(LIB)
+        and os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in _deps())):
+      return LIB
+    tmp = "%s.tmp.%d" % (LIB, os.getpid())
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+      print(" ".join(cmd).replace(tmp, LIB))
+    try:
+      subprocess.check_call(cmd)
+      os.replace(tmp, LIB)
+    finally:
+      if os.path.exists(tmp):
+        os.remove(tmp)
   return LIB
 
 

@@ -248,7 +248,11 @@ struct Cursor {
   __device__ Cursor(const KArgs& a, long long env) : p(a.state + env), stride(a.n_pad) {}
   __device__ uint64_t get() { uint64_t v = *p; p += stride; return v; }
   __device__ double getf() { return __longlong_as_double((long long)get()); }
+#ifdef SGW_STATE_WT
+  __device__ void put(uint64_t v) { store8_wt(p, v); p += stride; }
+#else
   __device__ void put(uint64_t v) { *p = v; p += stride; }  // plain: the next launch re-reads the state from this XCD's L2
+#endif
   __device__ void putf(double v) { put((uint64_t)__double_as_longlong(v)); }
   __device__ void skip(int n) { p += stride * n; }
   // conditional (wave-uniform) column access without a branch: a disabled slot reads the env's word 0 (always valid)
