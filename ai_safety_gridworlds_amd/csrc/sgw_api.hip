@@ -451,6 +451,21 @@ int sgw_observe_layers(sgw_engine* e, const uint8_t* board_dev, const uint8_t* l
   return SGW_OK;
 }
 
+int sgw_state_layers(sgw_engine* e, const uint8_t* layer_chars_dev, int n_layers, int gap_only_blank, uint8_t* layers_dev,
+                     void* stream) {
+  if (!e || !layer_chars_dev || !layers_dev || n_layers < 1) return fail(SGW_ERR_ARG, "sgw_state_layers: bad argument");
+  if (e->spec.family != SGW_AINTELOPE_SAVANNA)
+    return fail(SGW_ERR_UNSUPPORTED, "sgw_state_layers: this family's layers follow from its board (sgw_observe_layers)");
+  HIP_TRY(hipSetDevice(e->device));
+  const long long total = e->n_envs * e->ks.HW;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(k_savanna_layers, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e->state_dev, e->n_pad, e->n_envs,
+                     e->ks.HW, e->ks.W, (e->spec.flags & Savanna::F_TWO) ? 1 : 0, layer_chars_dev, n_layers, gap_only_blank,
+                     layers_dev);
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
 static ViewSpec make_viewspec(const sgw_engine* e) {
   ViewSpec v; memset(&v, 0, sizeof(v));
   v.A = e->spec.A; v.H = e->spec.H; v.W = e->spec.W;

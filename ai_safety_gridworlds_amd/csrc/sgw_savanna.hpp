@@ -654,4 +654,36 @@ struct Savanna {
   static __device__ __forceinline__ int agent_safety(const State& s, int ag, const KSpec&) { return s.saf[ag]; }
 };
 
+// Unoccluded observation layers straight from the state bitmaps (the rendered board only shows the top drape of a cell):
+// layers[n][l][cell] for the characters in layer_chars ('#', ' ', W P D F d f G S, '0', '1'); the gap layer is set only
+// where every other layer is blank when gap_only_blank (observe_gaps_only_where_other_layers_are_blank=True, SV:1690).
+__global__ void k_savanna_layers(const uint64_t* state, long long n_pad, long long n, int HW, int W, int two,
+                                 const uint8_t* layer_chars, int n_layers, int gap_only_blank, uint8_t* layers) {
+  const long long total = n * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long env = i / HW;
+    const int cell = (int)(i - env * HW);
+    const int wi = cell >> 6, sh = cell & 63;
+    auto bit = [&](int word0) { return (int)((state[(long long)(word0 + wi) * n_pad + env] >> sh) & 1ull); };
+    const uint64_t w1 = state[1 * n_pad + env];
+    const int c0 = (int)(w1 & 0xff) * W + (int)((w1 >> 8) & 0xff), c1 = (int)((w1 >> 16) & 0xff) * W + (int)((w1 >> 24) & 0xff);
+    const int wall = bit(Savanna::W_STATIC), water = bit(Savanna::W_STATIC + 3), gold = bit(Savanna::W_STATIC + 6), silver = bit(Savanna::W_STATIC + 9);
+    const int P = bit(Savanna::W_DYN), D = bit(Savanna::W_DYN + 3), F = bit(Savanna::W_DYN + 6), sd = bit(Savanna::W_DYN + 9), sf = bit(Savanna::W_DYN + 12);
+    const int a0 = cell == c0, a1 = two && cell == c1;
+    const int other = wall | water | gold | silver | P | D | F | sd | sf | a0 | a1;
+    for (int l = 0; l < n_layers; ++l) {
+      const uint8_t ch = layer_chars[l];
+      int v = 0;
+      switch (ch) {
+        case '#': v = wall; break;    case 'W': v = water; break;  case 'G': v = gold; break;   case 'S': v = silver; break;
+        case 'P': v = P; break;       case 'D': v = D; break;      case 'F': v = F; break;      case 'd': v = sd; break;
+        case 'f': v = sf; break;      case '0': v = a0; break;     case '1': v = a1; break;
+        case ' ': v = gap_only_blank ? !other : !wall; break;
+        default: v = 0;
+      }
+      layers[(env * n_layers + l) * HW + cell] = (uint8_t)v;
+    }
+  }
+}
+
 }  // namespace sgw

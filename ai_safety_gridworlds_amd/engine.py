@@ -301,6 +301,14 @@ class BatchedEngine(object):
     """Unoccluded per-character layers with the gap correction: uint8 [N, L, H, W], L = len(spec.layer_chars)
     (what the MO/MA envs put in observation['layers']: rendering.py:188-302, observation_distiller_ex.py:164-178)."""
     sp = self.spec
+    if getattr(sp, "layers_from_state", False):   # aintelope_savanna: drapes overlap, the board shows only the top one
+      if board is not None:
+        raise N.SgwError("observe_layers: this family's layers come from the engine state (current step), not from a board")
+      chars = torch.tensor([ord(c) for c in sp.layer_chars], dtype=torch.uint8, device=self.device)
+      out = torch.empty((self.n_envs, len(sp.layer_chars), sp.H, sp.W), dtype=torch.uint8, device=self.device)
+      N.check(self._lib.sgw_state_layers(self._h, chars.data_ptr(), len(sp.layer_chars), 1, out.data_ptr(), self._stream()),
+              "sgw_state_layers")
+      return out
     if board is None:
       board = self._bufs["board"][:self.n_envs]
     board = board.reshape(-1, sp.H * sp.W).contiguous()

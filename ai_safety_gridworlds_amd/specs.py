@@ -938,7 +938,7 @@ def _savanna_spec(kwargs):
                   bg_colours=SAVANNA_BG, actions=MO_ACTIONS, scalar=False, max_iterations=int(cfg["max_iterations"]),
                   config=cfg, layer_chars=sorted(set(flat) | set(' WPDFdfGS') | set(agents)), what_lies_beneath=' ',
                   what_lies_outside='#', agent_chars=agents, drape_chars='WPDFdfGS', dynamic_drapes='PDFdfWGS',
-                  per_agent=True, needs_rng=True, family_table=table,
+                  per_agent=True, needs_rng=True, family_table=table, layers_from_state=True,
                   rotating_views=cfg["observation_direction_mode"] != 0, randomized_map=bool(mrf),
                   view_shapes=[(rad[0] + rad[1] + 1, rad[2] + rad[3] + 1)] * 2)
 

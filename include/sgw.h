@@ -229,6 +229,14 @@ int sgw_observe_layers(sgw_engine* e, const uint8_t* board_dev, const uint8_t* l
                        const uint8_t* layer_static_dev, int n_layers, int gap_index, const uint8_t* agent_pos_dev,
                        const uint8_t* agent_flags_dev, int hidden_layer, uint8_t* layers_dev, void* stream);
 
+/* aintelope_savanna: its drapes overlap (a food tile may spawn on gold, a predator may stand on either), so the board
+ * shows only the top one and the unoccluded layers come from the state instead: layers_dev uint8 [N, L, H*W] for the
+ * characters in layer_chars_dev ('#', ' ', W P D F d f G S, '0', '1'), as of the last step / reset.  gap_only_blank != 0:
+ * the ' ' layer is set only where every other layer is blank (observe_gaps_only_where_other_layers_are_blank=True,
+ * aintelope_savanna.py:1690), else wherever the backdrop is not a wall. */
+int sgw_state_layers(sgw_engine* e, const uint8_t* layer_chars_dev, int n_layers, int gap_only_blank, uint8_t* layers_dev,
+                     void* stream);
+
 /* Agent-centric observations (get_agent_perspective, safety_game_moma.py:1996-2101): for every env and
  * agent a, the (up+down+1) x (left+right+1) window of the rendered board centred on the agent, cells
  * outside the board filled with `outside_chr`.  views_dev uint8 [N, view_bytes] with agent a's window at

@@ -26,9 +26,11 @@ def run(spec, actions, rng_states):
   rec = {k: [] for k in OUTS}
   views = [[], []]
   rng = []
+  lay = []
   def grab(o):
     for k in OUTS:
       rec[k].append(o[k].clone())
+    lay.append(eng.observe_layers().clone())
     for i, v in enumerate(eng.agent_views()):
       views[i].append(v.clone())
     st = eng.get_state()[:, :E].cpu().numpy().view(np.uint64)
@@ -46,6 +48,7 @@ def run(spec, actions, rng_states):
   out = {k: torch.stack(v, dim=1).cpu().numpy() for k, v in rec.items()}
   out["view"] = np.stack([torch.stack(v, dim=1).cpu().numpy() for v in views], axis=2)    # [E, S, 2, VS, VS]
   out["rng_all"] = np.stack(rng, axis=1)
+  out["layers"] = torch.stack(lay, dim=1).cpu().numpy()                                   # [E, S, L, H, W], L = spec.layer_chars
   eng.close()
   return out
 
@@ -82,6 +85,20 @@ def test_savanna_hip_matches_reference_fixture(name):
   got = run(spec, fx["actions"], fx["rng_seeded"])
   check(name, got, fx, spec.K, spec.n_agents)
   G.assert_same(name + ".obs_board", got["obs_board"][:, 1:].reshape(fx["obs_board"][:, 1:].shape), fx["obs_board"][:, 1:])
+  # unoccluded layers from the state: the reference's drape curtains (W P D F d f G S), the agents, walls, and the gap layer
+  # "only where every other layer is blank"
+  chars = spec.layer_chars
+  for li, ch in enumerate("WPDFdfGS"):
+    G.assert_same(name + ".layer " + ch, got["layers"][:, 1:, chars.index(ch)], fx["layers"][:, 1:, li])
+  occupied = fx["layers"][:, 1:, :8].any(axis=2) | (fx["board"][:, 1:] == ord('#'))
+  for i in range(spec.n_agents):
+    agent = np.zeros_like(occupied)
+    E, S1 = agent.shape[:2]
+    ee, ss = np.meshgrid(np.arange(E), np.arange(S1), indexing="ij")
+    agent[ee, ss, fx["pos"][:, 1:, i, 0], fx["pos"][:, 1:, i, 1]] = True
+    G.assert_same(name + ".layer agent", got["layers"][:, 1:, chars.index("01"[i])], agent.astype(np.uint8))
+    occupied |= agent
+  G.assert_same(name + ".layer gap", got["layers"][:, 1:, chars.index(' ')], (~occupied).astype(np.uint8))
 
 
 RICH = dict(amount_predators=3, amount_water_tiles=3, amount_gold_deposits=3, amount_silver_deposits=2,
