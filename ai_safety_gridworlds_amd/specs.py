@@ -248,6 +248,13 @@ def _map_contains(art, ch):     # safety_ui_ex.py:662-666
   return any(ch in row for row in art)
 
 
+def _check_regrowth_exponent(name, value):
+  """csrc/sgw_pow.hpp restates glibc's pow for the regrowth domain (base in [2, 61]) without its special cases: the
+  product exponent * log(base) must stay inside glibc's main path, |y log x| in [2^-54, 2^9)."""
+  if not (1e-9 <= float(value) <= 100.0):
+    raise NotImplementedError("%s = %r: the device pow covers regrowth exponents in [1e-9, 100]" % (name, value))
+
+
 def _island_spec(kwargs):
   cfg = dict(ISLAND_DEFAULTS)
   upper = {k.upper(): k for k in cfg}
@@ -264,6 +271,7 @@ def _island_spec(kwargs):
   # a flag that puts its event on dimensions beyond its own (experiments/food_drink_rolf*: DRINK_REWARD = {DRINK: a, FOOD: b,
   # GOLD: c}) switches the kernel to per-event reward vectors (csrc/sgw_island.hpp, F_GENERAL)
   general = any(isinstance(d, dict) and set(cfg[f]) - set(d) for f, d in ISLAND_DEFAULTS.items())
+  _check_regrowth_exponent("DRINK_REGROWTH_EXPONENT", cfg["DRINK_REGROWTH_EXPONENT"])
   level = int(cfg["level"])
   if not 0 <= level < len(ISLAND_ART):
     raise IndexError("island_navigation_ex level %d" % level)
@@ -585,6 +593,7 @@ def _island_ma_spec(kwargs):
       cfg[flag] = float(cfg[flag])
   if int(cfg["amount_agents"]) != 2:
     raise NotImplementedError("island_navigation_ex_ma: the batched engine implements amount_agents=2 (the reference's AGENT_CHRS)")
+  _check_regrowth_exponent("DRINK_REGROWTH_EXPONENT", cfg["DRINK_REGROWTH_EXPONENT"])
   if cfg["action_direction_mode"] not in (0, 1) or cfg["observation_direction_mode"] not in (0, 1):
     raise NotImplementedError("island_navigation_ex_ma: direction mode 2 (separate turning actions) is not implemented")
   if cfg["map_width"] is not None or cfg["map_height"] is not None:
@@ -756,6 +765,7 @@ def _savanna_spec(kwargs):
   A = int(cfg["amount_agents"])
   if A not in (1, 2):
     raise NotImplementedError("aintelope_savanna: amount_agents must be 1 or 2 (the reference's AGENT_CHRS)")
+  _check_regrowth_exponent("DRINK_REGROWTH_EXPONENT", cfg["DRINK_REGROWTH_EXPONENT"])
   if cfg["thirst_hunger_death"]:
     raise NotImplementedError("aintelope_savanna: thirst_hunger_death raises NameError in the reference "
                               "(safety_game_moma.py:1636 refers to safety_game_ma, which is never imported)")

@@ -128,3 +128,25 @@ def test_savanna_hip_matches_oracle_fresh_seed(kw, E, T, resets):
   want["step_type"] = want["step_type"].astype(np.uint8)
   want["term_reason"] = want["term_reason"].astype(np.int16)
   check("fresh", got, want, spec.K, spec.n_agents)
+
+
+def test_savanna_long_streams_match_oracle():
+  """~10^6 rounds: rare paths (tile floods, predators on agents, long regrowth chains, many map generations) against the
+  oracle; boards, rewards, metrics and the generator position of every tick."""
+  from oracle import oracle_ma as OM
+  from oracle import oracle_sav as OS
+  kw = dict(amount_agents=2, sustainability_challenge=True, penalise_oversatiation=True, use_satiation_proportional_reward=True,
+            max_iterations=150, amount_predators=4, amount_water_tiles=4, amount_gold_deposits=3, amount_silver_deposits=3,
+            amount_small_food_patches=2, amount_drink_holes=3, amount_small_drink_holes=2, observation_radius=[1, 1, 1, 1])
+  E, T = 3000, 330
+  actions = np.stack([philox.actions(0xBEEF, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(2)], axis=-1)
+  actions = np.transpose(actions, (1, 0, 2)).astype(np.int8).copy()
+  actions[:, 100, :] = RESET; actions[:, 101, :] = RESET; actions[:, 250, :] = RESET
+  rng = np.stack([OM.rng_state_words(50000 + e) for e in range(E)])
+  want = dict(OS.run_streams(OS.make_config(**kw), actions, rng, nthreads=16))
+  spec = make_spec("aintelope_savanna", **kw)
+  got = run(spec, actions, rng)
+  want["step_type"] = want["step_type"].astype(np.uint8)
+  want["term_reason"] = want["term_reason"].astype(np.int16)
+  check("long", got, want, spec.K, spec.n_agents)
+

@@ -85,6 +85,8 @@ def test_spec_errors_mirror_the_reference():
   with pytest.raises(ValueError, match="unknown reward dimensions"):
     make_spec("island_navigation_ex", MOVEMENT_REWARD={"SOME_OTHER_DIM": -1})
   g = make_spec("island_navigation_ex", DRINK_REWARD={"DRINK_REWARD": 2.0, "FOOD_REWARD": -1.0})   # one event, two dimensions
+  with pytest.raises(NotImplementedError, match="device pow"):     # csrc/sgw_pow.hpp: glibc's main path only
+    make_spec("island_navigation_ex", DRINK_REGROWTH_EXPONENT=0.0)
   assert g.native.flags & 16 and g.family_table.shape == (195,) and g.family_table[3 * 12 + 7] == -1.0
   s = make_spec("island_navigation_ex", movement_reward="{'MOVEMENT_REWARD': -2.5}", GOLD_REWARD={"GOLD_REWARD": 0})
   assert "GOLD_REWARD" not in s.dim_names and s.K == 9          # zero units drop out (mo_reward.py:131-135)
