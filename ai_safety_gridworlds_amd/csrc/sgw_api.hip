@@ -536,6 +536,7 @@ int sgw_set_state(sgw_engine* e, const uint64_t* state_dev, void* stream) {
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipMemcpyAsync(e->state_dev, state_dev, (size_t)sgw_state_bytes(e), hipMemcpyDeviceToDevice,
                          (hipStream_t)stream));
+  e->rng_set = 1;          // a saved state carries its envs' generator streams (resume needs no sgw_set_rng_state)
   return SGW_OK;
 }
 
