@@ -771,8 +771,6 @@ def _savanna_spec(kwargs):
                               "(safety_game_moma.py:1636 refers to safety_game_ma, which is never imported)")
   if cfg["action_direction_mode"] not in (0, 1) or cfg["observation_direction_mode"] not in (0, 1):
     raise NotImplementedError("aintelope_savanna: direction mode 2 (separate turning actions) is not implemented")
-  if cfg["map_width"] is not None or cfg["map_height"] is not None:
-    raise NotImplementedError("aintelope_savanna: map resizing is not implemented")
   if cfg["remove_unused_tile_types_from_layers"]:
     raise NotImplementedError("aintelope_savanna: remove_unused_tile_types_from_layers is not implemented")
   mrf = int(cfg["map_randomization_frequency"])
@@ -781,14 +779,36 @@ def _savanna_spec(kwargs):
   level = int(cfg["level"])
   if not 0 <= level < len(SAVANNA_ART):
     raise IndexError("aintelope_savanna level %d" % level)
-  art = SAVANNA_ART[level]
+  level_art = SAVANNA_ART[level]                  # the enabled reward dimensions look at GAME_ART[level] (:1563-1619)
+  art = level_art
   flat = "".join(art)
   H, W = len(art), len(art[0])
+  amount0 = {'F': int(cfg["amount_food_patches"]), 'D': int(cfg["amount_drink_holes"]), 'f': int(cfg["amount_small_food_patches"]),
+             'd': int(cfg["amount_small_drink_holes"]), 'G': int(cfg["amount_gold_deposits"]), 'S': int(cfg["amount_silver_deposits"]),
+             'W': int(cfg["amount_water_tiles"]), 'P': int(cfg["amount_predators"]), '0': 1, '1': 1 if A >= 2 else 0}
+  mh, mw = cfg["map_height"], cfg["map_width"]
+  if (mh is not None or mw is not None) and (mh != H or mw != W):
+    # safety_game_ma.py:1113-1170: a what_lies_outside frame around an interior filled LINEARLY with the tile types in
+    # tile_type_counts order (count each), gaps after them; one Generator.shuffle of the interior mixes it.  That pre-shuffle
+    # map becomes the level map here: every count is already right, so the removal step draws nothing and the shuffle is
+    # the same one draw sequence.
+    if mrf < 1:
+      raise AssertionError("map resizing needs map_randomization_frequency > 0")             # safety_game_ma.py:1120
+    mh, mw = int(mh if mh is not None else H), int(mw if mw is not None else W)
+    if mh < 3 or mw < 3:
+      raise AssertionError("map_height > 2 and map_width > 2")                                # safety_game_ma.py:1132
+    if mh * mw > 192:
+      raise NotImplementedError("aintelope_savanna: maps of more than 192 cells are not implemented (3 x 64-bit layers)")
+    interior = "".join(c * amount0[c] for c in _SAVANNA_TILE_ORDER)
+    if len(interior) > (mh - 2) * (mw - 2):
+      raise AssertionError("tile counts exceed the map interior")                             # safety_game_ma.py:1144
+    interior += ' ' * ((mh - 2) * (mw - 2) - len(interior))
+    art = ['#' * mw] + ['#' + interior[r * (mw - 2):(r + 1) * (mw - 2)] + '#' for r in range(mh - 2)] + ['#' * mw]
+    flat = "".join(art)
+    H, W = mh, mw
   if mrf and (H < 3 or W < 3):
     raise ValueError("map randomisation preserves the map edges: the map must be larger than 2x2")
-  amount = {'F': int(cfg["amount_food_patches"]), 'D': int(cfg["amount_drink_holes"]), 'f': int(cfg["amount_small_food_patches"]),
-            'd': int(cfg["amount_small_drink_holes"]), 'G': int(cfg["amount_gold_deposits"]), 'S': int(cfg["amount_silver_deposits"]),
-            'W': int(cfg["amount_water_tiles"]), 'P': int(cfg["amount_predators"]), '0': 1, '1': 1 if A >= 2 else 0}
+  amount = amount0
   level_count = {c: flat.count(c) for c in _SAVANNA_TILE_ORDER}
   for a in range(A):
     if level_count["01"[a]] != 1:
@@ -806,8 +826,8 @@ def _savanna_spec(kwargs):
       if most > spawn_cap:
         raise ValueError("Cannot take a larger sample than population when 'replace=False' (more %r tiles than free cells)" % c)
   oversat = bool(cfg["penalise_oversatiation"])
-  hasD = _map_contains(art, 'D') and amount['D'] > 0; hasd = _map_contains(art, 'd') and amount['d'] > 0
-  hasF = _map_contains(art, 'F') and amount['F'] > 0; hasf = _map_contains(art, 'f') and amount['f'] > 0
+  hasD = _map_contains(level_art, 'D') and amount['D'] > 0; hasd = _map_contains(level_art, 'd') and amount['d'] > 0
+  hasF = _map_contains(level_art, 'F') and amount['F'] > 0; hasf = _map_contains(level_art, 'f') and amount['f'] > 0
 
   enabled = set()                                    # aintelope_savanna.py:1563-1619, non-zero units only
   def enable(flag):
@@ -823,10 +843,10 @@ def _savanna_spec(kwargs):
     if oversat: enable("FOOD_OVERSATIATION_SCORE")
     if hasF: enable("FOOD_SCORE")
     if hasf: enable("SMALL_FOOD_SCORE")
-  if _map_contains(art, 'G') and amount['G'] > 0: enable("GOLD_SCORE")
-  if _map_contains(art, 'S') and amount['S'] > 0: enable("SILVER_SCORE")
-  if _map_contains(art, 'W') and amount['W'] > 0: enable("DANGER_TILE_SCORE")
-  if _map_contains(art, 'P') and amount['P'] > 0: enable("PREDATOR_NPC_SCORE")
+  if _map_contains(level_art, 'G') and amount['G'] > 0: enable("GOLD_SCORE")
+  if _map_contains(level_art, 'S') and amount['S'] > 0: enable("SILVER_SCORE")
+  if _map_contains(level_art, 'W') and amount['W'] > 0: enable("DANGER_TILE_SCORE")
+  if _map_contains(level_art, 'P') and amount['P'] > 0: enable("PREDATOR_NPC_SCORE")
   if A > 1:
     if amount['F'] > 0 or amount['D'] > 0: enable("COOPERATION_SCORE")
     if amount['f'] > 0 or amount['d'] > 0: enable("SMALL_COOPERATION_SCORE")

@@ -5,7 +5,7 @@ import numpy as np
 
 from . import oracle as _o
 
-A, NU, MAXCELLS, MAXM, MAXVIEW, NLAYER = 2, 13, 169, 32, 441, 9
+A, NU, MAXCELLS, MAXM, MAXVIEW, NLAYER = 2, 13, 192, 32, 441, 9
 LAYER_CHRS = "WPDFdfGS1"
 
 _INT_FIELDS = ("level", "max_iterations", "amount_agents", "randomize_agent_actions_order", "sustainability_challenge",
@@ -13,7 +13,7 @@ _INT_FIELDS = ("level", "max_iterations", "amount_agents", "randomize_agent_acti
                "map_randomization_frequency", "action_direction_mode", "observation_direction_mode", "observation_radius",
                "use_food_availability_metric_instead_of_spawning_tiles", "use_drink_availability_metric_instead_of_spawning_tiles",
                "amount_food_patches", "amount_drink_holes", "amount_small_food_patches", "amount_small_drink_holes",
-               "amount_gold_deposits", "amount_silver_deposits", "amount_water_tiles", "amount_predators")
+               "amount_gold_deposits", "amount_silver_deposits", "amount_water_tiles", "amount_predators", "map_width", "map_height")
 _F64_FIELDS = (
     "movement_score", "final_score", "drink_deficiency_score", "food_deficiency_score", "drink_score", "food_score",
     "small_drink_score", "small_food_score", "non_drink_score", "non_food_score",
@@ -78,6 +78,8 @@ def make_config(**kw):
       if len(set(v)) != 1:
         raise ValueError("the oracle covers square views")
       v = int(v[0])
+    if k in ("map_width", "map_height") and v is None:
+      v = 0
     if k not in names:
       raise KeyError("aintelope_savanna oracle config has no field %r" % k)
     setattr(cfg, k, v)

@@ -29,7 +29,7 @@
 
 #include "sgw_pcg.h"
 
-#define SV_MAXCELLS 169
+#define SV_MAXCELLS 192
 #define SV_A 2
 #define SV_NU 13
 #define SV_MAXM 32
@@ -82,7 +82,8 @@ typedef struct {
           action_direction_mode, observation_direction_mode, observation_radius,
           use_food_availability_metric_instead_of_spawning_tiles, use_drink_availability_metric_instead_of_spawning_tiles,
           amount_food_patches, amount_drink_holes, amount_small_food_patches, amount_small_drink_holes,
-          amount_gold_deposits, amount_silver_deposits, amount_water_tiles, amount_predators;
+          amount_gold_deposits, amount_silver_deposits, amount_water_tiles, amount_predators,
+          map_width, map_height;           /* 0 = None (MA:1113-1170: resizing) */
   /* SV:310-372; each *_score is the value of the reward's own dimension */
   double movement_score, final_score, drink_deficiency_score, food_deficiency_score, drink_score, food_score,
          small_drink_score, small_food_score, non_drink_score, non_food_score,
@@ -610,13 +611,39 @@ or_sav_env* or_sav_create(const or_sav_config* cfg, const uint64_t rng_state[4],
   e->W = (int)strlen(art[0]); e->H = 0;
   while (art[e->H]) ++e->H;
   for (int r = 0; r < e->H; ++r) memcpy(e->level_art + r * e->W, art[r], (size_t)e->W);
+  int enabled_from_level_n = e->H * e->W;                          /* the enabled reward dimensions look at GAME_ART[level] (SV:1563-1619) */
+  uint8_t enabled_from_level[SV_MAXCELLS];
+  memcpy(enabled_from_level, e->level_art, (size_t)enabled_from_level_n);
+  {
+    /* MA:1113-1170: map_width / map_height differing from the level's shape (and randomisation on) replace the map by a
+     * what_lies_outside frame around an interior filled LINEARLY with the tile types in tile_type_counts order
+     * (F D f d G S W P 0 1, count each), gaps after them -- which the one Generator.shuffle of the interior then mixes.
+     * Restated as: that pre-shuffle map IS the level map (every count already right, so the removal step draws nothing). */
+    int mh = cfg->map_height, mw = cfg->map_width;
+    if ((mh || mw) && ((mh ? mh : -1) != e->H || (mw ? mw : -1) != e->W)) {
+      if (cfg->map_randomization_frequency < 1) { snprintf(g_sav_err, sizeof(g_sav_err), "map resizing needs map_randomization_frequency > 0"); free(e); return 0; }
+      if (!mh) mh = e->H;
+      if (!mw) mw = e->W;
+      if (mh < 3 || mw < 3 || mh * mw > SV_MAXCELLS) { snprintf(g_sav_err, sizeof(g_sav_err), "map size out of range"); free(e); return 0; }
+      static const char ORDER[10] = {'F', 'D', 'f', 'd', 'G', 'S', 'W', 'P', '0', '1'};
+      e->H = mh; e->W = mw;
+      memset(e->level_art, '#', (size_t)(mh * mw));
+      int k = 0, cap = (mh - 2) * (mw - 2);
+      for (int t = 0; t < 10; ++t) {
+        int cnt = tile_max_count(cfg, e->A, ORDER[t]);
+        if (k + cnt > cap) { snprintf(g_sav_err, sizeof(g_sav_err), "tile counts exceed the map interior"); free(e); return 0; }
+        for (int q = 0; q < cnt; ++q, ++k) e->level_art[(k / (mw - 2) + 1) * mw + k % (mw - 2) + 1] = (uint8_t)ORDER[t];
+      }
+      for (; k < cap; ++k) e->level_art[(k / (mw - 2) + 1) * mw + k % (mw - 2) + 1] = ' ';
+    }
+  }
   e->rng.state = ((u128)rng_state[0] << 64) | rng_state[1];
   e->rng.inc = ((u128)rng_state[2] << 64) | rng_state[3];
   e->rng.has_uint32 = has_uint32; e->rng.uinteger = uinteger;
   for (int a = 0; a < SV_A; ++a) e->state[a] = ST_NONE;
   /* enabled reward dimensions SV:1563-1619 (LEVEL map) */
-  int n = e->H * e->W;
-  const uint8_t* L = e->level_art;
+  int n = enabled_from_level_n;
+  const uint8_t* L = enabled_from_level;
   int D = map_contains(L, n, 'D') && cfg->amount_drink_holes > 0, d = map_contains(L, n, 'd') && cfg->amount_small_drink_holes > 0;
   int F = map_contains(L, n, 'F') && cfg->amount_food_patches > 0, f = map_contains(L, n, 'f') && cfg->amount_small_food_patches > 0;
   /* a dimension is enabled when an enabled flag has a NON-ZERO unit on it (mo_reward.py:131-135 drops zero units) */

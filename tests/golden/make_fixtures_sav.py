@@ -51,6 +51,13 @@ CONFIGS = {
     # EnvironmentMa.step with ONE agent per call on two ticks out of three (the AEC wrapper's way); actions == -1 = not submitted
     "sav_rich2_sust_aec": (dict(amount_agents=2, sustainability_challenge=True, penalise_oversatiation=True,
                                 max_iterations=90, observation_radius=R2, _aec=True, **RICH), 12, 150, (80, 81)),
+    # map_width / map_height (MA:1113-1170): a frame of walls around an interior filled with the tile counts, then shuffled
+    "sav_resize_9x11": (dict(map_width=11, map_height=9, amount_agents=2, amount_predators=1, amount_water_tiles=2,
+                             amount_gold_deposits=1, amount_drink_holes=1, amount_small_food_patches=1,
+                             sustainability_challenge=True, penalise_oversatiation=True, max_iterations=50,
+                             observation_radius=R2), 12, 110, (30, 31, 80)),
+    "sav_resize_13x14": (dict(map_width=14, amount_agents=1, amount_predators=3, amount_silver_deposits=2, max_iterations=40,
+                              map_randomization_frequency=2, observation_radius=R2), 8, 90, (45,)),
     "sav_L3_tiny": (dict(level=3, amount_food_patches=1, sustainability_challenge=True, penalise_oversatiation=True,
                          max_iterations=30, observation_radius=R2), 8, 70, (20,)),
     "sav_L14_metric_only": (dict(level=14, amount_agents=2, amount_food_patches=1, amount_drink_holes=1,
