@@ -85,6 +85,17 @@ class GridworldGymEnv(_Base):
     self._env_name = env_name
     self._env = BatchedSafetyEnvironment(env_name, num_envs=1, device=device, **kwargs)
     self.spec_ = self._env.spec
+    # multi-agent env behind the single-agent wrapper (gym_env.py:182-189, 476-479): ONE agent is controlled -- the given
+    # `agent_character` or the first player -- and stepped alone ({agent: action}); the state is that agent's window
+    self._ma = bool(getattr(self.spec_, "per_agent", False))
+    if self.spec_.A > 1 and not self._ma:
+      raise NotImplementedError("%s: the batched engine plays whole rounds of this env (use GridworldZooParallelEnv)" % env_name)
+    if self._ma:
+      chars = list(self.spec_.agent_chars)
+      self._agent_index = chars.index(agent_character) if agent_character is not None else 0
+      self._ma_ascii = bool(ascii_observation_format)
+      self._vm = np.array([self.spec_.native.value_map[i] for i in range(128)], np.float32)
+      self._seed_env(seed)
     self._use_transitions = use_transitions
     self._flatten_observations = flatten_observations
     self._layers_in_observation = layers_in_observation
@@ -118,6 +129,15 @@ class GridworldGymEnv(_Base):
   def seed(self, seed=None):                     # gym_env.py:706-712
     self._internal_np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
     self._action_space._rng = self._internal_np_random
+    if self._ma:
+      self._seed_env(seed)
+
+  def _seed_env(self, seed):                     # environment_data[NP_RANDOM] = seeding.np_random(seed)[0]
+    if getattr(self.spec_, "needs_rng", False):
+      st = np.random.PCG64(np.random.SeedSequence(seed)).state["state"]
+      m = (1 << 64) - 1
+      self._env.engine.set_rng_state(np.array([[st["state"] >> 64, st["state"] & m, st["inc"] >> 64, st["inc"] & m]],
+                                              dtype=np.uint64))
 
   def close(self):
     self._env.close()
@@ -133,14 +153,15 @@ class GridworldGymEnv(_Base):
   def _compute_info(self, o, first):
     sp = self.spec_
     K = sp.K
-    reward = o["reward"].reshape(-1)[:K]
-    cum = o["cumulative"].reshape(-1)[:K]
+    ai = self._agent_index if self._ma else 0
+    reward = o["reward"].reshape(-1)[ai * K:(ai + 1) * K]
+    cum = o["cumulative"].reshape(-1)[ai * K:(ai + 1) * K]
     frame = int(o["frame"])
     extra = {}
     if int(o["actual_action"].reshape(-1)[0]) >= 0:
       extra["actual_actions"] = int(o["actual_action"].reshape(-1)[0])
-    if int(o["step_type"].reshape(-1)[0]) == N.LAST:
-      extra["termination_reason"] = TerminationReason(int(o["term_reason"]))
+    if int(o["step_type"].reshape(-1)[ai]) == N.LAST:
+      extra["termination_reason"] = TerminationReason(int(o["term_reason"].reshape(-1)[ai]))
     info = {
         "observation_direction": None, "action_direction": DIRECTION_UP,
         "board": o["obs_board"].copy(), "ascii_codes": o["board"].copy(),
@@ -172,6 +193,9 @@ class GridworldGymEnv(_Base):
 
   def _state_from(self, o, first):
     board = o["obs_board"].copy()                # fresh copy (gym_env.py:525, Q16)
+    if self._ma:                                 # the controlled agent's window, ascii by default (gym_env.py:537-553)
+      view = self._env.engine.agent_views()[self._agent_index][0].cpu().numpy()
+      board = np.vectorize(chr)(view) if self._ma_ascii else self._vm[view]
     if self._use_transitions:
       prev = np.zeros_like(board) if first else self._last_board
       state = np.stack([prev, board], axis=0)
@@ -207,10 +231,15 @@ class GridworldGymEnv(_Base):
     if a.size != 1:                              # pycolab_interface_mo.py:168-171
       raise RuntimeError("A pycolab Environment adapter's step method was called with actions that were "
                          "not compatible with what the pycolab game expects.")
-    ts = self._env.step(torch.tensor([int(a.reshape(-1)[0])], dtype=torch.int8))
-    o = self._host(ts)
     sp = self.spec_
-    first = int(o["step_type"].reshape(-1)[0]) == N.FIRST          # auto-reset step: reward None -> 0.0
+    acts = [int(a.reshape(-1)[0])]
+    if self._ma:                                 # {agent: action}: the other agents are not in the dict (gym_env.py:476-479)
+      acts = [-1] * sp.A
+      acts[self._agent_index] = int(a.reshape(-1)[0])
+    ts = self._env.step(torch.tensor(acts, dtype=torch.int8))
+    o = self._host(ts)
+    ai = self._agent_index if self._ma else 0
+    first = int(o["step_type"].reshape(-1)[ai]) == N.FIRST         # auto-reset step: reward None -> 0.0
     info = self._compute_info(o, first)
     if first:
       reward = 0.0
@@ -218,7 +247,7 @@ class GridworldGymEnv(_Base):
       r = float(o["reward"].reshape(-1)[0])
       reward = int(r) if r == int(r) else r
     else:
-      reward = o["reward"].reshape(-1)[:sp.K].astype(np.float64).copy()
+      reward = o["reward"].reshape(-1)[ai * sp.K:(ai + 1) * sp.K].astype(np.float64).copy()
     if sp.scalar:                                # gym_env.py:498-505
       cumulative_hidden = float(o["hidden"])
       hidden_reward = cumulative_hidden - self._last_hidden_reward
@@ -229,7 +258,7 @@ class GridworldGymEnv(_Base):
     info.update({INFO_HIDDEN_REWARD: hidden_reward, INFO_OBSERVED_REWARD: reward,
                  INFO_DISCOUNT: None if np.isnan(disc) else disc})
     state = self._state_from(o, first)
-    done = int(o["step_type"].reshape(-1)[0]) == N.LAST
+    done = int(o["step_type"].reshape(-1)[ai]) == N.LAST
     self._cumulative_reward = self._cumulative_reward + reward
     result = (state, reward, done, False, info)
     if self._post_step_callback is not None:

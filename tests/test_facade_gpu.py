@@ -246,6 +246,31 @@ def test_savanna_through_the_zoo_aec_facade():
     GridworldZooAecEnv("firemaker_ex_ma", amount_agents=3)
 
 
+def test_savanna_single_agent_through_the_gym_facade():
+  """The Gym wrapper over a multi-agent env controls one agent and steps it alone ({agent: action}, gym_env.py:476-479);
+  the returned state is that agent's window.  A one-agent aintelope_savanna stream of a reference fixture."""
+  fx, meta = G.load("sav_rich1_prop")
+  e = 2
+  env = GridworldGymEnv("aintelope_savanna", seed=int(fx["seeds"][e]), **meta["kwargs"])
+  state, info = env.reset()
+  state, info = env.reset()
+  assert state.shape == (1, 5, 5) and state.dtype.kind == "U"
+  assert np.array_equal(state[0], np.vectorize(chr)(fx["view"][e, 1, 0]))
+  for t in range(fx["actions"].shape[1]):
+    a = int(fx["actions"][e, t, 0])
+    if a == -128:
+      state, info = env.reset()
+    else:
+      state, reward, terminated, truncated, info = env.step(a)
+      st = int(fx["step_type"][e, t + 2, 0])
+      assert terminated == (st == 2) and truncated is False
+      if st != 0:
+        assert np.array_equal(reward, fx["reward"][e, t + 2, 0])
+        assert list(info["reward_dict"]) == meta["dim_names"]
+    assert np.array_equal(state[0], np.vectorize(chr)(fx["view"][e, t + 2, 0]))
+    assert np.array_equal(info["ascii_codes"], fx["board"][e, t + 2])
+
+
 def test_step_logger_reproduces_the_reference_csv(tmp_path):
   """the CSV step log of one island_navigation_ex env, byte for byte against the file the reference wrote
   for the same action stream (tests/golden/island_L9_steplog.csv, make_fixtures_log.py)."""
