@@ -246,6 +246,40 @@ def test_savanna_through_the_zoo_aec_facade():
     GridworldZooAecEnv("firemaker_ex_ma", amount_agents=3)
 
 
+def test_island_ma_through_the_zoo_aec_facade_until_every_agent_is_done():
+  """island_navigation_ex_ma one agent at a time: agents finish individually (water, max_iterations), a finished agent takes its
+  dead step and leaves, the other plays on alone; the recorded (agent, action) sequence replayed by the oracle gives the
+  same boards, rewards and per-agent step types."""
+  from ai_safety_gridworlds_amd.helpers.gridworld_zoo_aec_env import GridworldZooAecEnv
+  from oracle import oracle_ima as OI
+  from oracle import oracle_ma as OM
+  kw = dict(level=9, max_iterations=30, penalise_oversatiation=True)
+  for seed in (5, 6, 7, 8):
+    env = GridworldZooAecEnv("island_navigation_ex_ma", seed=seed, **kw)
+    env.reset(); env.reset()
+    rnd = np.random.default_rng(seed)
+    record, boards, rewards, dead_steps = [], [], [], 0
+    for agent in env.agent_iter(max_iter=200):
+      obs, cum, term, trunc, info = env.last()
+      if term or trunc:
+        env.step(None); dead_steps += 1
+        continue
+      a = int(rnd.integers(0, 5))
+      i = env.possible_agents.index(agent)
+      env.step(a)
+      record.append((i, a)); boards.append(env.state[0].copy()); rewards.append(np.asarray(env.rewards[agent]).copy())
+    assert env.agents == [] and dead_steps == 2 and len(record) >= 2
+    T = len(record)
+    actions = np.full((1, T, 2), -1, np.int8)
+    for t, (i, a) in enumerate(record):
+      actions[0, t, i] = a
+    want = OI.run_streams(OI.make_config(**kw), actions, np.stack([OM.rng_state_words(seed)]))
+    for t, (i, a) in enumerate(record):
+      assert np.array_equal(boards[t], np.vectorize(chr)(want["board"][0, t + 2])), (seed, t)
+      assert np.array_equal(rewards[t], want["reward"][0, t + 2, i]), (seed, t)
+    assert (want["step_type"][0, T + 1] >= 2).all()            # both agents finished exactly where the AEC loop stopped
+
+
 def test_savanna_single_agent_through_the_gym_facade():
   """The Gym wrapper over a multi-agent env controls one agent and steps it alone ({agent: action}, gym_env.py:476-479);
   the returned state is that agent's window.  A one-agent aintelope_savanna stream of a reference fixture."""
