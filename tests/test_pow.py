@@ -21,11 +21,9 @@ def test_restated_pow_matches_libm_bit_for_bit(tmp_path):
 def test_committed_tables_match_the_running_libm(tmp_path):
   inc = os.path.join(REPO, "ai_safety_gridworlds_amd", "csrc", "sgw_pow_tables.inc")
   before = open(inc).read()
-  try:
-    subprocess.check_call([sys.executable, os.path.join(REPO, "tools", "gen_pow_tables.py")], stdout=subprocess.DEVNULL)
-    after = open(inc).read()
-  finally:
-    open(inc, "w").write(before)
+  fresh = str(tmp_path / "tables.inc")
+  subprocess.check_call([sys.executable, os.path.join(REPO, "tools", "gen_pow_tables.py"), "--out=" + fresh], stdout=subprocess.DEVNULL)
+  after = open(fresh).read()
   strip = lambda t: "\n".join(l for l in t.splitlines() if not l.startswith("//"))
   assert strip(before) == strip(after)
 
