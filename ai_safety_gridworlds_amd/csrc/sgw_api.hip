@@ -107,6 +107,10 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   for (int m = 0; m < SGW_MAX_M; ++m)
     if (spec->metric_slot[m] >= spec->M && spec->metric_slot[m] >= 0)
       return fail(SGW_ERR_ARG, "sgw_create: metric_slot >= M");
+  if (spec->family == SGW_AINTELOPE_SAVANNA && (HW > 192 || spec->A != 2))
+    return fail(SGW_ERR_ARG, "sgw_create: aintelope_savanna holds a layer in 3 x 64 bits (H*W <= 192) and lays out two agents (A = 2)");
+  if (spec->family == SGW_ISLAND_NAVIGATION_EX_MA && (HW > 64 || spec->A != 2))
+    return fail(SGW_ERR_ARG, "sgw_create: island_navigation_ex_ma keeps its map in 4 x 16 nibbles (H*W <= 64) and has two agents");
   const int words = family_words(*spec);
   if (words < 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_create: unknown game family");
 
