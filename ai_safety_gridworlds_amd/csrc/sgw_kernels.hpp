@@ -7,12 +7,17 @@
 //                                                                    safety_game_mo.py:971-1066
 #pragma once
 
+#include <type_traits>
+
 #include "sgw_common.hpp"
 #include "sgw_pow.hpp"
 
 namespace sgw {
 
 constexpr int TERM_NONE4 = 15;   // 4-bit in-state encoding of "termination_reason key absent"
+
+template <class F, class = void> struct has_board_prepare : std::false_type {};
+template <class F> struct has_board_prepare<F, std::void_t<typename F::BoardPrep>> : std::true_type {};
 
 template <class F>
 __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU], double discount,
@@ -26,9 +31,11 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
 
   // ---- phase 1: every lane writes its rows into the (disjoint) LDS staging regions
   lds_wave_sync();                                        // previous step's cooperative reads are done (program order)
-  if (want_board && (HW & 3)) { lds_zero_board(l.board, HW); lds_wave_sync(); }
   if (want_board) {
-    if constexpr (F::CUSTOM_BOARD) {
+    if constexpr (has_board_prepare<F>::value) {        // per-step precomputation shared by every dword of the row
+      const auto bp = F::board_prepare(s, sp);
+      lds_write_board_row_fn(l.board, HW, lane, [&](int i) { return F::board_dword(bp, s, sp, i); });
+    } else if constexpr (F::CUSTOM_BOARD) {
       lds_write_board_row_fn(l.board, HW, lane, [&](int i) { return F::board_dword(s, sp, l, i); });
     } else {
       int cells[F::NSPRITE]; uint8_t chars[F::NSPRITE];
@@ -177,6 +184,10 @@ __global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
 
   const int TT = (KIND == K_STEP) ? 1 : a.T;
   for (int t = 0; t < TT; ++t) {
+    // fused rollout: a compiler memory barrier per step keeps loop-invariant LDS reads (the family constants) from being
+    // hoisted into registers for the whole loop -- 76 VGPRs in island_navigation_ex_ma, enough to put that instantiation
+    // at 256 VGPRs + 150 AGPRs + 330 SGPR spills
+    if (KIND == K_ROLLOUT) asm volatile("" ::: "memory");
     double r[F::NU];
 #pragma unroll
     for (int u = 0; u < F::NU; ++u) r[u] = 0.0;

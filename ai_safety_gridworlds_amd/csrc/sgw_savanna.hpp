@@ -580,26 +580,34 @@ struct Savanna {
     return 1.0;
   }
 
-  // rendered board: seven bit planes of the top character of every cell (z-order W P D F d f G S, agents on top), four
-  // cells per dword
-  static __device__ __forceinline__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds& l, int i) {
+  // rendered board: bit planes of the top character of every cell (z-order W P D F d f G S, agents on top), computed once
+  // per step for the three 64-cell words; a dword of the row is then four cells cut out of the planes
+  struct BoardPrep { uint64_t b0[3], b1[3], b2[3], b4[3], b5[3], b6[3]; };
+  static __device__ __forceinline__ BoardPrep board_prepare(const State& s, const KSpec& sp) {
+    BoardPrep bp;
+#pragma unroll
+    for (int wi = 0; wi < 3; ++wi) {
+      const uint64_t wall = b3_word(s.wall, wi), wW = b3_word(s.water, wi), wP = b3_word(s.dyn[L_P], wi), wD = b3_word(s.dyn[L_D], wi),
+                     wF = b3_word(s.dyn[L_F], wi), wd = b3_word(s.dyn[L_SD], wi), wf = b3_word(s.dyn[L_SF], wi),
+                     wG = b3_word(s.gold, wi), wS = b3_word(s.silver, wi);
+      // exclusive masks, top first
+      const uint64_t xS = wS, xG = wG & ~wS, c1 = wS | wG, xf = wf & ~c1, c2 = c1 | wf, xd = wd & ~c2, c3 = c2 | wd,
+                     xF = wF & ~c3, c4 = c3 | wF, xD = wD & ~c4, c5 = c4 | wD, xP = wP & ~c5, c6 = c5 | wP, xW = wW & ~c6,
+                     c7 = c6 | wW, xwall = wall & ~c7, xgap = ~(c7 | wall);
+      // characters: ' ' 20  '#' 23  W 57  P 50  D 44  F 46  d 64  f 66  G 47  S 53
+      bp.b0[wi] = xwall | xW | xG | xS;
+      bp.b1[wi] = xwall | xW | xF | xf | xG | xS;
+      bp.b2[wi] = xW | xD | xF | xd | xf | xG;
+      bp.b4[wi] = xW | xP | xS;
+      bp.b5[wi] = xgap | xwall | xd | xf;
+      bp.b6[wi] = xW | xP | xD | xF | xd | xf | xG | xS;
+    }
+    return bp;
+  }
+  static __device__ __forceinline__ uint32_t board_dword(const BoardPrep& bp, const State& s, const KSpec& sp, int i) {
     const int wi = i >> 4, sh = (i & 15) * 4;
-    const uint64_t wall = b3_word(s.wall, wi), wW = b3_word(s.water, wi), wP = b3_word(s.dyn[L_P], wi), wD = b3_word(s.dyn[L_D], wi),
-                   wF = b3_word(s.dyn[L_F], wi), wd = b3_word(s.dyn[L_SD], wi), wf = b3_word(s.dyn[L_SF], wi),
-                   wG = b3_word(s.gold, wi), wS = b3_word(s.silver, wi);
-    // exclusive masks, top first
-    const uint64_t xS = wS, xG = wG & ~wS, c1 = wS | wG, xf = wf & ~c1, c2 = c1 | wf, xd = wd & ~c2, c3 = c2 | wd,
-                   xF = wF & ~c3, c4 = c3 | wF, xD = wD & ~c4, c5 = c4 | wD, xP = wP & ~c5, c6 = c5 | wP, xW = wW & ~c6,
-                   c7 = c6 | wW, xwall = wall & ~c7, xgap = ~(c7 | wall);
-    // characters: ' ' 20  '#' 23  W 57  P 50  D 44  F 46  d 64  f 66  G 47  S 53
-    const uint64_t b0 = xwall | xW | xG | xS;
-    const uint64_t b1 = xwall | xW | xF | xf | xG | xS;
-    const uint64_t b2 = xW | xD | xF | xd | xf | xG;
-    const uint64_t b4 = xW | xP | xS;
-    const uint64_t b5 = xgap | xwall | xd | xf;
-    const uint64_t b6 = xW | xP | xD | xF | xd | xf | xG | xS;
-    const uint32_t n0 = (uint32_t)(b0 >> sh) & 15u, n1 = (uint32_t)(b1 >> sh) & 15u, n2 = (uint32_t)(b2 >> sh) & 15u,
-                   n4 = (uint32_t)(b4 >> sh) & 15u, n5 = (uint32_t)(b5 >> sh) & 15u, n6 = (uint32_t)(b6 >> sh) & 15u;
+    auto pick = [&](const uint64_t (&p)[3]) { return (uint32_t)((wi == 0 ? p[0] : (wi == 1 ? p[1] : p[2])) >> sh) & 15u; };
+    const uint32_t n0 = pick(bp.b0), n1 = pick(bp.b1), n2 = pick(bp.b2), n4 = pick(bp.b4), n5 = pick(bp.b5), n6 = pick(bp.b6);
     const uint32_t SPREAD = 0x00204081u, LANES = 0x01010101u;       // nibble bit k -> bit 8k
     uint32_t v = ((n0 * SPREAD) & LANES) | (((n1 * SPREAD) & LANES) << 1) | (((n2 * SPREAD) & LANES) << 2) |
                  (((n4 * SPREAD) & LANES) << 4) | (((n5 * SPREAD) & LANES) << 5) | (((n6 * SPREAD) & LANES) << 6);
@@ -616,6 +624,9 @@ struct Savanna {
       }
     }
     return v;
+  }
+  static __device__ __forceinline__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds&, int i) {
+    return board_dword(board_prepare(s, sp), s, sp, i);
   }
   static __device__ __forceinline__ const uint8_t* board_layers(const State&, const KSpec&, const Lds& l, int (&)[2], uint8_t (&)[2]) { return l.static_board; }
 
