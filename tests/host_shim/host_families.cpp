@@ -1,0 +1,161 @@
+// TEST INFRASTRUCTURE ONLY (see hip/hip_runtime.h here): drives the per-lane family code one env at a time through the
+// same sequence k_engine runs -- load, [pre_autoreset + begin_episode | play + step bookkeeping], outputs, store -- and
+// writes what it produced to a file.  tests/test_host_families.py compares it with the reference fixtures.
+//
+//   host_families <in> <out>
+//   in : int32 family, n, T, reset_proto | sgw_spec bytes | int32 ftable_n | ftable doubles | uint64 rng[n][4] | int8 actions[n][T][A]
+//        reset_proto 1: slot 0 = reset, slot 1 = reset, then T ticks (actions[..][0] == -128: explicit reset)   (multi-agent fixtures)
+//        reset_proto 0: slot 0 = reset, then T ticks                                                            (scalar fixtures)
+//   out: per env and slot: step_type[A] int32 | frame int32 | reward[A*K] f64 | cumulative[A*K] f64 | board[HW] u8
+#define __HIPCC__ 1
+#define SGW_PLAIN_STORES 1
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../ai_safety_gridworlds_amd/csrc/sgw_island.hpp"
+#include "../../ai_safety_gridworlds_amd/csrc/sgw_island_ma.hpp"
+#include "../../ai_safety_gridworlds_amd/csrc/sgw_savanna.hpp"
+
+using namespace sgw;
+
+#include <type_traits>
+template <class F, class = void> struct has_prep : std::false_type {};
+template <class F> struct has_prep<F, std::void_t<typename F::BoardPrep>> : std::true_type {};
+
+struct Host {
+  sgw_spec spec; KArgs a; Lds l;
+  std::vector<uint8_t> tables, lds; std::vector<uint64_t> state; std::vector<double> ftable;
+  long long n, n_pad;
+};
+
+template <class F> static int words_of(const sgw_spec& sp);
+template <> int words_of<Island>(const sgw_spec& sp) { return Island::words(sp.K); }
+template <> int words_of<IslandGeneral>(const sgw_spec& sp) { return IslandGeneral::words(sp.K); }
+template <> int words_of<IslandMa>(const sgw_spec& sp) { return IslandMa::words(sp.K); }
+template <> int words_of<Savanna>(const sgw_spec& sp) { return Savanna::words(sp.K); }
+
+template <class F> static void setup(Host& h, const uint64_t* rng) {
+  const sgw_spec& sp = h.spec;
+  KSpec& k = h.a.sp;
+  std::memset(&h.a, 0, sizeof(h.a));
+  k.family = sp.family; k.H = sp.H; k.W = sp.W; k.HW = sp.H * sp.W; k.K = sp.K; k.M = sp.M; k.A = sp.A;
+  k.max_iterations = sp.max_iterations; k.flags = sp.flags; k.action_lo = sp.action_lo; k.n_actions = sp.n_actions;
+  k.words = words_of<F>(sp);
+  std::memcpy(k.start_cell, sp.start_cell, sizeof(k.start_cell));
+  std::memcpy(k.dim_slot, sp.dim_slot, sizeof(k.dim_slot));
+  std::memcpy(k.metric_slot, sp.metric_slot, sizeof(k.metric_slot));
+  h.tables.assign(TABLE_BYTES, 0);
+  std::memcpy(h.tables.data(), sp.static_board, k.HW);
+  std::memcpy(h.tables.data() + SGW_MAX_CELLS, sp.art, k.HW);
+  std::memcpy(h.tables.data() + 2 * SGW_MAX_CELLS, sp.aux, k.HW);
+  std::memcpy(h.tables.data() + 3 * SGW_MAX_CELLS, sp.value_map, 512);
+  std::memcpy(h.tables.data() + 3 * SGW_MAX_CELLS + 512, sp.params, SGW_N_PARAMS * 8);
+  h.n_pad = (h.n + 63) / 64 * 64;
+  h.state.assign((size_t)k.words * h.n_pad, 0);
+  for (long long e = 0; e < h.n_pad; ++e) h.state[e] = ((uint64_t)ST_NONE << 32) | ((uint64_t)15 << 36);      // sgw_create
+  if (rng) for (long long e = 0; e < h.n_pad; ++e) {                                                           // k_set_rng
+    const uint64_t pad[4] = {0x9E3779B97F4A7C15ull, (uint64_t)e, 0ull, 1ull};
+    for (int q = 0; q < 4; ++q) h.state[(size_t)(3 + q) * h.n_pad + e] = e < h.n ? rng[e * 4 + q] : pad[q];
+  }
+  h.a.tables = h.tables.data(); h.a.state = h.state.data(); h.a.n_pad = h.n_pad; h.a.n_envs = h.n; h.a.T = 1;
+  h.a.ftable = h.ftable.empty() ? nullptr : h.ftable.data();
+  // LDS image: the level tables, 64 board rows, and the family's extra region (island: the pow tables)
+  const size_t extra = F::LDS_EXTRA;
+  h.lds.assign(TABLE_BYTES + lds_board_bytes(k.HW) + 64 * 8 + extra + 64, 0);
+  std::memcpy(h.lds.data(), h.tables.data(), TABLE_BYTES);
+  h.l = lds_carve(h.lds.data(), k, 0);
+  if (extra) { for (int lane = 0; lane < 64; ++lane) { threadIdx.x = lane; typename F::Ctx cx; F::init_ctx(cx, h.l); } }
+}
+
+template <class F> static void emit(Host& h, const typename F::State& s, const double (&r)[F::NU], long long env, FILE* out) {
+  const KSpec& sp = h.a.sp;
+  for (int ag = 0; ag < sp.A; ++ag) {
+    int32_t st;
+    if constexpr (F::PER_AGENT) st = F::agent_step_type(s, ag); else st = s.step_type;
+    fwrite(&st, 4, 1, out);
+  }
+  int32_t fr = s.frame; fwrite(&fr, 4, 1, out);
+  std::vector<double> rew(sp.A * sp.K, 0.0), cum(sp.A * sp.K, 0.0);
+  for (int u = 0; u < F::NU; ++u) { const int sl = F::slot(sp, u); if (sl >= 0) { rew[sl] = r[u]; cum[sl] = s.cum[u]; } }
+  fwrite(rew.data(), 8, rew.size(), out); fwrite(cum.data(), 8, cum.size(), out);
+  std::vector<uint8_t> board((sp.HW + 3) / 4 * 4, 0);
+  if constexpr (has_prep<F>::value) {
+    const auto bp = F::board_prepare(s, sp);
+    for (int i = 0; i < (sp.HW + 3) / 4; ++i) { const uint32_t v = F::board_dword(bp, s, sp, i); std::memcpy(&board[4 * i], &v, 4); }
+  } else if constexpr (F::CUSTOM_BOARD) {
+    for (int i = 0; i < (sp.HW + 3) / 4; ++i) { const uint32_t v = F::board_dword(s, sp, h.l, i); std::memcpy(&board[4 * i], &v, 4); }
+  } else {
+    int cells[F::NSPRITE]; uint8_t chars[F::NSPRITE];
+    const uint8_t* base = F::board_layers(s, sp, h.l, cells, chars);
+    std::memcpy(board.data(), base, sp.HW);
+    for (int q = 0; q < F::NSPRITE; ++q) board[cells[q]] = chars[q];
+  }
+  fwrite(board.data(), 1, sp.HW, out);
+  (void)env;
+}
+
+template <class F> static void reset_env(Host& h, long long env, FILE* out) {
+  threadIdx.x = (unsigned)(env & 63);
+  typename F::State s; F::load(s, h.a, env);
+  double r[F::NU]; for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
+  h.a.mode = MODE_RESET;
+  F::begin_episode(s, h.a, h.l, env, env);
+  F::store(s, h.a, env);
+  emit<F>(h, s, r, env, out);
+}
+
+template <class F> static void step_env(Host& h, long long env, const int8_t* act, FILE* out) {   // k_engine, non-cooperative branch
+  threadIdx.x = (unsigned)(env & 63);
+  typename F::State s; F::load(s, h.a, env);
+  double r[F::NU]; for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
+  int action[F::NA]; for (int ag = 0; ag < F::NA; ++ag) action[ag] = act[ag];
+  h.a.mode = MODE_STEP;
+  if (s.step_type >= ST_LAST) {
+    F::pre_autoreset(s, h.a, action);
+    F::begin_episode(s, h.a, h.l, env, env);
+  } else {
+    const double discount = F::play(s, action, h.a, h.l, r, env);
+    const bool over = (discount == 0.0) || (s.frame >= h.a.sp.max_iterations);
+    s.step_type = over ? ST_LAST : ST_MID;
+    if (over && s.term == 15) s.term = SGW_MAX_STEPS;
+    for (int u = 0; u < F::NU; ++u) s.cum[u] += r[u];
+  }
+  F::store(s, h.a, env);
+  emit<F>(h, s, r, env, out);
+}
+
+template <class F> static int run(Host& h, int T, int proto, const uint64_t* rng, const int8_t* actions, FILE* out) {
+  setup<F>(h, rng);
+  const int A = F::NA;
+  for (long long e = 0; e < h.n; ++e) {
+    reset_env<F>(h, e, out);
+    if (proto) reset_env<F>(h, e, out);
+    for (int t = 0; t < T; ++t) {
+      const int8_t* act = actions + ((size_t)e * T + t) * A;
+      if (proto && act[0] == -128) reset_env<F>(h, e, out); else step_env<F>(h, e, act, out);
+    }
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  FILE* in = fopen(argv[1], "rb"); FILE* out = fopen(argv[2], "wb");
+  if (!in || !out) return 2;
+  int32_t hd[4]; if (fread(hd, 4, 4, in) != 4) return 2;
+  Host h; h.n = hd[1];
+  if (fread(&h.spec, sizeof(h.spec), 1, in) != 1) return 2;
+  int32_t fn; if (fread(&fn, 4, 1, in) != 1) return 2;
+  h.ftable.resize(fn); if (fn && fread(h.ftable.data(), 8, fn, in) != (size_t)fn) return 2;
+  std::vector<uint64_t> rng((size_t)h.n * 4); if (fread(rng.data(), 8, rng.size(), in) != rng.size()) return 2;
+  const int A = hd[0] == SGW_ISLAND_NAVIGATION_EX ? 1 : 2;
+  std::vector<int8_t> actions((size_t)h.n * hd[2] * A); if (fread(actions.data(), 1, actions.size(), in) != actions.size()) return 2;
+  int rc = 3;
+  if (hd[0] == SGW_ISLAND_NAVIGATION_EX) rc = (h.spec.flags & Island::F_GENERAL) ? run<IslandGeneral>(h, hd[2], hd[3], nullptr, actions.data(), out)
+                                                                                   : run<Island>(h, hd[2], hd[3], nullptr, actions.data(), out);
+  else if (hd[0] == SGW_ISLAND_NAVIGATION_EX_MA) rc = run<IslandMa>(h, hd[2], hd[3], rng.data(), actions.data(), out);
+  else if (hd[0] == SGW_AINTELOPE_SAVANNA) rc = run<Savanna>(h, hd[2], hd[3], rng.data(), actions.data(), out);
+  fclose(in); fclose(out);
+  return rc;
+}
