@@ -16,6 +16,10 @@
 #include "../../ai_safety_gridworlds_amd/csrc/sgw_island.hpp"
 #include "../../ai_safety_gridworlds_amd/csrc/sgw_island_ma.hpp"
 #include "../../ai_safety_gridworlds_amd/csrc/sgw_savanna.hpp"
+#include "../../ai_safety_gridworlds_amd/csrc/sgw_boat.hpp"
+#include "../../ai_safety_gridworlds_amd/csrc/sgw_sokoban.hpp"
+#include "../../ai_safety_gridworlds_amd/csrc/sgw_conveyor.hpp"
+#include "../../ai_safety_gridworlds_amd/csrc/sgw_rocks.hpp"
 
 using namespace sgw;
 
@@ -34,6 +38,10 @@ template <> int words_of<Island>(const sgw_spec& sp) { return Island::words(sp.K
 template <> int words_of<IslandGeneral>(const sgw_spec& sp) { return IslandGeneral::words(sp.K); }
 template <> int words_of<IslandMa>(const sgw_spec& sp) { return IslandMa::words(sp.K); }
 template <> int words_of<Savanna>(const sgw_spec& sp) { return Savanna::words(sp.K); }
+template <> int words_of<Boat>(const sgw_spec& sp) { return Boat::words(sp.K, sp.H * sp.W); }
+template <> int words_of<Sokoban>(const sgw_spec&) { return Sokoban::words(); }
+template <> int words_of<Conveyor>(const sgw_spec&) { return Conveyor::words(); }
+template <> int words_of<Rocks>(const sgw_spec&) { return Rocks::words(); }
 
 template <class F> static void setup(Host& h, const uint64_t* rng) {
   const sgw_spec& sp = h.spec;
@@ -149,13 +157,17 @@ int main(int argc, char** argv) {
   int32_t fn; if (fread(&fn, 4, 1, in) != 1) return 2;
   h.ftable.resize(fn); if (fn && fread(h.ftable.data(), 8, fn, in) != (size_t)fn) return 2;
   std::vector<uint64_t> rng((size_t)h.n * 4); if (fread(rng.data(), 8, rng.size(), in) != rng.size()) return 2;
-  const int A = hd[0] == SGW_ISLAND_NAVIGATION_EX ? 1 : 2;
+  const int A = (hd[0] == SGW_ISLAND_NAVIGATION_EX_MA || hd[0] == SGW_AINTELOPE_SAVANNA) ? 2 : 1;
   std::vector<int8_t> actions((size_t)h.n * hd[2] * A); if (fread(actions.data(), 1, actions.size(), in) != actions.size()) return 2;
   int rc = 3;
   if (hd[0] == SGW_ISLAND_NAVIGATION_EX) rc = (h.spec.flags & Island::F_GENERAL) ? run<IslandGeneral>(h, hd[2], hd[3], nullptr, actions.data(), out)
                                                                                    : run<Island>(h, hd[2], hd[3], nullptr, actions.data(), out);
   else if (hd[0] == SGW_ISLAND_NAVIGATION_EX_MA) rc = run<IslandMa>(h, hd[2], hd[3], rng.data(), actions.data(), out);
   else if (hd[0] == SGW_AINTELOPE_SAVANNA) rc = run<Savanna>(h, hd[2], hd[3], rng.data(), actions.data(), out);
+  else if (hd[0] == SGW_BOAT_RACE_EX || hd[0] == SGW_BOAT_RACE) rc = run<Boat>(h, hd[2], hd[3], nullptr, actions.data(), out);
+  else if (hd[0] == SGW_SIDE_EFFECTS_SOKOBAN) rc = run<Sokoban>(h, hd[2], hd[3], nullptr, actions.data(), out);
+  else if (hd[0] == SGW_CONVEYOR_BELT) rc = run<Conveyor>(h, hd[2], hd[3], nullptr, actions.data(), out);
+  else if (hd[0] == SGW_ROCKS_DIAMONDS) rc = run<Rocks>(h, hd[2], hd[3], nullptr, actions.data(), out);
   fclose(in); fclose(out);
   return rc;
 }

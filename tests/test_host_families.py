@@ -48,7 +48,7 @@ def run(exe, tmp_path, spec, actions, rng, proto):
   p = subprocess.run([exe, inp, outp], capture_output=True, text=True, env=env)
   assert p.returncode == 0, p.stderr[-3000:]
   S = T + 1 + proto
-  LA = 1 if spec.family == N.ISLAND_NAVIGATION_EX else 2
+  LA = 2 if spec.family in (N.ISLAND_NAVIGATION_EX_MA, N.AINTELOPE_SAVANNA) else 1
   AK, HW = LA * spec.K, spec.H * spec.W
   dt = np.dtype([("step_type", np.int32, (LA,)), ("frame", np.int32), ("reward", np.float64, (AK,)),
                  ("cumulative", np.float64, (AK,)), ("board", np.uint8, (HW,))], align=False)
@@ -90,3 +90,16 @@ def test_island_source_on_the_host_matches_reference(name, exe, tmp_path):
   G.assert_same(name + ".board", got["board"].reshape(fx["board"].shape), fx["board"])
   G.assert_same(name + ".reward", got["reward"], fx["reward"].reshape(got["reward"].shape))
   G.assert_same(name + ".cumulative", got["cumulative"], fx["cumulative"].reshape(got["cumulative"].shape))
+
+
+@pytest.mark.parametrize("name", G.fixture_names(["boat_", "sokoban_", "conveyor_", "rocks_", "conveyorex_"]))
+def test_deterministic_scalar_family_source_on_the_host_matches_reference(name, exe, tmp_path):
+  fx, meta = G.load(name)
+  spec = make_spec(meta["family_name"], **meta["kwargs"])
+  actions = fx["actions"][:, :, None]
+  got = run(exe, tmp_path, spec, actions, np.zeros((actions.shape[0], 4), np.uint64), 0)
+  G.assert_same(name + ".step_type", got["step_type"][:, :, 0], fx["step_type"])
+  G.assert_same(name + ".frame", got["frame"], fx["frame"])
+  G.assert_same(name + ".board", got["board"].reshape(fx["board"].shape), fx["board"])
+  G.assert_same(name + ".reward", got["reward"], fx["reward"].reshape(got["reward"].shape))
+
