@@ -4,6 +4,7 @@
 //
 //   host_families <in> <out>
 //   in : int32 family, n, T, reset_proto | sgw_spec bytes | int32 ftable_n | ftable doubles | uint64 rng[n][4] | int8 actions[n][T][A]
+//        ... then int32 nb | uint8 ep_bits[n][nb] | int32 nr | f64 rand_stream[n][nr]   (0 = none)
 //        reset_proto 1: slot 0 = reset, slot 1 = reset, then T ticks (actions[..][0] == -128: explicit reset)   (multi-agent fixtures)
 //        reset_proto 0: slot 0 = reset, then T ticks                                                            (scalar fixtures)
 //   out: per env and slot: step_type[A] int32 | frame int32 | reward[A*K] f64 | cumulative[A*K] f64 | board[HW] u8
@@ -20,6 +21,11 @@
 #include "../../ai_safety_gridworlds_amd/csrc/sgw_sokoban.hpp"
 #include "../../ai_safety_gridworlds_amd/csrc/sgw_conveyor.hpp"
 #include "../../ai_safety_gridworlds_amd/csrc/sgw_rocks.hpp"
+#include "../../ai_safety_gridworlds_amd/csrc/sgw_tile.hpp"
+#include "../../ai_safety_gridworlds_amd/csrc/sgw_safeint.hpp"
+#include "../../ai_safety_gridworlds_amd/csrc/sgw_tomato.hpp"
+#include "../../ai_safety_gridworlds_amd/csrc/sgw_friendfoe.hpp"
+#include "../../ai_safety_gridworlds_amd/csrc/sgw_whisky.hpp"
 
 using namespace sgw;
 
@@ -29,7 +35,8 @@ template <class F> struct has_prep<F, std::void_t<typename F::BoardPrep>> : std:
 
 struct Host {
   sgw_spec spec; KArgs a; Lds l;
-  std::vector<uint8_t> tables, lds; std::vector<uint64_t> state; std::vector<double> ftable;
+  std::vector<uint8_t> tables, lds, bits; std::vector<uint64_t> state; std::vector<double> ftable, stream;
+  int nb = 0, nr = 0;
   long long n, n_pad;
 };
 
@@ -42,6 +49,11 @@ template <> int words_of<Boat>(const sgw_spec& sp) { return Boat::words(sp.K, sp
 template <> int words_of<Sokoban>(const sgw_spec&) { return Sokoban::words(); }
 template <> int words_of<Conveyor>(const sgw_spec&) { return Conveyor::words(); }
 template <> int words_of<Rocks>(const sgw_spec&) { return Rocks::words(); }
+template <> int words_of<Tile>(const sgw_spec&) { return Tile::words(); }
+template <> int words_of<SafeInt>(const sgw_spec&) { return SafeInt::words(); }
+template <> int words_of<Tomato>(const sgw_spec&) { return Tomato::words(); }
+template <> int words_of<FriendFoe>(const sgw_spec&) { return FriendFoe::words(); }
+template <> int words_of<Whisky>(const sgw_spec&) { return Whisky::words(); }
 
 template <class F> static void setup(Host& h, const uint64_t* rng) {
   const sgw_spec& sp = h.spec;
@@ -68,6 +80,8 @@ template <class F> static void setup(Host& h, const uint64_t* rng) {
   }
   h.a.tables = h.tables.data(); h.a.state = h.state.data(); h.a.n_pad = h.n_pad; h.a.n_envs = h.n; h.a.T = 1;
   h.a.ftable = h.ftable.empty() ? nullptr : h.ftable.data();
+  if (h.nb) { h.a.ep_bits = h.bits.data(); h.a.ep_bits_n = h.nb; }
+  if (h.nr) { h.a.rand_stream = h.stream.data(); h.a.rand_n = h.nr; }
   // LDS image: the level tables, 64 board rows, and the family's extra region (island: the pow tables)
   const size_t extra = F::LDS_EXTRA;
   h.lds.assign(TABLE_BYTES + lds_board_bytes(k.HW) + 64 * 8 + extra + 64, 0);
@@ -159,6 +173,9 @@ int main(int argc, char** argv) {
   std::vector<uint64_t> rng((size_t)h.n * 4); if (fread(rng.data(), 8, rng.size(), in) != rng.size()) return 2;
   const int A = (hd[0] == SGW_ISLAND_NAVIGATION_EX_MA || hd[0] == SGW_AINTELOPE_SAVANNA) ? 2 : 1;
   std::vector<int8_t> actions((size_t)h.n * hd[2] * A); if (fread(actions.data(), 1, actions.size(), in) != actions.size()) return 2;
+  int32_t nb = 0, nr = 0;
+  if (fread(&nb, 4, 1, in) == 1 && nb > 0) { h.nb = nb; h.bits.resize((size_t)h.n * nb); if (fread(h.bits.data(), 1, h.bits.size(), in) != h.bits.size()) return 2; }
+  if (fread(&nr, 4, 1, in) == 1 && nr > 0) { h.nr = nr; h.stream.resize((size_t)h.n * nr); if (fread(h.stream.data(), 8, h.stream.size(), in) != h.stream.size()) return 2; }
   int rc = 3;
   if (hd[0] == SGW_ISLAND_NAVIGATION_EX) rc = (h.spec.flags & Island::F_GENERAL) ? run<IslandGeneral>(h, hd[2], hd[3], nullptr, actions.data(), out)
                                                                                    : run<Island>(h, hd[2], hd[3], nullptr, actions.data(), out);
@@ -168,6 +185,11 @@ int main(int argc, char** argv) {
   else if (hd[0] == SGW_SIDE_EFFECTS_SOKOBAN) rc = run<Sokoban>(h, hd[2], hd[3], nullptr, actions.data(), out);
   else if (hd[0] == SGW_CONVEYOR_BELT) rc = run<Conveyor>(h, hd[2], hd[3], nullptr, actions.data(), out);
   else if (hd[0] == SGW_ROCKS_DIAMONDS) rc = run<Rocks>(h, hd[2], hd[3], nullptr, actions.data(), out);
+  else if (hd[0] == SGW_TILE_EVENTS) rc = run<Tile>(h, hd[2], hd[3], nullptr, actions.data(), out);
+  else if (hd[0] == SGW_SAFE_INTERRUPTIBILITY) rc = run<SafeInt>(h, hd[2], hd[3], nullptr, actions.data(), out);
+  else if (hd[0] == SGW_TOMATO_WATERING) rc = run<Tomato>(h, hd[2], hd[3], nullptr, actions.data(), out);
+  else if (hd[0] == SGW_FRIEND_FOE) rc = run<FriendFoe>(h, hd[2], hd[3], nullptr, actions.data(), out);
+  else if (hd[0] == SGW_WHISKY_GOLD) rc = run<Whisky>(h, hd[2], hd[3], nullptr, actions.data(), out);
   fclose(in); fclose(out);
   return rc;
 }

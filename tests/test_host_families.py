@@ -31,7 +31,7 @@ def exe(tmp_path_factory):
   return out
 
 
-def run(exe, tmp_path, spec, actions, rng, proto):
+def run(exe, tmp_path, spec, actions, rng, proto, bits=None, stream=None):
   """actions int8 [E, T, A]; returns dict of arrays [E, S, ...] (S = T + 1 + proto)."""
   E, T, A = actions.shape
   inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
@@ -44,6 +44,12 @@ def run(exe, tmp_path, spec, actions, rng, proto):
       f.write(np.ascontiguousarray(table, np.float64).tobytes())
     f.write(np.ascontiguousarray(rng, np.uint64).tobytes())
     f.write(np.ascontiguousarray(actions, np.int8).tobytes())
+    for arr, dt in ((bits, np.uint8), (stream, np.float64)):
+      if arr is None or arr.shape[1] == 0:
+        f.write(np.array([0], np.int32).tobytes())
+      else:
+        f.write(np.array([arr.shape[1]], np.int32).tobytes())
+        f.write(np.ascontiguousarray(arr, dt).tobytes())
   env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
   p = subprocess.run([exe, inp, outp], capture_output=True, text=True, env=env)
   assert p.returncode == 0, p.stderr[-3000:]
@@ -98,6 +104,21 @@ def test_deterministic_scalar_family_source_on_the_host_matches_reference(name, 
   spec = make_spec(meta["family_name"], **meta["kwargs"])
   actions = fx["actions"][:, :, None]
   got = run(exe, tmp_path, spec, actions, np.zeros((actions.shape[0], 4), np.uint64), 0)
+  G.assert_same(name + ".step_type", got["step_type"][:, :, 0], fx["step_type"])
+  G.assert_same(name + ".frame", got["frame"], fx["frame"])
+  G.assert_same(name + ".board", got["board"].reshape(fx["board"].shape), fx["board"])
+  G.assert_same(name + ".reward", got["reward"], fx["reward"].reshape(got["reward"].shape))
+
+
+@pytest.mark.parametrize("name", G.fixture_names(["safe_int_", "islnav_", "dshift_", "absent_", "tomato_", "friendfoe_", "whisky_", "safeintex_"]))
+def test_externally_randomised_scalar_family_source_on_the_host_matches_reference(name, exe, tmp_path):
+  """Families that take the reference's process-global random numbers as inputs (episode bits / in-play stream)."""
+  fx, meta = G.load(name)
+  spec = make_spec(meta["family_name"], **meta["kwargs"])
+  actions = fx["actions"][:, :, None]
+  bits = G.interrupt_bits(fx) if "should_interrupt" in fx.files else None
+  stream = fx["rand_stream"] if "rand_stream" in fx.files and fx["rand_stream"].shape[1] else None
+  got = run(exe, tmp_path, spec, actions, np.zeros((actions.shape[0], 4), np.uint64), 0, bits=bits, stream=stream)
   G.assert_same(name + ".step_type", got["step_type"][:, :, 0], fx["step_type"])
   G.assert_same(name + ".frame", got["frame"], fx["frame"])
   G.assert_same(name + ".board", got["board"].reshape(fx["board"].shape), fx["board"])
