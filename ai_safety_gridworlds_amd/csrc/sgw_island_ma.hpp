@@ -181,9 +181,24 @@ struct IslandMa {
 
   // The step after every agent is done still shuffles the (discarded) actions when both were submitted (all LAST)
   // (an action < 0 = the agent did not submit one: EnvironmentMa.step with a subset of the agents, the AEC wrapper's way)
+  // On a finished episode the agents whose action counts are the DEAD ones when there is one (the reference raises for a
+  // LAST agent next to a DEAD one, PM:213-221), otherwise everybody; the shuffle draws when two of them were submitted.
+  static __device__ bool eligible(const State& s, int ag, const int (&actions)[2]) {
+    const bool any_dead = s.ast[0] == AST_DEAD || s.ast[1] == AST_DEAD;
+    return actions[ag] >= 0 && (!any_dead || s.ast[ag] == AST_DEAD);
+  }
   static __device__ void pre_autoreset(State& s, const KArgs& a, const int (&actions)[2]) {
-    if ((a.sp.flags & F_SHUFFLE) && s.step_type == ST_LAST && s.ast[0] != AST_DEAD && s.ast[1] != AST_DEAD &&
-        actions[0] >= 0 && actions[1] >= 0) interval(s, 1);
+    if ((a.sp.flags & F_SHUFFLE) && s.step_type == ST_LAST && eligible(s, 0, actions) && eligible(s, 1, actions)) interval(s, 1);
+  }
+  static __device__ bool reset_requested(const State& s, const KArgs&, const int (&actions)[2]) {
+    return s.step_type == ST_NONE || eligible(s, 0, actions) || eligible(s, 1, actions);
+  }
+  // nobody eligible: no play, no reset; the adapter's state loop still turns LAST into DEAD (PM:223-233).  Returns the
+  // discount of the last play (0 when every agent had terminated by itself).
+  static __device__ double idle_round(State& s) {
+#pragma unroll
+    for (int ag = 0; ag < 2; ++ag) s.ast[ag] = AST_DEAD;
+    return (s.tr[0] == T_TERMINATED && s.tr[1] == T_TERMINATED) ? 0.0 : 1.0;
   }
 
   // make_game + its_showtime (IM:420-512, MB:949-1120, MM:868-900).  Explicit resets (sgw_reset) advance the episode

@@ -16,6 +16,8 @@ namespace sgw {
 
 constexpr int TERM_NONE4 = 15;   // 4-bit in-state encoding of "termination_reason key absent"
 
+template <class F, class = void> struct has_idle_round : std::false_type {};
+template <class F> struct has_idle_round<F, std::void_t<decltype(&F::idle_round)>> : std::true_type {};
 template <class F, class = void> struct has_board_prepare : std::false_type {};
 template <class F> struct has_board_prepare<F, std::void_t<typename F::BoardPrep>> : std::true_type {};
 
@@ -201,7 +203,13 @@ __global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
                                              : (real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0);
         else action[ag] = synth_action(a.seed, env_id, a.step0 + t, ag, a.sp.action_lo, a.sp.n_actions);
       }
-      if (s.step_type >= ST_LAST) {
+      bool idle = false;
+      if constexpr (has_idle_round<F>::value) idle = s.step_type >= ST_LAST && !F::reset_requested(s, a, action);
+      if (idle) {
+        // multi-agent adapter, finished episode, no eligible agent in the submitted dict (PM:173-246: the play loop does not
+        // run, so nothing resets): only the per-agent states move on (LAST -> DEAD); rewards are the default zeros
+        if constexpr (has_idle_round<F>::value) discount = F::idle_round(s);
+      } else if (s.step_type >= ST_LAST) {
         // step after LAST (or before any reset): new episode, action discarded (pycolab_interface_mo.py:175-178); the
         // multi-agent adapters still shuffle the discarded actions when more than one was submitted
         F::pre_autoreset(s, a, action);

@@ -248,6 +248,11 @@ struct Savanna {
   static __device__ __forceinline__ void pre_autoreset(State& s, const KArgs& a, const int (&actions)[2]) {
     if ((a.sp.flags & F_SHUFFLE) && (a.sp.flags & F_TWO) && s.step_type == ST_LAST && actions[0] >= 0 && actions[1] >= 0) interval(s.g, 1);
   }
+  static __device__ __forceinline__ bool reset_requested(const State& s, const KArgs& a, const int (&actions)[2]) {
+    return s.step_type == ST_NONE || actions[0] >= 0 || ((a.sp.flags & F_TWO) && actions[1] >= 0);   // a one-agent env's second slot is padding
+  }
+  // nobody in the submitted dict on a finished episode: no play, no reset; LAST becomes DEAD (PM:223-233)
+  static __device__ __forceinline__ double idle_round(State& s) { s.ast = AST_DEAD; return 1.0; }
 
   // Drink/FoodDrapeBase.update for resource R (0 D, 1 F, 2 d, 3 f); `showtime`: iteration_index == 0
   template <int R>

@@ -30,6 +30,8 @@
 using namespace sgw;
 
 #include <type_traits>
+template <class F, class = void> struct has_idle : std::false_type {};
+template <class F> struct has_idle<F, std::void_t<decltype(&F::idle_round)>> : std::true_type {};
 template <class F, class = void> struct has_prep : std::false_type {};
 template <class F> struct has_prep<F, std::void_t<typename F::BoardPrep>> : std::true_type {};
 
@@ -133,7 +135,11 @@ template <class F> static void step_env(Host& h, long long env, const int8_t* ac
   double r[F::NU]; for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
   int action[F::NA]; for (int ag = 0; ag < F::NA; ++ag) action[ag] = act[ag];
   h.a.mode = MODE_STEP;
-  if (s.step_type >= ST_LAST) {
+  bool idle = false;
+  if constexpr (has_idle<F>::value) idle = s.step_type >= ST_LAST && !F::reset_requested(s, h.a, action);
+  if (idle) {
+    if constexpr (has_idle<F>::value) F::idle_round(s);
+  } else if (s.step_type >= ST_LAST) {
     F::pre_autoreset(s, h.a, action);
     F::begin_episode(s, h.a, h.l, env, env);
   } else {
