@@ -148,7 +148,7 @@ struct Sokoban {
   static __device__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds& l, int i) {
     uint32_t v = reinterpret_cast<const uint32_t*>(l.static_board)[i];
     const double* p = l.params;
-    const int nb = (int)p[P_NBOX], nc = (int)p[P_NCOIN];
+    const int nb = (int)p[P_NBOX];
     auto put = [&](int cell, uint32_t ch) {
       if ((cell >> 2) == i) { const int sh = (cell & 3) * 8; v = (v & ~(0xffu << sh)) | (ch << sh); }
     };
