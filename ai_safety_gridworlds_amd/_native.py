@@ -76,6 +76,8 @@ def lib():
   L.sgw_set_rng_state.argtypes = [C.c_void_p, C.c_void_p]
   L.sgw_set_random_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
   L.sgw_set_family_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+  L.sgw_pow_selfcheck.restype = C.c_int64
+  L.sgw_pow_selfcheck.argtypes = []
   L.sgw_pow_f64.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
   L.sgw_reset.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Out), C.c_void_p]
   L.sgw_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Out), C.c_void_p]
@@ -109,7 +111,7 @@ def lib():
 EXPORTS = [
     "sgw_abi_version", "sgw_last_error", "sgw_sizeof_spec", "sgw_sizeof_out", "sgw_create",
     "sgw_destroy", "sgw_n_envs", "sgw_n_pad", "sgw_state_bytes", "sgw_set_episode_bits",
-    "sgw_set_rng_state", "sgw_set_random_stream", "sgw_set_family_table", "sgw_pow_f64", "sgw_reset", "sgw_step", "sgw_step_n", "sgw_rollout", "sgw_read_returns", "sgw_fill_actions",
+    "sgw_set_rng_state", "sgw_set_random_stream", "sgw_set_family_table", "sgw_pow_f64", "sgw_pow_selfcheck", "sgw_reset", "sgw_step", "sgw_step_n", "sgw_rollout", "sgw_read_returns", "sgw_fill_actions",
     "sgw_accumulate_returns", "sgw_observe", "sgw_derived_stats", "sgw_observe_layers", "sgw_state_layers", "sgw_view_bytes", "sgw_agent_views", "sgw_agent_layer_views", "sgw_state_words", "sgw_get_state", "sgw_set_state"]
 
 

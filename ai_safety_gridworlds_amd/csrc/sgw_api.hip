@@ -25,6 +25,13 @@
 
 using namespace sgw;
 
+// Host copy of the pow tables: sgw_create checks the RUNNING libm against them (see pow_selfcheck).
+namespace sgw_host_pow {
+#undef SGW_POW_TABLE
+#define SGW_POW_TABLE static const
+#include "sgw_pow_tables.inc"
+}
+
 static thread_local char g_err[512] = "";
 
 static int fail(int code, const char* fmt, const char* detail = "") {
@@ -79,12 +86,37 @@ static int family_words(const sgw_spec& sp) {
   }
 }
 
+// The device pow restates glibc's algorithm over tables extracted from the BUILD host's libm (csrc/sgw_pow_tables.inc);
+// the reference's math.pow is the RUNNING host's libm pow.  When the two differ (another glibc, a non-FMA dispatch) parity
+// of resource regrowth would fail later and quietly, so the families that regrow resources refuse to construct instead.
+// Probe: the regrowth domain (halves and pseudo-random x in [1, 61]) at three exponents.  Returns the mismatch count.
+static long pow_selfcheck() {
+  static long cached = -1;
+  if (cached >= 0) return cached;
+  long bad = 0;
+  unsigned long long s = 88172645463325252ULL;
+  const double ys[3] = {1.1, 1.05, 1.5};
+  for (int i = 0; i < 4096; ++i) {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    double x = 1.0 + 60.0 * ((double)(s >> 11) / 9007199254740992.0);
+    if (i < 240) x = 1.0 + 0.25 * i;
+    const double y = ys[i % 3];
+    const double want = pow(x, y);
+    const double got = sgw_glibc_pow_core(x, y, sgw_host_pow::SGW_POW_LOG_HEAD, sgw_host_pow::SGW_POW_EXP_HEAD,
+                                          sgw_host_pow::SGW_POW_LOG_TAB, sgw_host_pow::SGW_POW_EXP_TAB);
+    if (memcmp(&want, &got, 8) != 0) ++bad;
+  }
+  cached = bad;
+  return bad;
+}
+
 extern "C" {
 
 int sgw_abi_version(void) { return SGW_ABI_VERSION; }
 const char* sgw_last_error(void) { return g_err; }
 int sgw_sizeof_spec(void) { return (int)sizeof(sgw_spec); }
 int sgw_sizeof_out(void) { return (int)sizeof(sgw_out); }
+int64_t sgw_pow_selfcheck(void) { return (int64_t)pow_selfcheck(); }
 
 int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int device, sgw_engine** out_engine) {
   if (!spec || !out_engine) return fail(SGW_ERR_ARG, "sgw_create: null argument");
@@ -113,6 +145,12 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
     return fail(SGW_ERR_ARG, "sgw_create: island_navigation_ex_ma keeps its map in 4 x 16 nibbles (H*W <= 64) and has two agents");
   const int words = family_words(*spec);
   if (words < 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_create: unknown game family");
+  if ((spec->family == SGW_ISLAND_NAVIGATION_EX || spec->family == SGW_ISLAND_NAVIGATION_EX_MA ||
+       spec->family == SGW_AINTELOPE_SAVANNA) && pow_selfcheck() != 0 && !getenv("SGW_ALLOW_LIBM_MISMATCH"))
+    return fail(SGW_ERR_UNSUPPORTED, "sgw_create: this host's libm pow() differs from the tables the device pow was built from "
+                "(csrc/sgw_pow_tables.inc, glibc 2.35 x86-64 FMA build): resource regrowth would not match the reference's "
+                "math.pow here.  Regenerate the tables on this host (tools/gen_pow_tables.py) and rebuild, or set "
+                "SGW_ALLOW_LIBM_MISMATCH=1");
 
   HIP_TRY(hipSetDevice(device));
   sgw_engine* e = new (std::nothrow) sgw_engine();

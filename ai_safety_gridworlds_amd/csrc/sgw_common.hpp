@@ -216,7 +216,9 @@ __device__ inline void store16_wt(void* p, const uint4& v) {
   *reinterpret_cast<uint4*>(p) = v;
 #else
   sgw_u32x4 d = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(d) : "memory");
+  // s_nop 1: the assembler-level store is invisible to the compiler's hazard recognizer (a VALU write to the data VGPRs of
+  // a >64-bit VMEM store needs 2 wait states on gfx940-class parts); the nop makes every build safe whatever is scheduled next
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
 #endif
 }
 template <class T> __device__ inline void store_wt(T* p, T v) {   // 1/4/8-byte scalar outputs

@@ -14,14 +14,16 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__)
-#include <hip/hip_runtime.h>
-#define SGW_POW_FN __device__ inline
-#define SGW_POW_TABLE __device__ const
-#else
 #include <math.h>
 #include <string.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SGW_POW_FN __host__ __device__ inline
+#define SGW_POW_DEV_FN __device__ inline
+#define SGW_POW_TABLE __device__ const
+#else
 #define SGW_POW_FN static inline
+#define SGW_POW_DEV_FN static inline
 #define SGW_POW_TABLE static const
 #endif
 
@@ -44,10 +46,11 @@ SGW_POW_FN unsigned long long sgw_pow_asu(double x) {
 
 // `log_tab` / `exp_tab`: SGW_POW_LOG_TAB / SGW_POW_EXP_TAB or a copy of them (a kernel may stage the 5 KB in LDS: the two
 // lookups are data-dependent per lane, and an LDS read costs a fraction of an L2 round trip)
-SGW_POW_FN double sgw_glibc_pow_t(double x, double y, const unsigned long long* log_tab, const unsigned long long* exp_tab) {
+// `LH` / `EH`: the two 9- / 8-entry constant heads (SGW_POW_LOG_HEAD / SGW_POW_EXP_HEAD or the host copy sgw_create checks the
+// running libm against)
+SGW_POW_FN double sgw_glibc_pow_core(double x, double y, const unsigned long long* LH, const unsigned long long* EH,
+                                     const unsigned long long* log_tab, const unsigned long long* exp_tab) {
   const unsigned long long OFF = 0x3fe6955500000000ULL;
-  const unsigned long long* LH = SGW_POW_LOG_HEAD;
-  const unsigned long long* EH = SGW_POW_EXP_HEAD;
   // ---- log_inline (e_pow.c:60-140)
   const unsigned long long ix = sgw_pow_asu(x);
   const unsigned long long tmp = ix - OFF;
@@ -93,7 +96,10 @@ SGW_POW_FN double sgw_glibc_pow_t(double x, double y, const unsigned long long* 
   const double scale = sgw_pow_asd(sbits);
   return fma(scale, tm, scale);
 }
-SGW_POW_FN double sgw_glibc_pow(double x, double y) { return sgw_glibc_pow_t(x, y, SGW_POW_LOG_TAB, SGW_POW_EXP_TAB); }
+SGW_POW_DEV_FN double sgw_glibc_pow_t(double x, double y, const unsigned long long* log_tab, const unsigned long long* exp_tab) {
+  return sgw_glibc_pow_core(x, y, SGW_POW_LOG_HEAD, SGW_POW_EXP_HEAD, log_tab, exp_tab);
+}
+SGW_POW_DEV_FN double sgw_glibc_pow(double x, double y) { return sgw_glibc_pow_t(x, y, SGW_POW_LOG_TAB, SGW_POW_EXP_TAB); }
 
 #if defined(__HIPCC__)
 // One wave copies both tables (3 KB + 2 KB) into `lds` (16-byte aligned): five 16-byte loads per lane, all L2 hits.  Every

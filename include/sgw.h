@@ -165,6 +165,13 @@ int sgw_set_family_table(sgw_engine* e, const double* table_host, int64_t n);
  * x finite, positive, normal; device pointers.  Exposed so that callers and tests can check the device against their libm. */
 int sgw_pow_f64(const double* x_dev, double y, double* out_dev, int64_t n, int device, void* stream);
 
+/* Host-side probe, no GPU needed: number of probe inputs (4096 points of the regrowth domain x in [1, 61] at exponents 1.1,
+ * 1.05, 1.5) on which the RUNNING host's libm pow() -- the reference's math.pow -- differs from the table-based restatement
+ * the device uses (csrc/sgw_pow.hpp over csrc/sgw_pow_tables.inc).  0 on the build host.  sgw_create refuses the families
+ * that regrow resources (island_navigation_ex, island_navigation_ex_ma, aintelope_savanna) with SGW_ERR_UNSUPPORTED when it is
+ * not 0 (override: environment variable SGW_ALLOW_LIBM_MISMATCH). */
+int64_t sgw_pow_selfcheck(void);
+
 /* Start a new episode in every env with mask_dev[n] != 0 (NULL = all) and emit the FIRST
  * timestep into `out` for those envs (other rows of `out` are left untouched). */
 int sgw_reset(sgw_engine* e, const uint8_t* mask_dev, const sgw_out* out, void* stream);

@@ -20,6 +20,9 @@ SEED, T, RESET_AT = 0x5AFE, 260, 150
 
 
 def main():
+  # scratch cwd: the reference's step logger writes ./logs/*.csv into the current directory
+  import tempfile
+  os.chdir(tempfile.mkdtemp(prefix="sgw_fixtures_"))
   sys.dont_write_bytecode = True
   sys.path.insert(0, "/root/reference"); sys.path.insert(0, os.path.join(HERE, "standins")); sys.path.insert(0, REPO)
   import numpy as np

@@ -56,3 +56,9 @@ def test_engine_fails_loudly_without_a_gpu():
     BatchedEngine(make_spec("island_navigation_ex"), 64, device="cuda:0")
   with pytest.raises(N.SgwError):
     BatchedEngine(make_spec("island_navigation_ex"), 64, device="cpu")
+
+
+def test_host_libm_matches_the_pow_tables():
+  """sgw_create refuses the regrowth families when the running libm's pow() (the reference's math.pow) is not the one the
+  device tables were extracted from; on the build host the probe finds no difference."""
+  assert N.lib().sgw_pow_selfcheck() == 0
