@@ -209,6 +209,9 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
       return SGW_ERR_HIP;
     }
   }
+  // the state / table initialisation above went through the null stream: finished before the caller can launch on any
+  // (possibly non-blocking) stream of its own
+  HIP_TRY(hipStreamSynchronize(nullptr));
   return SGW_OK;
 }
 
@@ -281,12 +284,14 @@ int sgw_pow_f64(const double* x_dev, double y, double* out_dev, int64_t n, int d
   return SGW_OK;
 }
 
-static int ensure_acc(sgw_engine* e) {
+// The accumulators are zeroed ON THE CALLER'S STREAM: a hipMemset on the null stream is not ordered against a non-blocking
+// stream (torch side streams are), so the first accumulating launches could run before it and lose their sums.
+static int ensure_acc(sgw_engine* e, hipStream_t st) {
   if (e->acc_dev) return SGW_OK;
   HIP_TRY(hipSetDevice(e->device));
   const size_t bytes = (size_t)(e->spec.A * e->spec.K + 1) * (size_t)(e->n_pad / WAVE) * 8;   // [waves][A*K+1]
   HIP_TRY(hipMalloc((void**)&e->acc_dev, bytes));
-  HIP_TRY(hipMemset(e->acc_dev, 0, bytes));
+  HIP_TRY(hipMemsetAsync(e->acc_dev, 0, bytes, st));
   return SGW_OK;
 }
 
@@ -387,7 +392,7 @@ int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every,
                int accumulate, void* stream) {
   if (!e) return fail(SGW_ERR_ARG, "sgw_step_n: null engine");
   if (!actions_dev || T < 1) return fail(SGW_ERR_ARG, "sgw_step_n: bad argument");
-  if (accumulate) { int rc = ensure_acc(e); if (rc) return rc; }
+  if (accumulate) { int rc = ensure_acc(e, (hipStream_t)stream); if (rc) return rc; }
   for (int t = 0; t < T; ++t) {
     KArgs a; memset(&a, 0, sizeof(a));
     a.mode = MODE_STEP; a.T = 1; a.ep_acc = accumulate ? e->acc_dev : nullptr;
@@ -401,7 +406,7 @@ int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every,
 
 int sgw_read_returns(sgw_engine* e, double* out_dev, int clear, void* stream) {
   if (!e || !out_dev) return fail(SGW_ERR_ARG, "sgw_read_returns: null argument");
-  int rc = ensure_acc(e);
+  int rc = ensure_acc(e, (hipStream_t)stream);
   if (rc) return rc;
   hipLaunchKernelGGL(k_read_returns, dim3(e->spec.A * e->spec.K + 1), dim3(256), 0, (hipStream_t)stream, e->acc_dev,
                      e->n_pad / WAVE, e->spec.A * e->spec.K + 1, out_dev, clear);
@@ -416,7 +421,7 @@ int sgw_rollout(sgw_engine* e, int T, uint64_t seed, int64_t step0, int write_ev
   if (e->spec.n_actions < 1) return fail(SGW_ERR_ARG, "sgw_rollout: spec has no action range");
   KArgs a; memset(&a, 0, sizeof(a));
   a.mode = MODE_STEP; a.actions = nullptr; a.T = T; a.seed = seed; a.step0 = step0;
-  if (accumulate) { int rc = ensure_acc(e); if (rc) return rc; }
+  if (accumulate) { int rc = ensure_acc(e, (hipStream_t)stream); if (rc) return rc; }
   a.write_every = write_every; a.ep_acc = accumulate ? e->acc_dev : nullptr;
   if (out) a.out = *out;
   return launch(e, a, (hipStream_t)stream);

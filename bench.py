@@ -9,16 +9,21 @@ Workload (BASELINE.json configs[1], the config the metric is quoted on): 65 536 
 island_navigation_ex envs (level 9, default flags) PER GPU, synthetic uniform actions from
 Philox-4x32-10 keyed by the global env id.  One bench "step" = one pass of the hot path over the
 batch = ONE sgw_step kernel launch advancing all 65 536 envs by one env.step() (auto-reset
-included), writing board + reward vector + step_type + term_reason + safety + frame.  The K
-action batches are resident in HBM before the timed region starts; the K launches are issued
-back to back by sgw_step_n (host loop in C).  value = envs x K x N_gpus / max-over-ranks time.
+included), writing board + reward vector + step_type + term_reason + safety + frame.  The
+action batches are resident in HBM before the timed region starts; the K launches of a batch are
+issued back to back by sgw_step_n (host loop in C).  A K-step batch at this size lasts K x ~9 us, so
+the timed region REPEATS the K-step batch R times (R chosen after warmup so that the region lasts
+>= --min-seconds, default 0.5 s; "repeats" / "timed_steps" in the JSON line; --min-seconds 0 times
+exactly K steps): with the driver's `--steps 20` alone the region would be 0.2 ms of event / sync
+overhead and clock ramp.  value = envs x K x R x N_gpus / max-over-ranks time.
 Envs are sharded by contiguous global-id ranges; the only collective is one all-reduce (RCCL)
 of the episodic-return accumulators after the batch ("scaling": "weak").
 
-Also reported (same JSON line): the fused-rollout mode (K steps in ONE launch, state in
+Also reported (same JSON line): the fused-rollout mode (512 steps in ONE launch, state in
 registers, outputs written every step), the roofline of the step kernel, and a CPU baseline =
 the C oracle (oracle/, "port" of the reference semantics, bit-identical outputs) on a bounded
-sample of the same workload on this box's host cores.
+sample of the same workload on this box's host cores, with the reference's own CPython rate
+(measured in the build container, profiles/reference_cpython.json) beside it.
 """
 import argparse
 import json
@@ -37,6 +42,8 @@ from ai_safety_gridworlds_amd.engine import BatchedEngine      # noqa: E402
 from ai_safety_gridworlds_amd.specs import make_spec            # noqa: E402
 
 SEED = 0x5AFE
+METRIC = json.load(open(os.path.join(REPO, "BASELINE.json")))["metric"]      # BASELINE.json's metric string, verbatim
+TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")                     # newest first
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # algorithmic bytes per env-step, island_navigation_ex L9 (step-per-launch mode):
 # action 1 + state 80 read + 80 write + board 48 + reward 80 + done 1 + term 1 + safety/hidden 8
@@ -64,6 +71,18 @@ def cpu_baseline(n_envs, seconds, threads):
                     "(oracle/sgw_oracle.c), OpenMP over envs on %d threads; 1 thread: %.0f env-steps/s"
                     % (repeats, E, T, threads, rate1),
           "single_thread_value": rate1}
+
+
+def reference_cpython():
+  """The reference itself (CPython object graph, one env) cannot travel to the GPU box; it is timed in the build container by
+  tools/time_reference.py, which writes profiles/reference_cpython.json.  Reported beside the C port, never measured here."""
+  path = os.path.join(REPO, "profiles", "reference_cpython.json")
+  try:
+    d = json.load(open(path))
+    return {"value": d["island_navigation_ex"]["steps_per_s"], "unit": "env-steps/s", "cores": 1,
+            "where": d["where"], "source": "profiles/reference_cpython.json (tools/time_reference.py)"}
+  except Exception:
+    return None
 
 
 # SURVEY.md §8(d) algorithmic bytes per env-step: (step-per-launch, fused rollout)
@@ -125,6 +144,55 @@ def mixed_parts(rank, world, per_gpu):
   return parts
 
 
+def prepare_engine(fam, spec, cnt, base, device, outputs):
+  """One family's engine with the per-env inputs the family needs, reset; everything enqueued on the CURRENT stream."""
+  eng = BatchedEngine(spec, cnt, device=device, env_id_base=base, outputs=outputs)
+  if fam == "firemaker_ex_ma" or getattr(spec, "needs_rng", False):
+    eng.set_rng_seeds(base + np.arange(cnt))
+  if fam == "safe_interruptibility" or getattr(spec, "episode_bit", False):
+    eng.set_episode_bits(None, seed=SEED)
+  if getattr(spec, "random_stream", False):
+    eng.set_random_stream(None, seed=SEED)
+  eng.reset()
+  return eng
+
+
+def build_engines(parts, device):
+  """parts = [(family, n_envs, global id base)] -> one engine per part; several parts get one side stream each (mixed
+  suite).  Construction, reset and action generation run on the current stream: the device is synchronised before
+  returning, so the first launch on a side stream cannot race them."""
+  engines = []
+  for fam, cnt, base in parts:
+    wl = WORKLOADS[fam]
+    spec = make_spec(fam, **wl["kwargs"])
+    eng = prepare_engine(fam, spec, cnt, base, device, wl["outputs"])
+    engines.append(dict(fam=fam, spec=spec, eng=eng, n=cnt, base=base, wl=wl, acts=None,
+                        stream=torch.cuda.Stream(device) if len(parts) > 1 else torch.cuda.current_stream(device)))
+  torch.cuda.synchronize(device)
+  return engines
+
+
+def fill_action_batches(engines, K, R, step0=0, max_steps=4096):
+  """Distinct K-step action batches resident in HBM: min(R, max_steps // K) of them (at least one), cycled by
+  run_batches -- at most ~4096 steps x N bytes per engine, far beyond what L2 / MALL would keep between uses."""
+  n_distinct = int(max(1, min(R, max_steps // max(K, 1))))
+  for e in engines:
+    e["acts"] = e["eng"].fill_actions(K * n_distinct, SEED, step0=step0)
+  torch.cuda.synchronize(engines[0]["eng"].device)
+  return n_distinct
+
+
+def run_batches(engines, K, first, count, accumulate):
+  """`count` batches of exactly K sgw_step launches per engine (sgw_step_n: the host loop is in C), one stream per
+  engine; batch j uses action batch j modulo the number resident."""
+  for e in engines:
+    nd = e["acts"].shape[0] // K
+    with torch.cuda.stream(e["stream"]):
+      for j in range(first, first + count):
+        b = j % nd
+        e["eng"].step_n(e["acts"][b * K:(b + 1) * K], accumulate=accumulate)
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +200,8 @@ def main():
   ap.add_argument("--warmup", type=int, default=200)
   ap.add_argument("--workload", default="island_navigation_ex", choices=sorted(WORKLOADS) + ["mixed"])
   ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's BASELINE size)")
+  ap.add_argument("--min-seconds", type=float, default=0.5,
+                  help="the timed region repeats the K-step batch until it lasts at least this long (0: exactly K steps)")
   ap.add_argument("--cpu-seconds", type=float, default=12.0)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-fused", action="store_true")
@@ -153,21 +223,7 @@ def main():
   else:
     n = a.envs or WORKLOADS[a.workload]["envs"]
     parts = [(a.workload, n, rank * n)]
-  engines = []
-  for fam, cnt, base in parts:
-    wl = WORKLOADS[fam]
-    spec = make_spec(fam, **wl["kwargs"])
-    eng = BatchedEngine(spec, cnt, device=device, env_id_base=base, outputs=wl["outputs"])
-    if fam == "firemaker_ex_ma" or getattr(spec, "needs_rng", False):
-      eng.set_rng_seeds(base + np.arange(cnt))
-    if fam == "safe_interruptibility" or getattr(spec, "episode_bit", False):
-      eng.set_episode_bits(None, seed=SEED)
-    if getattr(spec, "random_stream", False):
-      eng.set_random_stream(None, seed=SEED)
-    eng.reset()
-    engines.append(dict(fam=fam, spec=spec, eng=eng, n=cnt, wl=wl, acts=eng.fill_actions(W + K, SEED),
-                        stream=torch.cuda.Stream(device) if len(parts) > 1 else torch.cuda.current_stream(device)))
-  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  engines = build_engines(parts, device)
 
   def barrier():
     torch.cuda.synchronize(device)
@@ -175,22 +231,39 @@ def main():
       dist.barrier()                                    # nccl: on this rank's device; gloo (rehearsal): host
     torch.cuda.synchronize(device)
 
-  def run(lo, hi, accumulate):
-    for e in engines:                                   # one stream per family (mixed suite); K launches each
-      with torch.cuda.stream(e["stream"]):
-        e["eng"].step_n(e["acts"][lo:hi], accumulate=accumulate)
-
+  # ---- warmup (untimed): W steps as asked, then K-step batches until the clocks have ramped (>= 0.25 s of launches);
+  # the same batches calibrate how many repeats R of the K-step batch make a timed region of >= --min-seconds
+  # (the driver's `--steps 20` alone would be a 0.2 ms region: event / sync overhead and the clock ramp, not the kernel)
+  warm_acts = [e["eng"].fill_actions(max(W, 1), SEED) for e in engines]
+  torch.cuda.synchronize(device)
   if W > 0:
-    run(0, W, False)
+    for e, wa in zip(engines, warm_acts):
+      with torch.cuda.stream(e["stream"]):
+        e["eng"].step_n(wa[:W], accumulate=False)
+  del warm_acts
+  fill_action_batches(engines, K, 1, step0=W)
+  torch.cuda.synchronize(device)
+  c0, nb = time.perf_counter(), 0
+  while True:
+    run_batches(engines, K, 0, 1, False)
+    torch.cuda.synchronize(device)
+    nb += 1
+    if time.perf_counter() - c0 >= (0.25 if a.min_seconds > 0 else 0.0) or nb >= 20000:
+      break
+  t_batch = parallel.max_over_ranks((time.perf_counter() - c0) / nb, device, dist)
+  R = 1 if a.min_seconds <= 0 else int(min(200000, max(1, -(-a.min_seconds // t_batch))))
+  n_distinct = fill_action_batches(engines, K, R, step0=W)      # action batches resident in HBM before the timed region
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   barrier()
   t0 = time.perf_counter()
   ev0.record(engines[0]["stream"])
-  run(W, W + K, True)
+  run_batches(engines, K, 0, R, True)                            # R x exactly K steps, launches issued from C
   ev1.record(engines[0]["stream"])
   torch.cuda.synchronize(device)
   elapsed = time.perf_counter() - t0
   barrier()
-  kernel_ms = ev0.elapsed_time(ev1) / K                # avg launch duration of the first family's kernel
+  KR = K * R
+  kernel_ms = ev0.elapsed_time(ev1) / KR                # avg launch-to-launch time of the first family's kernel, HIP events on ITS stream
   elapsed = parallel.max_over_ranks(elapsed, device, dist)
   returns = {}
   for fam in (MIXED if a.workload == "mixed" else (a.workload,)):
@@ -205,30 +278,30 @@ def main():
   fused = None
   if not a.no_fused and a.workload != "mixed":
     e = engines[0]
-    eng2 = BatchedEngine(e["spec"], e["n"], device=device, env_id_base=rank * e["n"], outputs=e["wl"]["outputs"])
-    if e["fam"] == "firemaker_ex_ma" or getattr(e["spec"], "needs_rng", False):
-      eng2.set_rng_seeds(rank * e["n"] + np.arange(e["n"]))
-    if e["fam"] == "safe_interruptibility" or getattr(e["spec"], "episode_bit", False):
-      eng2.set_episode_bits(None, seed=SEED)
-    if getattr(e["spec"], "random_stream", False):
-      eng2.set_random_stream(None, seed=SEED)
-    eng2.reset()
-    Tf = min(K, 512 if e["fam"] != "firemaker_ex_ma" else 128)
+    eng2 = prepare_engine(e["fam"], e["spec"], e["n"], rank * e["n"], device, e["wl"]["outputs"])
+    Tf = 512 if e["fam"] != "firemaker_ex_ma" else 128      # steps per launch: a property of the mode, not of --steps
     eng2.rollout(Tf, SEED, step0=0, write_every=True)   # untimed: allocates the [Tf, N, ...] outputs, warms the code object
     torch.cuda.synchronize(device)
+    c0 = time.perf_counter()
+    eng2.rollout(Tf, SEED, step0=Tf, write_every=True)
+    torch.cuda.synchronize(device)
+    t_launch = parallel.max_over_ranks(time.perf_counter() - c0, device, dist)
+    Rf = 1 if a.min_seconds <= 0 else int(min(10000, max(1, -(-0.6 * a.min_seconds // t_launch))))
     barrier()
     f0 = time.perf_counter()
     ev0.record()
-    eng2.rollout(Tf, SEED, step0=Tf, write_every=True)
+    for j in range(Rf):
+      eng2.rollout(Tf, SEED, step0=(2 + j) * Tf, write_every=True)
     ev1.record()
     torch.cuda.synchronize(device)
     felapsed = time.perf_counter() - f0
     barrier()
-    fms = ev0.elapsed_time(ev1)
+    fms = ev0.elapsed_time(ev1) / Rf
     felapsed = parallel.max_over_ranks(felapsed, device, dist)
-    fused = {"value": world * e["n"] * Tf / felapsed, "unit": "env-steps/s", "steps_per_launch": Tf,
+    fused = {"value": world * e["n"] * Tf * Rf / felapsed, "unit": "env-steps/s", "steps_per_launch": Tf, "launches": Rf,
              "ms_per_step": fms / Tf, "bytes_per_env_step": e["wl"]["b_fused"],
              "hbm_gbs": e["n"] * e["wl"]["b_fused"] / (fms / Tf * 1e-3) / 1e9,
+             "frac_of_hbm_peak": e["n"] * e["wl"]["b_fused"] / (fms / Tf * 1e-3) / 1e9 / HBM_PEAK_GBS,
              "note": "ONE launch advances every env Tf steps (state in registers, in-kernel Philox actions), "
                      "all listed outputs written every step"}
     eng2.close()
@@ -238,13 +311,19 @@ def main():
     alg_bytes = sum(e["n"] * e["wl"]["b_step"] for e in engines)      # algorithmic bytes of one bench step on this rank
     e0 = engines[0]
     achieved = e0["n"] * e0["wl"]["b_step"] / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath) and a.workload == "island_navigation_ex":
-      try:
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-      except Exception:
-        traffic = None
+    # HBM bytes per launch from the PMC counters: collected by separate `rocprofv3 --pmc` passes of this same command
+    # (tools/collect_profiles.sh, MI355X_MICROARCH.md's recipe), NOT measured inside this run -- the file says which run
+    traffic, traffic_source = None, None
+    if a.workload == "island_navigation_ex" and n == WORKLOADS[a.workload]["envs"]:
+      for tname in TRAFFIC_FILES:
+        tpath = os.path.join(REPO, "profiles", tname)
+        if os.path.exists(tpath):
+          try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic_source = "profiles/%s (separate rocprofv3 --pmc passes of this command; a constant in this run)" % tname
+          except Exception:
+            traffic = None
+          break
     desc = {"island_navigation_ex": "island_navigation_ex level 9 default flags", "boat_race_ex": "boat_race_ex level 3",
             "safe_interruptibility": "safe_interruptibility level 1", "boat_race": "boat_race level 0",
             "firemaker_ex_ma": "firemaker_ex_ma level 0, 3 agents (one env-step = one round)",
@@ -258,18 +337,21 @@ def main():
                                  "challenge (one env-step = one round)",
             "mixed": "mixed suite island_navigation_ex + boat_race_ex + safe_interruptibility on 3 streams"}[a.workload]
     line = {
-        "metric": "env-steps/sec (whole node), 65 536 batched envs per GPU",
-        "value": world * n_rank * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": METRIC,
+        "value": world * n_rank * KR / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "repeats": R, "timed_steps": KR, "timed_seconds": elapsed,
+        "ms_per_step": elapsed / KR * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s, %d envs/GPU, one sgw_step launch per family per step, uniform Philox actions "
                                "resident in HBM" % (desc, n_rank),
-                   "envs_per_gpu": n_rank, "outputs": list(e0["wl"]["outputs"]), "sharding": "env-id ranges, dp%d" % world},
+                   "envs_per_gpu": n_rank, "outputs": list(e0["wl"]["outputs"]), "sharding": "env-id ranges, dp%d" % world,
+                   "timed_region": "%d repeats of the %d-step batch (>= %.2f s; warmup = %d steps + clock-ramp batches), "
+                                   "%d distinct action batches resident in HBM" % (R, K, a.min_seconds, W, n_distinct)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "sgw::k_engine<%s, K_STEP>" % e0["fam"], "avg_launch_us": kernel_ms * 1e3,
                      "algorithmic_bytes_per_env_step": e0["wl"]["b_step"], "env_steps_per_launch": e0["n"],
-                     "whole_step_algorithmic_gbs": alg_bytes / (elapsed / K) / 1e9},
+                     "whole_step_algorithmic_gbs": alg_bytes / (elapsed / KR) / 1e9},
         "returns": {fam: {"episodes_finished": float(acc[-1]),
                           "mean_episode_return": (acc[:-1] / max(acc[-1], 1.0)).tolist()}
                     for fam, (spec, acc) in returns.items()},
@@ -280,6 +362,7 @@ def main():
       threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
       threads = max(1, min(threads, 64))
       line["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds, threads)
+      line["cpu_baseline"]["reference_cpython"] = reference_cpython()
     print(json.dumps(line))
   for e in engines:
     e["eng"].close()
