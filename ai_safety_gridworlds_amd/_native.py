@@ -58,12 +58,18 @@ def lib():
   # to the runtime torch's tensors/streams live in (two runtimes => "no ROCm-capable device").
   import torch  # noqa: F401
   from . import build as _build
-  try:
-    path = _build.build()
-  except Exception as ex:   # no hipcc: use a prebuilt .so if one travelled with the tree
-    if not os.path.exists(LIB_PATH):
-      raise SgwError("libsgw.so is missing and cannot be built (%s); the engine has no CPU fallback" % ex)
-    path = LIB_PATH
+  override = os.environ.get("SGW_LIBRARY")   # diagnostics: load this build of the library instead (tools/diag/)
+  if override:
+    if not os.path.exists(override):
+      raise SgwError("SGW_LIBRARY=%s does not exist" % override)
+    path = override
+  else:
+    try:
+      path = _build.build()
+    except Exception as ex:   # no hipcc: use a prebuilt .so if one travelled with the tree
+      if not os.path.exists(LIB_PATH):
+        raise SgwError("libsgw.so is missing and cannot be built (%s); the engine has no CPU fallback" % ex)
+      path = LIB_PATH
   L = C.CDLL(path)
   L.sgw_last_error.restype = C.c_char_p
   L.sgw_create.argtypes = [C.POINTER(Spec), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]

@@ -319,6 +319,12 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
   do {                                                                                                 \
     lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, lds_need(a, F::LDS_SCRATCH_M)) + F::LDS_EXTRA; \
     const dim3 block(F::WAVES * WAVE);                                                                 \
+    {  /* the bytes requested == the bytes the kernel carves (same arithmetic, checked on every launch) */ \
+      uint8_t* const base0 = reinterpret_cast<uint8_t*>((uintptr_t)65536);                             \
+      const Lds lc = lds_carve(base0, a.sp, lds_need(a, F::LDS_SCRATCH_M));                            \
+      if ((size_t)(lc.extra - base0) + F::LDS_EXTRA != lds_bytes || ((lc.extra - base0) & 15) != 0)    \
+        return fail(SGW_ERR_ARG, "launch: LDS footprint mismatch between the launcher and the kernel's carve"); \
+    }                                                                                                  \
     if (lds_bytes > 65536) {   /* above the default dynamic-LDS cap (aintelope_savanna with every output staged) */ \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, K_STEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, K_ROLLOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \

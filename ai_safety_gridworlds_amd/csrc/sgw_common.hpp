@@ -118,7 +118,7 @@ __host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M, i
   return TABLE_BYTES + lds_board_bytes(HW) + rows * 64 * 8;   // the family's LDS_EXTRA is added by the launcher
 }
 
-__device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp, int need) {
+__host__ __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp, int need) {
   Lds l;
   l.static_board = smem;
   l.art = smem + SGW_MAX_CELLS;
