@@ -182,10 +182,8 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
 
   hipError_t err = hipMalloc((void**)&e->tables_dev, tbytes);
   if (err == hipSuccess) err = hipMemcpy(e->tables_dev, host_tables, tbytes, hipMemcpyHostToDevice);
-  const size_t sbytes = (size_t)words * (size_t)e->n_pad * 8;
+  const size_t sbytes = (size_t)state_alloc_words(words, e->n_pad) * 8;      // pair layout (sgw_common.hpp): ceil(words / 2) KiB per env-wave
   if (err == hipSuccess) err = hipMalloc((void**)&e->state_dev, sbytes);
-  // step_type ST_NONE (3) in every env's core word => the first sgw_step auto-resets
-  if (err == hipSuccess) err = hipMemset(e->state_dev, 0, sbytes);
   if (err != hipSuccess) {
     snprintf(g_err, sizeof(g_err), "sgw_create: device allocation failed: %s", hipGetErrorString(err));
     if (e->tables_dev) (void)hipFree(e->tables_dev);
@@ -194,20 +192,13 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
     return SGW_ERR_HIP;
   }
   *out_engine = e;
-  // mark "never reset": run a masked reset with an all-zero effect is not needed; core word 0 has
-  // step_type bits = 0 (FIRST) after memset, so set them to ST_NONE explicitly.
-  {
-    uint64_t none = (uint64_t)ST_NONE << 32 | (uint64_t)TERM_NONE4 << 36;
-    uint64_t* host = (uint64_t*)malloc((size_t)e->n_pad * 8);
-    if (!host) { sgw_destroy(e); *out_engine = nullptr; return fail(SGW_ERR_NOMEM, "sgw_create: out of host memory"); }
-    for (long long i = 0; i < e->n_pad; ++i) host[i] = none;
-    err = hipMemcpy(e->state_dev, host, (size_t)e->n_pad * 8, hipMemcpyHostToDevice);
-    free(host);
-    if (err != hipSuccess) {
-      snprintf(g_err, sizeof(g_err), "sgw_create: state init failed: %s", hipGetErrorString(err));
-      sgw_destroy(e); *out_engine = nullptr;
-      return SGW_ERR_HIP;
-    }
+  // step_type ST_NONE (3) in every env's core word => the first sgw_step auto-resets
+  hipLaunchKernelGGL(k_state_init, dim3((unsigned)((sbytes / 8 + 255) / 256)), dim3(256), 0, 0, e->state_dev, e->n_pad, words);
+  err = hipGetLastError();
+  if (err != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "sgw_create: state init failed: %s", hipGetErrorString(err));
+    sgw_destroy(e); *out_engine = nullptr;
+    return SGW_ERR_HIP;
   }
   // the state / table initialisation above went through the null stream: finished before the caller can launch on any
   // (possibly non-blocking) stream of its own
@@ -251,7 +242,7 @@ int sgw_set_rng_state(sgw_engine* e, const uint64_t* pcg_state_dev) {
     return fail(SGW_ERR_UNSUPPORTED, "sgw_set_rng_state: this game family has no env-side RNG stream");
   HIP_TRY(hipSetDevice(e->device));
   hipLaunchKernelGGL(k_set_rng, dim3((unsigned)((e->n_pad + 255) / 256)), dim3(256), 0, 0, e->state_dev, e->n_pad,
-                     e->n_envs, pcg_state_dev);
+                     e->n_envs, e->ks.words, pcg_state_dev);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(0));
   e->rng_set = 1;
@@ -513,7 +504,7 @@ int sgw_state_layers(sgw_engine* e, const uint8_t* layer_chars_dev, int n_layers
   const long long total = e->n_envs * e->ks.HW;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(k_savanna_layers, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e->state_dev, e->n_pad, e->n_envs,
-                     e->ks.HW, e->ks.W, (e->spec.flags & Savanna::F_TWO) ? 1 : 0, layer_chars_dev, n_layers, gap_only_blank,
+                     e->ks.words, e->ks.HW, e->ks.W, (e->spec.flags & Savanna::F_TWO) ? 1 : 0, layer_chars_dev, n_layers, gap_only_blank,
                      layers_dev);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
@@ -579,16 +570,20 @@ int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_
 int sgw_get_state(sgw_engine* e, uint64_t* state_dev, void* stream) {
   if (!e || !state_dev) return fail(SGW_ERR_ARG, "sgw_get_state: null argument");
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipMemcpyAsync(state_dev, e->state_dev, (size_t)sgw_state_bytes(e), hipMemcpyDeviceToDevice,
-                         (hipStream_t)stream));
+  const long long total = (long long)e->ks.words * e->n_pad;
+  hipLaunchKernelGGL(k_state_export, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->state_dev,
+                     e->n_pad, e->ks.words, state_dev);
+  HIP_TRY(hipGetLastError());
   return SGW_OK;
 }
 
 int sgw_set_state(sgw_engine* e, const uint64_t* state_dev, void* stream) {
   if (!e || !state_dev) return fail(SGW_ERR_ARG, "sgw_set_state: null argument");
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipMemcpyAsync(e->state_dev, state_dev, (size_t)sgw_state_bytes(e), hipMemcpyDeviceToDevice,
-                         (hipStream_t)stream));
+  const long long total = (long long)e->ks.words * e->n_pad;
+  hipLaunchKernelGGL(k_state_import, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->state_dev,
+                     e->n_pad, e->ks.words, state_dev);
+  HIP_TRY(hipGetLastError());
   e->rng_set = 1;          // a saved state carries its envs' generator streams (resume needs no sgw_set_rng_state)
   return SGW_OK;
 }

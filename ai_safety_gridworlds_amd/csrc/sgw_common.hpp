@@ -236,37 +236,63 @@ __device__ inline void store8_wt(uint64_t* p, uint64_t v) {
 #endif
 }
 
-// ---- SoA state access ------------------------------------------------------------------------
-__device__ inline uint64_t ld_word(const KArgs& a, int w, long long env) { return a.state[(long long)w * a.n_pad + env]; }
-__device__ inline void st_word(const KArgs& a, int w, long long env, uint64_t v) { a.state[(long long)w * a.n_pad + env] = v; }
+// ---- state layout and access -------------------------------------------------------------------
+// One env-wave (64 consecutive envs) owns a contiguous block of ceil(words / 2) KiB: [word pair][lane][2 words].  Lane l's
+// words 2p and 2p+1 are the 16 bytes at (p * 64 + l) * 16, so a wave moves a word PAIR of its 64 envs with one
+// 16-byte-per-lane instruction (1 KiB, fully coalesced) -- half the vector-memory instructions of word columns, and the
+// widest (cheapest per byte) access the memory pipeline has.  Single words are 8-byte accesses at a 16-byte lane stride.
+__host__ __device__ inline long long state_pairs(int words) { return (words + 1) >> 1; }
+__host__ __device__ inline long long state_index(int w, long long env, int words) {       // index in 8-byte words
+  return ((env >> 6) * state_pairs(words) + (w >> 1)) * 128 + ((env & 63) << 1) + (w & 1);
+}
+__host__ __device__ inline long long state_alloc_words(int words, long long n_pad) { return (n_pad >> 6) * state_pairs(words) * 128; }
+
+__device__ inline uint64_t ld_word(const KArgs& a, int w, long long env) { return a.state[state_index(w, env, a.sp.words)]; }
+__device__ inline void st_word(const KArgs& a, int w, long long env, uint64_t v) { a.state[state_index(w, env, a.sp.words)] = v; }
 __device__ inline double ld_f64(const KArgs& a, int w, long long env) { return __longlong_as_double((long long)ld_word(a, w, env)); }
 __device__ inline void st_f64(const KArgs& a, int w, long long env, double v) { st_word(a, w, env, (uint64_t)__double_as_longlong(v)); }
 
-// Sequential cursor over one env's state column words (word w lives at state[w * n_pad + env]); stepping
-// by the column stride avoids a 64-bit multiply per word.
+// Sequential cursor over one env's words 0, 1, 2, ...: alternates between the two halves of a pair (+1 word) and the next
+// pair (+127 words).  In straight-line code `odd` folds to a constant; after a conditional advance it is a wave-uniform scalar.
 struct Cursor {
   uint64_t* p;
-  long long stride;
-  __device__ Cursor(const KArgs& a, long long env) : p(a.state + env), stride(a.n_pad) {}
-  __device__ uint64_t get() { uint64_t v = *p; p += stride; return v; }
+  uint64_t* w0;          // the env's word 0 (always valid: where disabled conditional reads go)
+  int odd;
+  __device__ Cursor(const KArgs& a, long long env) : p(a.state + state_index(0, env, a.sp.words)), w0(p), odd(0) {}
+  __device__ void advance() { p += odd ? 127 : 1; odd ^= 1; }
+  __device__ uint64_t get() { uint64_t v = *p; advance(); return v; }
   __device__ double getf() { return __longlong_as_double((long long)get()); }
-#ifdef SGW_STATE_WT
-  __device__ void put(uint64_t v) { store8_wt(p, v); p += stride; }
-#else
-  __device__ void put(uint64_t v) { *p = v; p += stride; }  // plain: the next launch re-reads the state from this XCD's L2
-#endif
+  __device__ void put(uint64_t v) { *p = v; advance(); }
   __device__ void putf(double v) { put((uint64_t)__double_as_longlong(v)); }
-  __device__ void skip(int n) { p += stride * n; }
-  // conditional (wave-uniform) column access without a branch: a disabled slot reads the env's word 0 (always valid)
-  // and contributes `fallback`; an enabled one advances the cursor.  Stores to a disabled slot are skipped by
-  // pointing them at `trash` (a per-env scratch column the caller owns).
-  __device__ double getf_if(bool on, const uint64_t* dummy, double fallback) {
-    const uint64_t* q = on ? p : dummy;
+  __device__ void skip(int n) { for (int i = 0; i < n; ++i) advance(); }
+  // conditional (wave-uniform) access without a branch: a disabled slot reads the env's word 0 and contributes `fallback`;
+  // an enabled one advances the cursor.
+  __device__ double getf_if(bool on, double fallback) {
+    const uint64_t* q = on ? p : w0;
     const double v = __longlong_as_double((long long)*q);
-    p += on ? stride : 0;
+    p += on ? (odd ? 127 : 1) : 0;
+    odd ^= on ? 1 : 0;
     return on ? v : fallback;
   }
 };
+
+// Word PAIRS, 16 bytes per lane per instruction (families whose word order is fixed at compile time).
+struct Cursor2 {
+  uint4* p;
+  __device__ Cursor2(const KArgs& a, long long env) : p(reinterpret_cast<uint4*>(a.state + state_index(0, env, a.sp.words))) {}
+  __device__ void get2(uint64_t& x, uint64_t& y) {
+    const uint4 v = *p; p += 64;
+    x = (uint64_t)v.x | ((uint64_t)v.y << 32); y = (uint64_t)v.z | ((uint64_t)v.w << 32);
+  }
+  // `wt`: write-through (sc1) -- the bytes leave the XCD's L2 while the kernel runs instead of at the kernel boundary
+  template <bool WT> __device__ void put2(uint64_t x, uint64_t y) {
+    const uint4 v = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32));
+    if constexpr (WT) store16_wt(p, v); else *p = v;
+    p += 64;
+  }
+};
+__device__ inline double u2f(uint64_t v) { return __longlong_as_double((long long)v); }
+__device__ inline uint64_t f2u(double v) { return (uint64_t)__double_as_longlong(v); }
 
 // ---- cooperative (wave-wide) env-major output stores -----------------------------------------
 // The wave's 64 rows of `row_bytes` bytes are contiguous in global memory at dst + env0*row_bytes

@@ -69,7 +69,7 @@ struct IslandT {
     s.d_avail = c.getf(); s.f_avail = c.getf();
     s.d_frac = c.getf(); s.f_frac = c.getf();
 #pragma unroll
-    for (int u = 0; u < NU; ++u) s.cum[u] = c.getf_if(a.sp.dim_slot[0][u] >= 0, a.state + env, 0.0);   // slots ascend with u
+    for (int u = 0; u < NU; ++u) s.cum[u] = c.getf_if(a.sp.dim_slot[0][u] >= 0, 0.0);   // slots ascend with u
   }
 
   static __device__ void store(const State& s, const KArgs& a, long long env) {

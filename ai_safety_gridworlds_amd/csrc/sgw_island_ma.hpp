@@ -114,7 +114,7 @@ struct IslandMa {
     s.d_avail = c.getf(); s.d_frac = c.getf(); s.f_avail = c.getf(); s.f_frac = c.getf();
     s.map.a = c.get(); s.map.b = c.get(); s.map.c = c.get(); s.map.d = c.get();
 #pragma unroll
-    for (int u = 0; u < NU; ++u) s.cum[u] = c.getf_if(slot(a.sp, u) >= 0, a.state + env, 0.0);   // slots ascend with u
+    for (int u = 0; u < NU; ++u) s.cum[u] = c.getf_if(slot(a.sp, u) >= 0, 0.0);   // slots ascend with u
   }
 
   static __device__ void store(const State& s, const KArgs& a, long long env) {

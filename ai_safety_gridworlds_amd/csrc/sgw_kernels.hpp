@@ -346,15 +346,38 @@ __global__ void k_pow(const double* x, double y, double* out, long long n) {
 }
 
 // numpy PCG64 streams into the firemaker state (words 3..6), buffered-uint32 flag (word 0 bit 27) cleared
-__global__ void k_set_rng(uint64_t* state, long long n_pad, long long n, const uint64_t* pcg) {
+__global__ void k_set_rng(uint64_t* state, long long n_pad, long long n, int words, const uint64_t* pcg) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_pad) return;
   // padding lanes run the same code as real envs: give them a working stream too (an all-zero PCG state returns 0 for
   // ever, and Lemire's rejection loop never leaves on a constant 0)
   const uint64_t pad[4] = {0x9E3779B97F4A7C15ull, (uint64_t)e, 0ull, 1ull};
-  for (int k = 0; k < 4; ++k) state[(3 + k) * n_pad + e] = e < n ? pcg[e * 4 + k] : pad[k];
-  state[0 * n_pad + e] &= ~(1ull << 27);
-  state[2 * n_pad + e] &= ~0xffffffffull;
+  for (int k = 0; k < 4; ++k) state[state_index(3 + k, e, words)] = e < n ? pcg[e * 4 + k] : pad[k];
+  state[state_index(0, e, words)] &= ~(1ull << 27);
+  state[state_index(2, e, words)] &= ~0xffffffffull;
+}
+
+// canonical view of the state for sgw_get_state / sgw_set_state: uint64 [words][n_pad] <-> the engine's pair layout
+__global__ void k_state_export(const uint64_t* state, long long n_pad, int words, uint64_t* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)words * n_pad) return;
+  const int w = (int)(i / n_pad);
+  const long long e = i - (long long)w * n_pad;
+  out[i] = state[state_index(w, e, words)];
+}
+__global__ void k_state_import(uint64_t* state, long long n_pad, int words, const uint64_t* in) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)words * n_pad) return;
+  const int w = (int)(i / n_pad);
+  const long long e = i - (long long)w * n_pad;
+  state[state_index(w, e, words)] = in[i];
+}
+// every env "never reset": step_type ST_NONE, termination reason absent, everything else zero
+__global__ void k_state_init(uint64_t* state, long long n_pad, int words) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= state_alloc_words(words, n_pad)) return;
+  const bool word0 = ((i & 127) & 1) == 0 && ((i >> 7) % state_pairs(words)) == 0;
+  state[i] = word0 ? (((uint64_t)ST_NONE << 32) | ((uint64_t)15 << 36)) : 0ull;
 }
 
 // ---- derived statistics (safety_game_mo.py:1027-1084) in numpy's summation order -----------------------------

@@ -152,7 +152,7 @@ struct Savanna {
 #pragma unroll
     for (int d = 0; d < 5; ++d) { s.dyn[d].a = c.get(); s.dyn[d].b = c.get(); s.dyn[d].c = c.get(); }
 #pragma unroll
-    for (int u = 0; u < NU; ++u) s.cum[u] = c.getf_if(slot(a.sp, u) >= 0, a.state + env, 0.0);   // slots ascend with u
+    for (int u = 0; u < NU; ++u) s.cum[u] = c.getf_if(slot(a.sp, u) >= 0, 0.0);   // slots ascend with u
   }
 
   static __device__ __forceinline__ void store(const State& s, const KArgs& a, long long env) {
@@ -673,15 +673,15 @@ struct Savanna {
 // Unoccluded observation layers straight from the state bitmaps (the rendered board only shows the top drape of a cell):
 // layers[n][l][cell] for the characters in layer_chars ('#', ' ', W P D F d f G S, '0', '1'); the gap layer is set only
 // where every other layer is blank when gap_only_blank (observe_gaps_only_where_other_layers_are_blank=True, SV:1690).
-__global__ void k_savanna_layers(const uint64_t* state, long long n_pad, long long n, int HW, int W, int two,
+__global__ void k_savanna_layers(const uint64_t* state, long long n_pad, long long n, int words, int HW, int W, int two,
                                  const uint8_t* layer_chars, int n_layers, int gap_only_blank, uint8_t* layers) {
   const long long total = n * HW;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long env = i / HW;
     const int cell = (int)(i - env * HW);
     const int wi = cell >> 6, sh = cell & 63;
-    auto bit = [&](int word0) { return (int)((state[(long long)(word0 + wi) * n_pad + env] >> sh) & 1ull); };
-    const uint64_t w1 = state[1 * n_pad + env];
+    auto bit = [&](int word0) { return (int)((state[state_index(word0 + wi, env, words)] >> sh) & 1ull); };
+    const uint64_t w1 = state[state_index(1, env, words)];
     const int c0 = (int)(w1 & 0xff) * W + (int)((w1 >> 8) & 0xff), c1 = (int)((w1 >> 16) & 0xff) * W + (int)((w1 >> 24) & 0xff);
     const int wall = bit(Savanna::W_STATIC), water = bit(Savanna::W_STATIC + 3), gold = bit(Savanna::W_STATIC + 6), silver = bit(Savanna::W_STATIC + 9);
     const int P = bit(Savanna::W_DYN), D = bit(Savanna::W_DYN + 3), F = bit(Savanna::W_DYN + 6), sd = bit(Savanna::W_DYN + 9), sf = bit(Savanna::W_DYN + 12);

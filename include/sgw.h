@@ -260,7 +260,8 @@ int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agen
 int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_t* agent_pos_dev, const uint8_t* agent_flags_dev,
                           const uint8_t* layer_chars_dev, int n_layers, uint8_t outside_chr, uint8_t* out_dev, void* stream);
 
-/* Raw SoA state copy-out / copy-in (tests, checkpointing): uint64 [words][N_pad]. */
+/* State copy-out / copy-in (tests, checkpointing) in a layout-independent form: uint64 [words][N_pad], word w of env n at
+ * [w][n] (the engine itself keeps word pairs interleaved per 64-env wave; these two calls convert). */
 int sgw_state_words(const sgw_engine* e);
 int sgw_get_state(sgw_engine* e, uint64_t* state_dev, void* stream);
 int sgw_set_state(sgw_engine* e, const uint64_t* state_dev, void* stream);

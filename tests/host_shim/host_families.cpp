@@ -74,11 +74,11 @@ template <class F> static void setup(Host& h, const uint64_t* rng) {
   std::memcpy(h.tables.data() + 3 * SGW_MAX_CELLS, sp.value_map, 512);
   std::memcpy(h.tables.data() + 3 * SGW_MAX_CELLS + 512, sp.params, SGW_N_PARAMS * 8);
   h.n_pad = (h.n + 63) / 64 * 64;
-  h.state.assign((size_t)k.words * h.n_pad, 0);
-  for (long long e = 0; e < h.n_pad; ++e) h.state[e] = ((uint64_t)ST_NONE << 32) | ((uint64_t)15 << 36);      // sgw_create
+  h.state.assign((size_t)state_alloc_words(k.words, h.n_pad), 0);
+  for (long long e = 0; e < h.n_pad; ++e) h.state[state_index(0, e, k.words)] = ((uint64_t)ST_NONE << 32) | ((uint64_t)15 << 36);      // sgw_create
   if (rng) for (long long e = 0; e < h.n_pad; ++e) {                                                           // k_set_rng
     const uint64_t pad[4] = {0x9E3779B97F4A7C15ull, (uint64_t)e, 0ull, 1ull};
-    for (int q = 0; q < 4; ++q) h.state[(size_t)(3 + q) * h.n_pad + e] = e < h.n ? rng[e * 4 + q] : pad[q];
+    for (int q = 0; q < 4; ++q) h.state[state_index(3 + q, e, k.words)] = e < h.n ? rng[e * 4 + q] : pad[q];
   }
   h.a.tables = h.tables.data(); h.a.state = h.state.data(); h.a.n_pad = h.n_pad; h.a.n_envs = h.n; h.a.T = 1;
   h.a.ftable = h.ftable.empty() ? nullptr : h.ftable.data();
