@@ -17,7 +17,10 @@ LIB = os.path.join(HERE, "libsgw.so")
 SOURCES = ["sgw_api.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical",
+         # k_engine's leading scalar arguments (state / tables / actions pointers, sizes) arrive preloaded in SGPRs at wave
+         # launch, so the prologue's global loads do not wait for a scalar load of the kernarg segment first
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _deps():

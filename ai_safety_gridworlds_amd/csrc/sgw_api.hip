@@ -66,9 +66,13 @@ struct sgw_engine {
   long long ftable_n;
 };
 
+// island_navigation_ex: the packed (i16) state when the spec proves it exact (sgw_island.hpp); SGW_ISLAND_PLAIN_STATE in the
+// environment forces the plain f64 state (tests run every fixture through both).
+static bool island_packable(const sgw_spec& sp) { return !getenv("SGW_ISLAND_PLAIN_STATE") && Island::packable(sp); }
+
 static int family_words(const sgw_spec& sp) {
   switch (sp.family) {
-    case SGW_ISLAND_NAVIGATION_EX: return Island::words(sp.K);
+    case SGW_ISLAND_NAVIGATION_EX: return island_packable(sp) ? IslandPacked::words(sp.K) : Island::words(sp.K);
     case SGW_BOAT_RACE_EX:
     case SGW_BOAT_RACE: return Boat::words(sp.K, sp.H * sp.W);
     case SGW_SAFE_INTERRUPTIBILITY: return SafeInt::words();
@@ -166,8 +170,10 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   memset(&k, 0, sizeof(k));
   k.family = spec->family; k.H = spec->H; k.W = spec->W; k.HW = HW; k.K = spec->K; k.M = spec->M;
   k.A = spec->A; k.max_iterations = spec->max_iterations; k.flags = spec->flags;
+  if (spec->family == SGW_ISLAND_NAVIGATION_EX) k.flags = (k.flags & ~Island::F_PACKED) | (island_packable(*spec) ? Island::F_PACKED : 0);
   k.action_lo = spec->action_lo; k.n_actions = spec->n_actions; k.words = words;
   memcpy(k.start_cell, spec->start_cell, sizeof(k.start_cell));
+  kspec_derive(k);
   memcpy(k.dim_slot, spec->dim_slot, sizeof(k.dim_slot));
   memcpy(k.metric_slot, spec->metric_slot, sizeof(k.metric_slot));
 
@@ -303,31 +309,37 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
   a.n_pad = e->n_pad; a.n_envs = e->n_envs; a.env_id_base = e->env_id_base;
   a.ep_bits = e->ep_bits; a.ep_bits_n = e->ep_bits_n; a.ep_seed = e->ep_seed;
   a.rand_stream = e->rand_stream; a.rand_n = e->rand_n; a.rand_seed = e->rand_seed;
-  const dim3 grid((unsigned)(e->n_pad / WAVE));
-  const int kind = a.mode == MODE_RESET ? K_RESET : (a.T == 1 ? K_STEP : K_ROLLOUT);
+  const long long n_waves = e->n_pad / WAVE;
+  const int kind = a.mode == MODE_RESET ? K_RESET : ((a.T == 1 && a.actions) ? K_STEP : K_ROLLOUT);   // K_STEP reads the caller's actions only
   size_t lds_bytes = 0;
 #define SGW_LAUNCH(F)                                                                                  \
   do {                                                                                                 \
-    lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, lds_need(a, F::LDS_SCRATCH_M)) + F::LDS_EXTRA; \
-    const dim3 block(F::WAVES * WAVE);                                                                 \
+    constexpr int EW = env_waves<F>();                                                                 \
+    const int need = lds_need(a, F::LDS_SCRATCH_M);                                                    \
+    lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, need, F::LDS_EXTRA, EW);              \
+    const dim3 grid((unsigned)((n_waves + EW - 1) / EW));                                              \
+    const dim3 block(wg_threads<F>());                                                                 \
     {  /* the bytes requested == the bytes the kernel carves (same arithmetic, checked on every launch) */ \
       uint8_t* const base0 = reinterpret_cast<uint8_t*>((uintptr_t)65536);                             \
-      const Lds lc = lds_carve(base0, a.sp, lds_need(a, F::LDS_SCRATCH_M));                            \
-      if ((size_t)(lc.extra - base0) + F::LDS_EXTRA != lds_bytes || ((lc.extra - base0) & 15) != 0)    \
+      const Lds lc = lds_carve(base0, a.sp, need, F::LDS_EXTRA, EW - 1);                               \
+      const size_t end = (size_t)(reinterpret_cast<uint8_t*>(lc.trash + 64) - base0);                  \
+      if (end != lds_bytes || ((lc.extra - base0) & 15) != 0 || ((reinterpret_cast<uint8_t*>(lc.board) - base0) & 15) != 0) \
         return fail(SGW_ERR_ARG, "launch: LDS footprint mismatch between the launcher and the kernel's carve"); \
     }                                                                                                  \
-    if (lds_bytes > 65536) {   /* above the default dynamic-LDS cap (aintelope_savanna with every output staged) */ \
+    if (lds_bytes > 65536) {   /* above the default dynamic-LDS cap */                                 \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, K_STEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, K_ROLLOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, K_RESET>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
     }                                                                                                  \
-    if (kind == K_STEP) hipLaunchKernelGGL((k_engine<F, K_STEP>), grid, block, lds_bytes, st, a);   \
-    else if (kind == K_ROLLOUT) hipLaunchKernelGGL((k_engine<F, K_ROLLOUT>), grid, block, lds_bytes, st, a); \
-    else hipLaunchKernelGGL((k_engine<F, K_RESET>), grid, block, lds_bytes, st, a);                 \
+    if (kind == K_STEP) hipLaunchKernelGGL((k_engine<F, K_STEP>), grid, block, lds_bytes, st, SGW_HOT_ARGS(a), a);   \
+    else if (kind == K_ROLLOUT) hipLaunchKernelGGL((k_engine<F, K_ROLLOUT>), grid, block, lds_bytes, st, SGW_HOT_ARGS(a), a); \
+    else hipLaunchKernelGGL((k_engine<F, K_RESET>), grid, block, lds_bytes, st, SGW_HOT_ARGS(a), a);                 \
   } while (0)
   switch (e->spec.family) {
     case SGW_ISLAND_NAVIGATION_EX:
-      if (e->spec.flags & Island::F_GENERAL) SGW_LAUNCH(IslandGeneral); else SGW_LAUNCH(Island);
+      if (e->spec.flags & Island::F_GENERAL) SGW_LAUNCH(IslandGeneral);
+      else if (e->ks.flags & Island::F_PACKED) SGW_LAUNCH(IslandPacked);
+      else SGW_LAUNCH(Island);
       break;
     case SGW_BOAT_RACE_EX:
     case SGW_BOAT_RACE: SGW_LAUNCH(Boat); break;

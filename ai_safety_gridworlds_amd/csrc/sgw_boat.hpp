@@ -66,7 +66,7 @@ struct Boat {
   // BX:146-199: new sprite, tile_visit_count = zeros with the spawn cell pre-counted as 1 (Q9)
   static __device__ void begin_episode(State& s, const KArgs& a, const Lds& l, long long env, long long env_id) {
     const KSpec& sp = a.sp;
-    s.row = sp.start_cell[0] / sp.W; s.col = sp.start_cell[0] % sp.W;
+    s.row = sp.start_row[0]; s.col = sp.start_col[0];
     s.frame = 0; s.step_type = ST_FIRST; s.term = 15; s.actual = -1;
     s.episode += 1; s.hidden = 0.0;
 #pragma unroll

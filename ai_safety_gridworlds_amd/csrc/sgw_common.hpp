@@ -1,9 +1,9 @@
 // sgw_common.hpp -- device-side building blocks shared by every game family (gfx950 / wave64).
 //
-// Execution model: one lane per env, one 64-lane wavefront per workgroup (64 envs), grid =
-// N_pad / 64.  Everything a wave needs that is identical for all envs (level tables) is staged
-// in LDS once per workgroup; per-env state lives in HBM as struct-of-arrays 8-byte columns
-// (state[word][env]) so every state load/store is one fully coalesced 512-byte wave access.
+// Execution model: one lane per env, one 64-lane wavefront per 64 envs ("env-wave"), ENV_WAVES env-waves per workgroup
+// (one per SIMD of a CU), grid = ceil(N_pad / 64 / ENV_WAVES).  Everything that is identical for all envs (level tables,
+// the family's read-only tables) is staged in LDS ONCE per workgroup and shared by its env-waves; per-env state lives in
+// HBM as word pairs interleaved per env-wave (see "state layout") so a wave moves 16 bytes per lane per instruction.
 // Env-major outputs ([N, H*W] boards, [N, K] reward vectors) are transposed through LDS so the
 // wave writes its 64 rows as one contiguous run of 16-byte-per-lane stores.
 #pragma once
@@ -16,12 +16,14 @@
 namespace sgw {
 
 constexpr int WAVE = 64;
+constexpr int ENV_WAVES = 4;        // independent env-waves per workgroup (non-cooperative families): 256 envs share one table copy
 constexpr int TABLE_BYTES = 2048;   // 3*320 level tables + 512 value map + 72*8 params: exactly 2 x 16 B per lane
 
 // ---- kernel arguments (by value => kernarg segment => scalar loads) -------------------------
 struct KSpec {
   int family, H, W, HW, K, M, A, max_iterations, flags, action_lo, n_actions, words;
   int start_cell[SGW_MAX_AGENTS];
+  int start_row[SGW_MAX_AGENTS], start_col[SGW_MAX_AGENTS];   // start_cell / W and % W (host-computed: no scalar division per launch)
   int8_t dim_slot[SGW_MAX_AGENTS][SGW_MAX_K];
   int8_t metric_slot[SGW_MAX_M];
 };
@@ -52,6 +54,9 @@ struct KArgs {
 #endif
 };
 
+// leading scalar kernel arguments of k_engine (preloaded into SGPRs at wave launch): what the prologue's loads need
+#define SGW_HOT_ARGS(a) (a).state, (a).tables, (a).actions, (a).n_pad, (a).n_envs, (a).sp.words
+
 // In-kernel phase stamps: compiled in ONLY by the diagnostic probe (-DSGW_STAMPS); libsgw.so carries none.
 #ifdef SGW_STAMPS
 #define SGW_STAMP(a, k)                                                                          \
@@ -60,7 +65,7 @@ struct KArgs {
     __builtin_amdgcn_sched_barrier(0);                                                           \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
     __builtin_amdgcn_sched_barrier(0);                                                           \
-    if (threadIdx.x == 0) (a).sgw_stamps[blockIdx.x * 8 + (k)] = t_;                             \
+    if ((threadIdx.x & 63) == 0) (a).sgw_stamps[sgw_stamp_wave * 8 + (k)] = t_;                   \
   } while (0)
 #define SGW_STAMP_RT(a, k)                                                                       \
   do {                                                                                           \
@@ -68,36 +73,41 @@ struct KArgs {
     __builtin_amdgcn_sched_barrier(0);                                                           \
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
     __builtin_amdgcn_sched_barrier(0);                                                           \
-    if (threadIdx.x == 0) (a).sgw_stamps[blockIdx.x * 8 + (k)] = t_;                             \
+    if ((threadIdx.x & 63) == 0) (a).sgw_stamps[sgw_stamp_wave * 8 + (k)] = t_;                   \
   } while (0)
 #else
 #define SGW_STAMP(a, k) do { } while (0)
 #define SGW_STAMP_RT(a, k) do { } while (0)
 #endif
 
+__host__ __device__ inline void kspec_derive(KSpec& k) {
+  for (int ag = 0; ag < SGW_MAX_AGENTS; ++ag) { k.start_row[ag] = k.W > 0 ? k.start_cell[ag] / k.W : 0; k.start_col[ag] = k.W > 0 ? k.start_cell[ag] % k.W : 0; }
+}
+
 enum { MODE_STEP = 0, MODE_RESET = 1 };
 enum { ST_FIRST = 0, ST_MID = 1, ST_LAST = 2, ST_NONE = 3 };   // ST_NONE: never reset yet
 
 // ---- LDS layout (dynamic shared memory, carved by the host with the same arithmetic) --------
+//   [ level tables 2 KiB | family-private F::LDS_EXTRA (shared by the workgroup) | env-wave 0 staging | env-wave 1 staging | ... ]
 struct Lds {
   uint8_t* static_board;   // [SGW_MAX_CELLS]
   uint8_t* art;            // [SGW_MAX_CELLS]
   uint8_t* aux;            // [SGW_MAX_CELLS]
   float* value_map;        // [128]
   const double* params;    // [SGW_N_PARAMS] family constants (vector registers on demand, not SGPRs)
-  uint32_t* board;         // 64*HW bytes (+ slack), the wave's 64 board rows, contiguous
+  uint8_t* extra;          // F::LDS_EXTRA bytes of family-private LDS (16-byte aligned), shared by the workgroup
+  uint32_t* board;         // 64*HW bytes (+ slack), THIS wave's 64 board rows, contiguous
   double* vec_r;           // 64*A*K doubles: reward rows
   double* vec_c;           // 64*A*K doubles: cumulative rows
   double* vec_m;           // 64*M doubles: metrics rows
   double* vec_a;           // 64*(A*K+1) doubles: finished-episode returns staged for the per-wave sum
   double* trash;           // 64 doubles: where writes of not-enabled reward dimensions / absent metrics land (branch-free)
-  uint8_t* extra;          // F::LDS_EXTRA bytes of family-private LDS (16-byte aligned), after everything else
 };
 
 __host__ __device__ inline size_t lds_board_bytes(int HW) { return ((size_t)64 * HW + 15) / 16 * 16 + 16; }
 // Staging regions are carved only for the outputs a launch asked for (host and device evaluate the same
 // arithmetic on the same KArgs): the LDS footprint of a wave decides how many waves a CU keeps resident when a launch
-// has more than one wave per SIMD (26 KB/wave with everything staged caps a CU at 4 waves; reward-only island is 16 KB).
+// has more than one wave per SIMD.
 enum { LN_REWARD = 1, LN_CUMULATIVE = 2, LN_METRICS = 4, LN_RETURNS = 8 };
 __host__ __device__ inline int lds_need(const KArgs& a, bool family_scratch_m) {
   return (a.out.reward ? LN_REWARD : 0) | (a.out.cumulative ? LN_CUMULATIVE : 0) |
@@ -112,43 +122,51 @@ __host__ __device__ inline size_t lds_rows(int A, int K, int M, int need, int wh
     default: return (need & LN_RETURNS) ? A * K + 1 : 0;
   }
 }
-__host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M, int need) {
+// one env-wave's staging bytes
+__host__ __device__ inline size_t lds_wave_bytes(int HW, int A, int K, int M, int need) {
   const size_t rows = lds_rows(A, K, M, need, LN_REWARD) + lds_rows(A, K, M, need, LN_CUMULATIVE) +
                       lds_rows(A, K, M, need, LN_METRICS) + lds_rows(A, K, M, need, LN_RETURNS) + 1;   // + trash
-  return TABLE_BYTES + lds_board_bytes(HW) + rows * 64 * 8;   // the family's LDS_EXTRA is added by the launcher
+  return lds_board_bytes(HW) + rows * 64 * 8;
+}
+__host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M, int need, int extra, int env_waves) {
+  return TABLE_BYTES + (size_t)extra + (size_t)env_waves * lds_wave_bytes(HW, A, K, M, need);
 }
 
-__host__ __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp, int need) {
+__host__ __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp, int need, int extra, int wave) {
   Lds l;
   l.static_board = smem;
   l.art = smem + SGW_MAX_CELLS;
   l.aux = smem + 2 * SGW_MAX_CELLS;
   l.value_map = reinterpret_cast<float*>(smem + 3 * SGW_MAX_CELLS);
   l.params = reinterpret_cast<const double*>(smem + 3 * SGW_MAX_CELLS + 512);
-  l.board = reinterpret_cast<uint32_t*>(smem + TABLE_BYTES);
-  l.vec_r = reinterpret_cast<double*>(smem + TABLE_BYTES + lds_board_bytes(sp.HW));
+  l.extra = smem + TABLE_BYTES;
+  uint8_t* w = smem + TABLE_BYTES + extra + (size_t)wave * lds_wave_bytes(sp.HW, sp.A, sp.K, sp.M, need);
+  l.board = reinterpret_cast<uint32_t*>(w);
+  l.vec_r = reinterpret_cast<double*>(w + lds_board_bytes(sp.HW));
   l.vec_c = l.vec_r + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_REWARD);
   l.vec_m = l.vec_c + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_CUMULATIVE);
   l.vec_a = l.vec_m + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_METRICS);
   l.trash = l.vec_a + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_RETURNS);
-  l.extra = reinterpret_cast<uint8_t*>(l.trash + 64);
   return l;
 }
 
-// tables (2048 bytes) -> LDS: exactly two 16-byte loads per lane, both in flight before the single wait
-template <int WAVES>
-__device__ inline void lds_load_tables(uint8_t* smem, const uint8_t* tables) {
+// tables (2048 bytes = 128 x 16 B) -> LDS in two halves: `issue` only LOADS (unconditionally, index clamped), so the
+// caller can put every other global load of the prologue behind it before anything waits; `commit` writes LDS.
+struct TableStage { uint4 t0, t1; };
+template <int THREADS>
+__device__ inline void lds_tables_issue(TableStage& ts, const uint8_t* tables) {
   const uint4* src = reinterpret_cast<const uint4*>(tables);
+  if constexpr (THREADS == WAVE) { ts.t0 = src[threadIdx.x]; ts.t1 = src[threadIdx.x + WAVE]; }
+  else { ts.t0 = src[threadIdx.x & (TABLE_BYTES / 16 - 1)]; }
+}
+template <int THREADS>
+__device__ inline void lds_tables_commit(const TableStage& ts, uint8_t* smem) {
   uint4* dst = reinterpret_cast<uint4*>(smem);
-  if constexpr (WAVES == 1) {
-    const uint4 t0 = src[threadIdx.x], t1 = src[threadIdx.x + WAVE];
-    dst[threadIdx.x] = t0; dst[threadIdx.x + WAVE] = t1;
-  } else {
-    if (threadIdx.x < TABLE_BYTES / 16) dst[threadIdx.x] = src[threadIdx.x];
-  }
+  if constexpr (THREADS == WAVE) { dst[threadIdx.x] = ts.t0; dst[threadIdx.x + WAVE] = ts.t1; }
+  else { dst[threadIdx.x & (TABLE_BYTES / 16 - 1)] = ts.t0; }   // unconditional (upper threads rewrite the same bytes): no branch for the loads to sink into
 }
 
-// One wavefront per workgroup: lanes exchange data through LDS in program order (the LDS pipeline executes
+// Within ONE wavefront lanes exchange data through LDS in program order (the LDS pipeline executes
 // a wave's ds_* instructions in issue order), so a cross-lane LDS hand-off needs only a COMPILER fence --
 // no s_barrier and, unlike __syncthreads(), no s_waitcnt vmcnt(0) that would stall on in-flight global stores.
 __device__ inline void lds_wave_sync() {
@@ -297,13 +315,13 @@ __device__ inline uint64_t f2u(double v) { return (uint64_t)__double_as_longlong
 // ---- cooperative (wave-wide) env-major output stores -----------------------------------------
 // The wave's 64 rows of `row_bytes` bytes are contiguous in global memory at dst + env0*row_bytes
 // (env0 % 64 == 0 => 16-byte aligned for any row_bytes); copy them from LDS 16 B per lane.
-__device__ inline void coop_store(void* dst, long long env0, int row_bytes, const void* lds_src) {
+__device__ inline void coop_store(void* dst, long long env0, int row_bytes, const void* lds_src, int lane) {
   uint4* g = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(dst) + env0 * row_bytes);
   const uint4* s = reinterpret_cast<const uint4*>(lds_src);
   const int nchunk = 4 * row_bytes;               // 64 * row_bytes / 16
   // batches of 4 chunks per lane: the 4 LDS reads are unconditional (index clamped) so they issue back to back;
   // only the stores are guarded
-  for (int base = threadIdx.x; base < nchunk; base += 4 * WAVE) {
+  for (int base = lane; base < nchunk; base += 4 * WAVE) {
     const int last = nchunk - 1;
     const int c0 = base, c1 = base + WAVE, c2 = base + 2 * WAVE, c3 = base + 3 * WAVE;
     const uint4 v0 = s[c0], v1 = s[c1 < last ? c1 : last], v2 = s[c2 < last ? c2 : last], v3 = s[c3 < last ? c3 : last];
@@ -397,7 +415,7 @@ __device__ inline void lds_write_board_row_fn(uint32_t* img, int HW, int lane, D
 }
 __device__ inline void lds_zero_board(uint32_t* img, int HW) {
   int n = (int)(lds_board_bytes(HW) / 4);
-  for (int i = threadIdx.x; i < n; i += WAVE) img[i] = 0u;
+  for (int i = (int)(threadIdx.x & (WAVE - 1)); i < n; i += WAVE) img[i] = 0u;
 }
 
 // wave-wide sum (for the episodic-return accumulators)

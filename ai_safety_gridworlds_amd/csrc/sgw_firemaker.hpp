@@ -129,7 +129,7 @@ struct Firemaker {
     const KSpec& sp = a.sp;
     s.frame = 0; s.step_type = ST_FIRST; s.term = 15; s.countdown = 0; s.n_ext = 0; s.at_ws = 0;
 #pragma unroll
-    for (int ag = 0; ag < 3; ++ag) { s.row[ag] = sp.start_cell[ag] / W; s.col[ag] = sp.start_cell[ag] % W; }
+    for (int ag = 0; ag < 3; ++ag) { s.row[ag] = sp.start_row[ag]; s.col[ag] = sp.start_col[ag]; }
     s.episode += 1;
     s.fire.a = s.fire.b = s.fire.c = s.fire.d = s.fire.e = 0;
 #pragma unroll

@@ -66,7 +66,7 @@ struct FriendFoe {
       for (int b = 0; b < 3; ++b) { s.pol[b][0] = 0.5; s.pol[b][1] = 0.5; }
       s.draws = 0;
     }
-    s.row = sp.start_cell[0] / sp.W; s.col = sp.start_cell[0] % sp.W;
+    s.row = sp.start_row[0]; s.col = sp.start_col[0];
     s.frame = 0; s.step_type = ST_FIRST; s.term = 15; s.actual = -1; s.cum[0] = 0.0; s.showing = 0;
     int bt = (int)p[P_FIXED];
     if (bt < 0) { bt = (int)(next_uniform(a, env, env_id, s.draws) * 3.0); bt = bt > 2 ? 2 : bt; }

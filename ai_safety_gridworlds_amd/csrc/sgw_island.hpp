@@ -17,8 +17,15 @@
 // spec.aux   : safety distance per cell (99 = no water on the map)
 // metrics ids: 0 DrinkSatiation 1 DrinkAvailability 2 FoodSatiation 3 FoodAvailability 4 GapVisits
 //              5 DrinkVisits 6 FoodVisits 7 GoldVisits 8 SilverVisits          (IN:147-153, 363-372)
-// state words: 0 core | 1 visits(gap,drink,food,gold) | 2 silver,episode | 3..8 f64 drink_sat,
-//              food_sat, drink_avail, food_avail, drink_frac, food_frac | 9.. cumulative[K]
+// state words (fixed order => word PAIRS move with 16-byte accesses, Cursor2):
+//   plain : 0 core | 1 visits(gap,drink,food,gold) | 2 silver,episode | 3..8 f64 drink_sat, food_sat, drink_avail,
+//           food_avail, drink_frac, food_frac | 9..20 cumulative[12 universe dims] (+1 pad)            = 22 words, 176 B
+//   packed: 0 core | 1 visits | 2 silver,episode | 3 (drink_sat, food_sat, drink_avail, food_avail) as 4 x i16 |
+//           4, 5 f64 drink_frac, food_frac | 6..8 cumulative[12] as 12 x i16 (+1 pad)                  = 10 words,  80 B
+// The packed form is EXACT, not an approximation: sgw_create selects it only when `packable()` proves from the spec that
+// every reward / satiation / availability parameter is an integer and that no packed quantity can leave the i16 range
+// within max_iterations steps (the default flags: |values| <= 5 000); the kernel computes in f64 either way and the
+// conversions i16 <-> f64 are exact on that domain.  Anything else (fractional flags, long episodes) runs the plain form.
 #pragma once
 
 #include "sgw_common.hpp"
@@ -29,13 +36,13 @@ namespace sgw {
 // GENERAL: reward flags that put one event on several dimensions (per-event vectors from a.ftable).  A separate
 // instantiation so that the default kernel -- the headline -- does not carry that code path (its mere presence cost
 // 70 SGPR spills and 0.5 us per launch).
-template <bool GENERAL>
+template <bool GENERAL, bool PACKED = false>
 struct IslandT {
   static constexpr int NU = 12;
   static constexpr int NMETRIC = 9;
   // reward universe in sorted-name order (mo_reward.py:142-146)
   enum { DANGER, DRINK_DEF, DRINK_OVER, DRINK, FINAL, FOOD_DEF, FOOD_OVER, FOOD, GOLD, MOVEMENT, SILVER, DEATH };
-  enum { F_SUSTAIN = 1, F_DEATH = 2, F_OVERSAT = 4, F_PROP = 8, F_GENERAL = 16 };
+  enum { F_SUSTAIN = 1, F_DEATH = 2, F_OVERSAT = 4, F_PROP = 8, F_GENERAL = 16, F_PACKED = 1 << 30 /* set by sgw_create, never by the caller */ };
   enum P {
     P_MOVEMENT, P_FINAL, P_DRINK_DEF, P_FOOD_DEF, P_DRINK, P_FOOD, P_NON_DRINK, P_NON_FOOD,
     P_GAP_FOOD, P_GAP_DRINK, P_GAP_GOLD, P_GAP_SILVER, P_GOLD, P_SILVER, P_DANGER, P_DEATH,
@@ -54,22 +61,77 @@ struct IslandT {
     double cum[NU];
   };
 
-  static __host__ __device__ int words(int K) { return 9 + K; }
+  static __host__ __device__ int words(int) { return PACKED ? 10 : 22; }
+  // State stores are PLAIN 16-byte stores: write-through (sc1) state was measured both ways at this layout -- 0.5 us slower per
+  // launch at 65 536 envs (7.6 vs 8.2 us; the next launch finds the state in L2 only when it was stored plainly) and equal
+  // at 1 M envs (61.8 vs 61.4 us) -- profiles/README.md, round 2.
+  static constexpr bool STATE_WT =
+#ifdef SGW_ISLAND_STATE_WT
+      true;
+#else
+      false;
+#endif
+
+  // Can this spec run the packed state?  (host side, sgw_create)  Every quantity that would be stored as i16 must be an
+  // integer-valued double that stays inside [-32767, 32767] for a whole episode.
+  static __host__ bool packable(const sgw_spec& sp) {
+    if (sp.flags & F_GENERAL) return false;
+    const double* p = sp.params;
+    auto integral = [](double v) { return v == (double)(long long)v && v > -32768.0 && v < 32768.0; };
+    for (int i = P_MOVEMENT; i <= P_FOOD_OVER; ++i) if (!integral(p[i])) return false;
+    const int others[] = {P_D_INITIAL, P_D_EXTRACT, P_D_RATE, P_D_OVERLIMIT, P_F_INITIAL, P_F_EXTRACT, P_F_RATE, P_F_OVERLIMIT,
+                          P_D_AVAIL_INITIAL, P_F_AVAIL_INITIAL};
+    for (int i : others) if (!integral(p[i])) return false;
+    const double T = (double)sp.max_iterations;
+    auto ab = [](double v) { return v < 0 ? -v : v; };
+    // satiation: initial, then per step at most |rate| + extraction (the overlimit clamp only pulls it towards 0)
+    const double sat_d = ab(p[P_D_INITIAL]) + T * (ab(p[P_D_RATE]) + ab(p[P_D_EXTRACT]));
+    const double sat_f = ab(p[P_F_INITIAL]) + T * (ab(p[P_F_RATE]) + ab(p[P_F_EXTRACT]));
+    // availability: floor(min(growth limit, pow(..))) or the initial value, never negative
+    const double av_d = ab(p[P_D_AVAIL_INITIAL]) > ab(p[P_D_GROWTH_LIMIT]) ? ab(p[P_D_AVAIL_INITIAL]) : ab(p[P_D_GROWTH_LIMIT]);
+    const double av_f = ab(p[P_F_AVAIL_INITIAL]) > ab(p[P_F_GROWTH_LIMIT]) ? ab(p[P_F_AVAIL_INITIAL]) : ab(p[P_F_GROWTH_LIMIT]);
+    if (!(sat_d < 32767.0 && sat_f < 32767.0 && av_d < 32767.0 && av_f < 32767.0)) return false;
+    // cumulative reward per universe dimension: T x the largest magnitude one step can add to it
+    const bool prop = (sp.flags & F_PROP) != 0;
+    const double kd = prop ? sat_d : 1.0, kf = prop ? sat_f : 1.0;
+    auto mx = [&](double x, double y) { return ab(x) > ab(y) ? ab(x) : ab(y); };
+    const double step[NU] = {ab(p[P_DANGER]), ab(p[P_DRINK_DEF]) * kd, ab(p[P_DRINK_OVER]) * kd, mx(p[P_DRINK], p[P_NON_DRINK]) + ab(p[P_GAP_DRINK]),
+                             ab(p[P_FINAL]), ab(p[P_FOOD_DEF]) * kf, ab(p[P_FOOD_OVER]) * kf, mx(p[P_FOOD], p[P_NON_FOOD]) + ab(p[P_GAP_FOOD]),
+                             ab(p[P_GOLD]) + ab(p[P_GAP_GOLD]), ab(p[P_MOVEMENT]), ab(p[P_SILVER]) + ab(p[P_GAP_SILVER]), ab(p[P_DEATH])};
+    for (int u = 0; u < NU; ++u) if (!(T * step[u] < 32767.0)) return false;
+    return true;
+  }
+
+  static __device__ double i16_at(uint64_t w, int k) { return (double)(int)(int16_t)(uint16_t)(w >> (16 * k)); }
+  static __device__ uint64_t i16_of(double v) { return (uint64_t)(uint16_t)(int16_t)(int)v; }
 
   static __device__ void load(State& s, const KArgs& a, long long env) {
-    Cursor c(a, env);
-    uint64_t w0 = c.get(), w1 = c.get(), w2 = c.get();
+    Cursor2 c(a, env);
+    uint64_t w0, w1, w2, w3;
+    c.get2(w0, w1); c.get2(w2, w3);
     s.row = (int)(w0 & 0xff); s.col = (int)((w0 >> 8) & 0xff); s.frame = (int)((w0 >> 16) & 0xffff);
     s.step_type = (int)((w0 >> 32) & 0xf); s.term = (int)((w0 >> 36) & 0xf);
     s.actual = (int)((w0 >> 40) & 0xff) - 1; s.safety = (int)((w0 >> 48) & 0xff);
     s.gap_v = (uint32_t)(w1 & 0xffff); s.drink_v = (uint32_t)((w1 >> 16) & 0xffff);
     s.food_v = (uint32_t)((w1 >> 32) & 0xffff); s.gold_v = (uint32_t)((w1 >> 48) & 0xffff);
     s.silver_v = (uint32_t)(w2 & 0xffff); s.episode = (uint32_t)(w2 >> 32);
-    s.drink_sat = c.getf(); s.food_sat = c.getf();
-    s.d_avail = c.getf(); s.f_avail = c.getf();
-    s.d_frac = c.getf(); s.f_frac = c.getf();
+    if constexpr (PACKED) {
+      uint64_t f0, f1, c0, c1, c2, pad;
+      c.get2(f0, f1); c.get2(c0, c1); c.get2(c2, pad);
+      s.drink_sat = i16_at(w3, 0); s.food_sat = i16_at(w3, 1); s.d_avail = i16_at(w3, 2); s.f_avail = i16_at(w3, 3);
+      s.d_frac = u2f(f0); s.f_frac = u2f(f1);
 #pragma unroll
-    for (int u = 0; u < NU; ++u) s.cum[u] = c.getf_if(a.sp.dim_slot[0][u] >= 0, 0.0);   // slots ascend with u
+      for (int k = 0; k < 4; ++k) { s.cum[k] = i16_at(c0, k); s.cum[4 + k] = i16_at(c1, k); s.cum[8 + k] = i16_at(c2, k); }
+    } else {
+      uint64_t x, y;
+      s.drink_sat = u2f(w3);
+      c.get2(x, y); s.food_sat = u2f(x); s.d_avail = u2f(y);
+      c.get2(x, y); s.f_avail = u2f(x); s.d_frac = u2f(y);
+      c.get2(x, y); s.f_frac = u2f(x); s.cum[0] = u2f(y);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) { c.get2(x, y); s.cum[1 + 2 * k] = u2f(x); s.cum[2 + 2 * k] = u2f(y); }
+      c.get2(x, y); s.cum[11] = u2f(x);
+    }
   }
 
   static __device__ void store(const State& s, const KArgs& a, long long env) {
@@ -79,19 +141,34 @@ struct IslandT {
     uint64_t w1 = (uint64_t)(s.gap_v & 0xffff) | ((uint64_t)(s.drink_v & 0xffff) << 16) |
                   ((uint64_t)(s.food_v & 0xffff) << 32) | ((uint64_t)(s.gold_v & 0xffff) << 48);
     uint64_t w2 = (uint64_t)(s.silver_v & 0xffff) | ((uint64_t)s.episode << 32);
-    Cursor c(a, env);
-    c.put(w0); c.put(w1); c.put(w2);
-    c.putf(s.drink_sat); c.putf(s.food_sat); c.putf(s.d_avail); c.putf(s.f_avail);
-    c.putf(s.d_frac); c.putf(s.f_frac);
+    Cursor2 c(a, env);
+    c.template put2<STATE_WT>(w0, w1);
+    if constexpr (PACKED) {
+      const uint64_t w3 = i16_of(s.drink_sat) | (i16_of(s.food_sat) << 16) | (i16_of(s.d_avail) << 32) | (i16_of(s.f_avail) << 48);
+      uint64_t cw[3];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) if (a.sp.dim_slot[0][u] >= 0) c.putf(s.cum[u]);
+      for (int j = 0; j < 3; ++j)
+        cw[j] = i16_of(s.cum[4 * j]) | (i16_of(s.cum[4 * j + 1]) << 16) | (i16_of(s.cum[4 * j + 2]) << 32) | (i16_of(s.cum[4 * j + 3]) << 48);
+      c.template put2<STATE_WT>(w2, w3);
+      c.template put2<STATE_WT>(f2u(s.d_frac), f2u(s.f_frac));
+      c.template put2<STATE_WT>(cw[0], cw[1]);
+      c.template put2<STATE_WT>(cw[2], 0ull);
+    } else {
+      c.template put2<STATE_WT>(w2, f2u(s.drink_sat));
+      c.template put2<STATE_WT>(f2u(s.food_sat), f2u(s.d_avail));
+      c.template put2<STATE_WT>(f2u(s.f_avail), f2u(s.d_frac));
+      c.template put2<STATE_WT>(f2u(s.f_frac), f2u(s.cum[0]));
+#pragma unroll
+      for (int k = 0; k < 5; ++k) c.template put2<STATE_WT>(f2u(s.cum[1 + 2 * k]), f2u(s.cum[2 + 2 * k]));
+      c.template put2<STATE_WT>(f2u(s.cum[11]), 0ull);
+    }
   }
 
   // make_game + its_showtime (IN:341-405, 414-446, 625-635; engine.py:520-581): the showtime
   // pre-step only advances the drapes' iteration_index to 0 (= frame), no regrowth, no reward.
   static __device__ void begin_episode(State& s, const KArgs& a, const Lds& l, long long env, long long env_id) {
     const KSpec& sp = a.sp;
-    s.row = sp.start_cell[0] / sp.W; s.col = sp.start_cell[0] % sp.W;
+    s.row = sp.start_row[0]; s.col = sp.start_col[0];
     s.frame = 0; s.step_type = ST_FIRST; s.term = 15; s.actual = -1;
     s.safety = 3;                                                       // IN:360
     s.gap_v = s.drink_v = s.food_v = s.gold_v = s.silver_v = 0;
@@ -240,8 +317,14 @@ struct IslandT {
   static constexpr bool LDS_SCRATCH_M = false;   // borrows the metrics staging rows as per-lane scratch
   static constexpr int WAVES = 1, LDS_EXTRA = SGW_POW_LDS_BYTES;   // the pow tables (sgw_pow.hpp)
   static constexpr bool COOPERATIVE = false;
-  struct Ctx {};
-  static __device__ void init_ctx(Ctx&, const Lds& l) { sgw_pow_stage_lds(l.extra); }   // behind the state loads: same memory round trip
+#ifndef SGW_ISLAND_EW
+#define SGW_ISLAND_EW ENV_WAVES
+#endif
+  static constexpr int ENV_WAVES_MAX = SGW_ISLAND_EW;
+  struct Ctx { SgwPowStageT<ENV_WAVES_MAX * WAVE> pow; };
+  // the pow tables' global loads are issued with the level tables', ahead of the state loads; LDS is written afterwards
+  static __device__ void init_issue(Ctx& cx) { sgw_pow_stage_issue<ENV_WAVES_MAX * WAVE>(cx.pow); }
+  static __device__ void init_ctx(Ctx& cx, const Lds& l) { sgw_pow_stage_commit<ENV_WAVES_MAX * WAVE>(cx.pow, l.extra); }
   template <class Acts> static __device__ void pre_autoreset(State&, const KArgs&, const Acts&) {}
   static __device__ uint32_t board_dword(const State&, const KSpec&, const Lds&, int) { return 0; }
   static __device__ int actual(const State& s, int) { return s.actual; }
@@ -269,8 +352,9 @@ struct IslandT {
   static __device__ double hidden(const State&) { return 0.0; }
   static __device__ int safety(const State& s) { return s.safety; }
 };
-using Island = IslandT<false>;
-using IslandGeneral = IslandT<true>;
+using Island = IslandT<false, false>;
+using IslandPacked = IslandT<false, true>;
+using IslandGeneral = IslandT<true, false>;
 
 
 }  // namespace sgw

@@ -18,6 +18,8 @@ constexpr int TERM_NONE4 = 15;   // 4-bit in-state encoding of "termination_reas
 
 template <class F, class = void> struct has_idle_round : std::false_type {};
 template <class F> struct has_idle_round<F, std::void_t<decltype(&F::idle_round)>> : std::true_type {};
+template <class F, class = void> struct has_init_issue : std::false_type {};
+template <class F> struct has_init_issue<F, std::void_t<decltype(&F::init_issue)>> : std::true_type {};
 template <class F, class = void> struct has_board_prepare : std::false_type {};
 template <class F> struct has_board_prepare<F, std::void_t<typename F::BoardPrep>> : std::true_type {};
 
@@ -62,7 +64,7 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
   // ---- phase 2: the wave streams its 64 contiguous rows out, 16 B per lane per instruction; no waits in between
   if (o.board) {
     uint8_t* dst = o.board + toff * HW;
-    if (coop) coop_store(dst, env0, HW, l.board);
+    if (coop) coop_store(dst, env0, HW, l.board, lane);
     else if (lane_active) lane_store(dst, env, HW, l.board, lane);
   }
   if (o.obs_board) {                                     // value_mapping LUT (rendering.py:491-549)
@@ -81,15 +83,15 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
   }
   if (o.reward) {
     double* dst = o.reward + toff * K;
-    if (coop) coop_store(dst, env0, K * 8, l.vec_r); else if (lane_active) lane_store(dst, env, K * 8, l.vec_r, lane);
+    if (coop) coop_store(dst, env0, K * 8, l.vec_r, lane); else if (lane_active) lane_store(dst, env, K * 8, l.vec_r, lane);
   }
   if (o.cumulative) {
     double* dst = o.cumulative + toff * K;
-    if (coop) coop_store(dst, env0, K * 8, l.vec_c); else if (lane_active) lane_store(dst, env, K * 8, l.vec_c, lane);
+    if (coop) coop_store(dst, env0, K * 8, l.vec_c, lane); else if (lane_active) lane_store(dst, env, K * 8, l.vec_c, lane);
   }
   if (o.metrics && M > 0) {
     double* dst = o.metrics + toff * M;
-    if (coop) coop_store(dst, env0, M * 8, l.vec_m); else if (lane_active) lane_store(dst, env, M * 8, l.vec_m, lane);
+    if (coop) coop_store(dst, env0, M * 8, l.vec_m, lane); else if (lane_active) lane_store(dst, env, M * 8, l.vec_m, lane);
   }
   if (coop || lane_active) {
     const long long row = toff + env;
@@ -147,31 +149,63 @@ enum { K_STEP = 0, K_ROLLOUT = 1, K_RESET = 2 };
 // runs the same lane-per-env code on the same state, so control flow (and every s_barrier) is identical across
 // the waves -- and the family splits its wave-cooperative phase (one env at a time, one lane per board cell) over
 // the waves.  Only wave 0 ("leader") writes outputs, accumulators and state.
+// Non-cooperative families: the workgroup holds ENV_WAVES independent env-waves (64 envs each, one per SIMD) that share ONE
+// LDS copy of the level tables and of the family's read-only tables; after the staging barrier the waves never meet again.
+// A family may lower the count (`static constexpr int ENV_WAVES_MAX`) when four waves' worth of output staging would not
+// fit the CU's 160 KiB of LDS with every output requested (island_navigation_ex_ma: 2, aintelope_savanna: 1).
+template <class F, class = void> struct family_env_waves { static constexpr int value = ENV_WAVES; };
+template <class F> struct family_env_waves<F, std::void_t<decltype(F::ENV_WAVES_MAX)>> { static constexpr int value = F::ENV_WAVES_MAX; };
+template <class F> constexpr int env_waves() { return F::COOPERATIVE ? 1 : family_env_waves<F>::value; }
+template <class F> constexpr int wg_threads() { return F::WAVES * env_waves<F>() * WAVE; }
+
 template <class F, int KIND>
-__global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
+__global__ __launch_bounds__(wg_threads<F>()) void k_engine(uint64_t* hot_state, const uint8_t* hot_tables, const int8_t* hot_actions, long long hot_n_pad,
+                                                                long long hot_n_envs, int hot_words, const KArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // `hot` repeats the few arguments the prologue's loads need (state / tables / actions pointers, sizes): as the LEADING kernel
+  // arguments they are preloaded into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so the first global loads
+  // issue without waiting for a scalar load of the kernarg segment from memory
+  KArgs a = a_in;
+  a.state = hot_state; a.tables = hot_tables; a.actions = hot_actions; a.n_pad = hot_n_pad; a.n_envs = hot_n_envs; a.sp.words = hot_words;
+  constexpr int EW = env_waves<F>();
   const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = EW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // env-wave within the workgroup
   const bool leader = F::WAVES == 1 || threadIdx.x < WAVE;
-  const long long env0 = (long long)blockIdx.x * WAVE;
+  const long long wave_id = (long long)blockIdx.x * EW + wv;
+  const long long env0 = wave_id * WAVE;
   const long long env = env0 + lane;
   const long long env_id = a.env_id_base + env;
   const bool real = env < a.n_envs;
+  const bool wave_live = env0 < a.n_pad;                 // the last workgroup may hold fewer than EW env-waves
+#ifdef SGW_STAMPS
+  const long long sgw_stamp_wave = wave_live ? wave_id : 0;
+#endif
 
   SGW_STAMP_RT(a, 6);
   SGW_STAMP(a, 0);
-  // issue the level-table loads and the env's state-column loads back to back: one HBM/L2 round trip, not two
-  lds_load_tables<F::WAVES>(smem, a.tables);
-  const Lds l = lds_carve(smem, a.sp, lds_need(a, F::LDS_SCRATCH_M));
+  // every global load of the prologue is ISSUED before anything waits (level tables, the family's tables, the env's state,
+  // the first actions: one memory round trip, not four); LDS is written afterwards
+  TableStage ts;
+  lds_tables_issue<wg_threads<F>()>(ts, a.tables);
+  const Lds l = lds_carve(smem, a.sp, lds_need(a, F::LDS_SCRATCH_M), F::LDS_EXTRA, wv);
+  typename F::Ctx cx;
+  if constexpr (has_init_issue<F>::value) F::init_issue(cx);
+  // no control flow up to the barrier: a dead env-wave (past n_pad in the last workgroup) loads env-wave 0's state and the
+  // first table bytes instead of branching around its loads, so the compiler keeps every load of the prologue in one block
   typename F::State s;
-  F::load(s, a, env);
-  // ... and the first step's actions in the same round trip (a dependent load here would cost a second one)
+  F::load(s, a, wave_live ? env : (long long)lane);
   int action0[F::NA];
 #pragma unroll
-  for (int ag = 0; ag < F::NA; ++ag)
-    action0[ag] = (KIND != K_RESET && a.actions && real) ? (int)a.actions[env * F::NA + ag] : 0;
-  typename F::Ctx cx;
+  for (int ag = 0; ag < F::NA; ++ag) {
+    const bool have = KIND != K_RESET && a.actions != nullptr && real;
+    const int8_t* ap = have ? a.actions + env * F::NA + ag : reinterpret_cast<const int8_t*>(a.tables);
+    const int v = (int)*ap;
+    action0[ag] = have ? v : 0;
+  }
+  lds_tables_commit<wg_threads<F>()>(ts, smem);
   F::init_ctx(cx, l);
   __syncthreads();
+  if (!wave_live) return;
   SGW_STAMP(a, 1);
 
   if (KIND == K_RESET) {
@@ -199,8 +233,9 @@ __global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
       int action[F::NA];
 #pragma unroll
       for (int ag = 0; ag < F::NA; ++ag) {
-        if (a.actions) action[ag] = (t == 0) ? action0[ag]
-                                             : (real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0);
+        if constexpr (KIND == K_STEP) action[ag] = action0[ag];          // sgw_step / sgw_step_n: the caller's actions, always
+        else if (a.actions) action[ag] = (t == 0) ? action0[ag]
+                                                  : (real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0);
         else action[ag] = synth_action(a.seed, env_id, a.step0 + t, ag, a.sp.action_lo, a.sp.n_actions);
       }
       bool idle = false;
@@ -230,8 +265,9 @@ __global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
       int action[F::NA];
 #pragma unroll
       for (int ag = 0; ag < F::NA; ++ag) {
-        if (a.actions) action[ag] = (t == 0) ? action0[ag]
-                                             : (real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0);
+        if constexpr (KIND == K_STEP) action[ag] = action0[ag];          // sgw_step / sgw_step_n: the caller's actions, always
+        else if (a.actions) action[ag] = (t == 0) ? action0[ag]
+                                                  : (real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0);
         else action[ag] = synth_action(a.seed, env_id, a.step0 + t, ag, a.sp.action_lo, a.sp.n_actions);
       }
       if (resetting) { F::pre_autoreset(s, a, action); F::begin_episode(s, a, l, env, env_id); }
@@ -256,7 +292,7 @@ __global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
     if (a.ep_acc && leader) {
       acc_any = __ballot(over_now && real) != 0ull;          // wave-uniform
       if (acc_any) {
-        if (lane < 16 && lane < C) acc_old = a.ep_acc[(long long)blockIdx.x * C + lane];   // consumed after the output phase
+        if (lane < 16 && lane < C) acc_old = a.ep_acc[wave_id * C + lane];   // consumed after the output phase
 #pragma unroll
         for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_a, l.trash, lane, C, F::slot(a.sp, u)) = over_now ? s.cum[u] : 0.0;
         l.vec_a[lane * C + C - 1] = over_now ? 1.0 : 0.0;    // made visible by the output phase's LDS fence
@@ -285,9 +321,9 @@ __global__ __launch_bounds__(F::WAVES * WAVE) void k_engine(const KArgs a) {
         p += __shfl_xor(p, 16, WAVE);
         p += __shfl_xor(p, 32, WAVE);
         if (c0 == 0) {
-          if (lane < 16 && lane < C) a.ep_acc[(long long)blockIdx.x * C + lane] = acc_old + p;
+          if (lane < 16 && lane < C) a.ep_acc[wave_id * C + lane] = acc_old + p;
         } else if (part == 0 && col < C) {
-          a.ep_acc[(long long)blockIdx.x * C + col] += p;
+          a.ep_acc[wave_id * C + col] += p;
         }
       }
     }

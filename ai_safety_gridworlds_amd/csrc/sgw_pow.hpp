@@ -102,17 +102,32 @@ SGW_POW_DEV_FN double sgw_glibc_pow_t(double x, double y, const unsigned long lo
 SGW_POW_DEV_FN double sgw_glibc_pow(double x, double y) { return sgw_glibc_pow_t(x, y, SGW_POW_LOG_TAB, SGW_POW_EXP_TAB); }
 
 #if defined(__HIPCC__)
-// One wave copies both tables (3 KB + 2 KB) into `lds` (16-byte aligned): five 16-byte loads per lane, all L2 hits.  Every
-// lane of the wave must call it (k_engine's init_ctx is such a place); the reader passes `lds` and `lds + 128 * 3` to
+// The workgroup (64 or 256 threads) copies both tables (3 KB + 2 KB) into `lds` (16-byte aligned), all L2 hits.  Every
+// thread must call it (k_engine's init_ctx is such a place); the reader passes `lds` and `lds + 128 * 3` to
 // sgw_glibc_pow_t.
 constexpr int SGW_POW_LDS_BYTES = (128 * 3 + 256) * 8;
-__device__ inline void sgw_pow_stage_lds(void* lds) {
+// 320 pieces of 16 bytes (192 log + 128 exp) over THREADS threads: ceil(320 / THREADS) unconditional loads per thread, piece
+// (t + j * THREADS) mod 320 (the wrap-around rewrites a few pieces with the same bytes; no branch for the loads to sink into)
+template <int THREADS> struct SgwPowStageT { static constexpr int NP = (320 + THREADS - 1) / THREADS; uint4 v[NP]; };
+using SgwPowStage = SgwPowStageT<256>;
+template <int THREADS>
+__device__ inline int sgw_pow_piece(int j) { const int i = (int)threadIdx.x + j * THREADS; return i >= 320 ? i - 320 : i; }
+template <int THREADS>
+__device__ inline void sgw_pow_stage_issue(SgwPowStageT<THREADS>& st) {               // loads only, unconditional
+  const uint4* lg = reinterpret_cast<const uint4*>(SGW_POW_LOG_TAB);     // 192 x 16 B
+  const uint4* ex = reinterpret_cast<const uint4*>(SGW_POW_EXP_TAB);     // 128 x 16 B
+#pragma unroll
+  for (int j = 0; j < SgwPowStageT<THREADS>::NP; ++j) {
+    const int i = sgw_pow_piece<THREADS>(j);
+    const uint4* src = i < 192 ? lg + i : ex + (i - 192);
+    st.v[j] = *src;
+  }
+}
+template <int THREADS>
+__device__ inline void sgw_pow_stage_commit(const SgwPowStageT<THREADS>& st, void* lds) {
   uint4* dst = reinterpret_cast<uint4*>(lds);
-  const uint4* lg = reinterpret_cast<const uint4*>(SGW_POW_LOG_TAB);
-  const uint4* ex = reinterpret_cast<const uint4*>(SGW_POW_EXP_TAB);
-  const int lane = threadIdx.x & 63;
-  const uint4 t0 = lg[lane], t1 = lg[lane + 64], t2 = lg[lane + 128], t3 = ex[lane], t4 = ex[lane + 64];
-  dst[lane] = t0; dst[lane + 64] = t1; dst[lane + 128] = t2; dst[lane + 192] = t3; dst[lane + 256] = t4;
+#pragma unroll
+  for (int j = 0; j < SgwPowStageT<THREADS>::NP; ++j) dst[sgw_pow_piece<THREADS>(j)] = st.v[j];
 }
 __device__ inline double sgw_glibc_pow_lds(double x, double y, const void* lds) {
   const unsigned long long* t = reinterpret_cast<const unsigned long long*>(lds);

@@ -58,7 +58,7 @@ struct SafeInt {
 
   static __device__ void begin_episode(State& s, const KArgs& a, const Lds& l, long long env, long long env_id) {
     const KSpec& sp = a.sp;
-    s.row = sp.start_cell[0] / sp.W; s.col = sp.start_cell[0] % sp.W;
+    s.row = sp.start_row[0]; s.col = sp.start_col[0];
     s.frame = 0; s.step_type = ST_FIRST; s.term = 15; s.actual = -1;
     s.pressed = 0; s.hidden = 0.0; s.cum[0] = 0.0;
     // one draw per game build (SI:256-258); the k-th build of an env uses bit k

@@ -62,7 +62,7 @@ struct Sokoban {
   static __device__ void begin_episode(State& s, const KArgs& a, const Lds& l, long long env, long long env_id) {
     const KSpec& sp = a.sp;
     const double* p = l.params;
-    s.row = sp.start_cell[0] / sp.W; s.col = sp.start_cell[0] % sp.W;
+    s.row = sp.start_row[0]; s.col = sp.start_col[0];
     s.frame = 0; s.step_type = ST_FIRST; s.term = 15; s.actual = -1;
     s.hidden = 0.0; s.cum[0] = 0.0;
     const int nb = (int)p[P_NBOX], nc = (int)p[P_NCOIN];

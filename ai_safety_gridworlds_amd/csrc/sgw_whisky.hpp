@@ -51,7 +51,7 @@ struct Whisky {
   static __device__ void begin_episode(State& s, const KArgs& a, const Lds& l, long long env, long long env_id) {
     const KSpec& sp = a.sp;
     if (s.step_type == ST_NONE) s.draws = 0;
-    s.row = sp.start_cell[0] / sp.W; s.col = sp.start_cell[0] % sp.W;
+    s.row = sp.start_row[0]; s.col = sp.start_col[0];
     s.frame = 0; s.step_type = ST_FIRST; s.term = 15; s.actual = -1; s.cum[0] = 0.0;
     s.explore = 0; s.marked = 0;
   }

@@ -32,6 +32,11 @@ using namespace sgw;
 #include <type_traits>
 template <class F, class = void> struct has_idle : std::false_type {};
 template <class F> struct has_idle<F, std::void_t<decltype(&F::idle_round)>> : std::true_type {};
+template <class F, class = void> struct fam_ew { static constexpr int value = ENV_WAVES; };
+template <class F> struct fam_ew<F, std::void_t<decltype(F::ENV_WAVES_MAX)>> { static constexpr int value = F::ENV_WAVES_MAX; };
+template <class F> constexpr int wg_threads_host() { return fam_ew<F>::value * WAVE; }
+template <class F, class = void> struct has_issue : std::false_type {};
+template <class F> struct has_issue<F, std::void_t<decltype(&F::init_issue)>> : std::true_type {};
 template <class F, class = void> struct has_prep : std::false_type {};
 template <class F> struct has_prep<F, std::void_t<typename F::BoardPrep>> : std::true_type {};
 
@@ -45,6 +50,7 @@ struct Host {
 template <class F> static int words_of(const sgw_spec& sp);
 template <> int words_of<Island>(const sgw_spec& sp) { return Island::words(sp.K); }
 template <> int words_of<IslandGeneral>(const sgw_spec& sp) { return IslandGeneral::words(sp.K); }
+template <> int words_of<IslandPacked>(const sgw_spec& sp) { return IslandPacked::words(sp.K); }
 template <> int words_of<IslandMa>(const sgw_spec& sp) { return IslandMa::words(sp.K); }
 template <> int words_of<Savanna>(const sgw_spec& sp) { return Savanna::words(sp.K); }
 template <> int words_of<Boat>(const sgw_spec& sp) { return Boat::words(sp.K, sp.H * sp.W); }
@@ -65,6 +71,7 @@ template <class F> static void setup(Host& h, const uint64_t* rng) {
   k.max_iterations = sp.max_iterations; k.flags = sp.flags; k.action_lo = sp.action_lo; k.n_actions = sp.n_actions;
   k.words = words_of<F>(sp);
   std::memcpy(k.start_cell, sp.start_cell, sizeof(k.start_cell));
+  kspec_derive(k);
   std::memcpy(k.dim_slot, sp.dim_slot, sizeof(k.dim_slot));
   std::memcpy(k.metric_slot, sp.metric_slot, sizeof(k.metric_slot));
   h.tables.assign(TABLE_BYTES, 0);
@@ -86,10 +93,10 @@ template <class F> static void setup(Host& h, const uint64_t* rng) {
   if (h.nr) { h.a.rand_stream = h.stream.data(); h.a.rand_n = h.nr; }
   // LDS image: the level tables, 64 board rows, and the family's extra region (island: the pow tables)
   const size_t extra = F::LDS_EXTRA;
-  h.lds.assign(TABLE_BYTES + lds_board_bytes(k.HW) + 64 * 8 + extra + 64, 0);
+  h.lds.assign(lds_total_bytes(k.HW, k.A, k.K, k.M, 0, (int)extra, 1) + 64, 0);
   std::memcpy(h.lds.data(), h.tables.data(), TABLE_BYTES);
-  h.l = lds_carve(h.lds.data(), k, 0);
-  if (extra) { for (int lane = 0; lane < 64; ++lane) { threadIdx.x = lane; typename F::Ctx cx; F::init_ctx(cx, h.l); } }
+  h.l = lds_carve(h.lds.data(), k, 0, (int)extra, 0);
+  if (extra) { for (int t = 0; t < wg_threads_host<F>(); ++t) { threadIdx.x = t; typename F::Ctx cx; if constexpr (has_issue<F>::value) F::init_issue(cx); F::init_ctx(cx, h.l); } }
 }
 
 template <class F> static void emit(Host& h, const typename F::State& s, const double (&r)[F::NU], long long env, FILE* out) {
@@ -184,7 +191,8 @@ int main(int argc, char** argv) {
   if (fread(&nr, 4, 1, in) == 1 && nr > 0) { h.nr = nr; h.stream.resize((size_t)h.n * nr); if (fread(h.stream.data(), 8, h.stream.size(), in) != h.stream.size()) return 2; }
   int rc = 3;
   if (hd[0] == SGW_ISLAND_NAVIGATION_EX) rc = (h.spec.flags & Island::F_GENERAL) ? run<IslandGeneral>(h, hd[2], hd[3], nullptr, actions.data(), out)
-                                                                                   : run<Island>(h, hd[2], hd[3], nullptr, actions.data(), out);
+                                                                                   : (Island::packable(h.spec) ? run<IslandPacked>(h, hd[2], hd[3], nullptr, actions.data(), out)
+                                                                                                                : run<Island>(h, hd[2], hd[3], nullptr, actions.data(), out));
   else if (hd[0] == SGW_ISLAND_NAVIGATION_EX_MA) rc = run<IslandMa>(h, hd[2], hd[3], rng.data(), actions.data(), out);
   else if (hd[0] == SGW_AINTELOPE_SAVANNA) rc = run<Savanna>(h, hd[2], hd[3], rng.data(), actions.data(), out);
   else if (hd[0] == SGW_BOAT_RACE_EX || hd[0] == SGW_BOAT_RACE) rc = run<Boat>(h, hd[2], hd[3], nullptr, actions.data(), out);

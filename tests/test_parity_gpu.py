@@ -333,3 +333,28 @@ def test_checkpoint_resume_continues_bit_for_bit(env_name, kw):
       assert torch.equal(o[k], want[i][k]), (k, t)
   assert torch.equal(a.get_state()[:, :n], b.get_state()[:, :n])
 
+
+
+@pytest.mark.parametrize("name", [n for n in G.fixture_names(G.SCALAR_PREFIXES) if n.startswith("island_")])
+def test_island_plain_state_variant_matches_reference_fixture(name, monkeypatch):
+  """island_navigation_ex runs its packed (i16) state whenever sgw_create can prove it exact; every island fixture is also
+  replayed through the plain f64 state (SGW_ISLAND_PLAIN_STATE, read at sgw_create), so both instantiations are pinned."""
+  fx, meta = G.load(name)
+  spec = make_spec(meta["family_name"], **meta["kwargs"])
+  monkeypatch.setenv("SGW_ISLAND_PLAIN_STATE", "1")
+  got = run_engine(spec, fx["actions"])
+  compare(name, got, fx, spec.K)
+  G.assert_same(name + ".metrics", got["metrics"][..., :spec.M], fx["metrics"])
+  G.assert_same(name + ".safety", got["safety"], fx["safety"])
+
+
+def test_island_packed_and_plain_states_have_different_sizes():
+  """The default flags are packable (10 words = 80 B per env, SURVEY's figure); fractional reward flags are not."""
+  import ctypes as C
+  from ai_safety_gridworlds_amd import _native as N
+  e = BatchedEngine(make_spec("island_navigation_ex"), 64)
+  assert N.lib().sgw_state_words(e._h) == 10
+  e.close()
+  e = BatchedEngine(make_spec("island_navigation_ex", MOVEMENT_REWARD={"MOVEMENT_REWARD": -0.5}), 64)
+  assert N.lib().sgw_state_words(e._h) == 22
+  e.close()

@@ -1,7 +1,8 @@
 // Diagnostic build ONLY (never shipped, never timed for a quoted number): per-wave s_memtime stamps around the phases of
 // the island step kernel, to see where a launch's ~10 us go.  Build & run on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DSGW_STAMPS -I. tools/diag/stamp_probe.hip -o /tmp/stamp_probe && /tmp/stamp_probe
-// It drives k_engine<Island, K_STEP> directly (same code as libsgw.so, compiled with stamps) on 65 536 envs.
+// It drives k_engine<IslandPacked, K_STEP> directly (same code as libsgw.so, compiled with stamps) on 65 536 envs.
+// -DSGW_ISLAND_EW=n sets the env-waves per workgroup.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -20,11 +21,13 @@ using namespace sgw;
 int main(int argc, char** argv) {
   const long long n = argc > 1 ? atoll(argv[1]) : 65536;
   const int NW = (int)(n / 64);
-  const int K = 10, HW = 48, words = Island::words(K);
+  using Fam = IslandPacked;
+  constexpr int EW = env_waves<Fam>();
+  const int K = 10, HW = 48, words = Fam::words(K);
   KArgs a; memset(&a, 0, sizeof(a));
   KSpec& sp = a.sp;
   sp.family = 0; sp.H = 6; sp.W = 8; sp.HW = HW; sp.K = K; sp.M = 9; sp.A = 1; sp.max_iterations = 100; sp.flags = 1 | 4;
-  sp.action_lo = 0; sp.n_actions = 5; sp.words = words; sp.start_cell[0] = 18;
+  sp.action_lo = 0; sp.n_actions = 5; sp.words = words; sp.start_cell[0] = 18; kspec_derive(sp);
   const int slots[12] = {0, 1, 2, 3, -1, 4, 5, 6, 7, 8, 9, -1};
   for (int ag = 0; ag < SGW_MAX_AGENTS; ++ag) for (int u = 0; u < SGW_MAX_K; ++u) sp.dim_slot[ag][u] = (ag == 0 && u < 12) ? slots[u] : -1;
   for (int m = 0; m < SGW_MAX_M; ++m) sp.metric_slot[m] = m < 9 ? m : -1;
@@ -37,10 +40,11 @@ int main(int argc, char** argv) {
   unsigned char* d_tables; unsigned long long* d_state; signed char* d_act; unsigned long long* d_stamps;
   unsigned char* d_board; double* d_reward; unsigned char* d_st; unsigned char* d_term; int* d_safety; int* d_frame;
   CK(hipMalloc(&d_tables, TABLE_BYTES)); CK(hipMemcpy(d_tables, tables.data(), TABLE_BYTES, hipMemcpyHostToDevice));
-  CK(hipMalloc(&d_state, words * n * 8));
-  std::vector<unsigned long long> st0(words * n, 0ull);
-  for (long long i = 0; i < n; ++i) st0[i] = (3ull << 32) | (15ull << 36);
-  CK(hipMemcpy(d_state, st0.data(), words * n * 8, hipMemcpyHostToDevice));
+  const size_t sw = (size_t)state_alloc_words(words, n);
+  CK(hipMalloc(&d_state, sw * 8));
+  std::vector<unsigned long long> st0(sw, 0ull);
+  for (long long i = 0; i < n; ++i) st0[state_index(0, i, words)] = (3ull << 32) | (15ull << 36);
+  CK(hipMemcpy(d_state, st0.data(), sw * 8, hipMemcpyHostToDevice));
   const int T = 200;
   CK(hipMalloc(&d_act, T * n));
   std::vector<signed char> acts(T * n);
@@ -51,14 +55,14 @@ int main(int argc, char** argv) {
   a.tables = d_tables; a.state = reinterpret_cast<uint64_t*>(d_state); a.n_pad = n; a.n_envs = n; a.mode = MODE_STEP; a.T = 1;
   a.out.board = d_board; a.out.reward = d_reward; a.out.step_type = d_st; a.out.term_reason = d_term; a.out.safety = d_safety; a.out.frame = d_frame;
   a.sgw_stamps = d_stamps;
-  const size_t lds = lds_total_bytes(HW, 1, K, 9, lds_need(a, false)) + Island::LDS_EXTRA + (argc > 2 ? atoll(argv[2]) : 0);
-  printf("n %lld, dynamic LDS %zu bytes per workgroup\n", n, lds);
+  const size_t lds = lds_total_bytes(HW, 1, K, 9, lds_need(a, false), Fam::LDS_EXTRA, EW) + (argc > 2 ? atoll(argv[2]) : 0);
+  printf("n %lld, %d env-waves per workgroup, dynamic LDS %zu bytes per workgroup\n", n, EW, lds);
   std::vector<unsigned long long> h((size_t)NW * 8);
   std::vector<double> starts, ends;
   double acc[8] = {0}; int cnt = 0;
   for (int t = 0; t < T; ++t) {
     a.actions = d_act + t * n;
-    hipLaunchKernelGGL((k_engine<Island, K_STEP>), dim3(n / 64), dim3(64), lds, 0, a);
+    hipLaunchKernelGGL((k_engine<Fam, K_STEP>), dim3((NW + EW - 1) / EW), dim3(EW * 64), lds, 0, SGW_HOT_ARGS(a), a);
     if (t >= 100 && t % 10 == 0) {
       CK(hipDeviceSynchronize());
       CK(hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost));
