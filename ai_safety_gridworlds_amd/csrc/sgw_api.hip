@@ -312,28 +312,28 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
   const long long n_waves = e->n_pad / WAVE;
   const int kind = a.mode == MODE_RESET ? K_RESET : ((a.T == 1 && a.actions) ? K_STEP : K_ROLLOUT);   // K_STEP reads the caller's actions only
   size_t lds_bytes = 0;
+#define SGW_LAUNCH_KIND(F, KIND)                                                                       \
+  do {                                                                                                 \
+    constexpr int EW = env_waves<F, KIND>(), NB = lds_buffers<F, KIND>();                                    \
+    const int need = lds_need(a, F::LDS_SCRATCH_M), pa = F::PER_AGENT ? F::NA : 1;                     \
+    a.lp = lds_plan(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need); a.need = need;                                        \
+    lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, F::LDS_EXTRA, EW, NB);      \
+    const dim3 grid((unsigned)((n_waves + EW - 1) / EW));                                              \
+    const dim3 block(wg_threads<F, KIND>());                                                           \
+    /* the bytes requested == the bytes the plan hands out (checked on every launch) */                \
+    if ((size_t)TABLE_BYTES + F::LDS_EXTRA + (size_t)EW * NB * a.lp.wave_bytes != lds_bytes || (F::LDS_EXTRA & 15) != 0 || \
+        (a.lp.wave_bytes & 15) != 0 || (a.lp.st & 15) != 0)                                            \
+      return fail(SGW_ERR_ARG, "launch: LDS footprint mismatch between the launcher and the kernel's plan"); \
+    if (lds_bytes > 160 * 1024) return fail(SGW_ERR_UNSUPPORTED, "launch: the requested outputs need more than 160 KiB of LDS per workgroup"); \
+    if (lds_bytes > 65536)   /* above the default dynamic-LDS cap */                                   \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+    hipLaunchKernelGGL((k_engine<F, KIND>), grid, block, lds_bytes, st, SGW_HOT_ARGS(a), a);         \
+  } while (0)
 #define SGW_LAUNCH(F)                                                                                  \
   do {                                                                                                 \
-    constexpr int EW = env_waves<F>();                                                                 \
-    const int need = lds_need(a, F::LDS_SCRATCH_M);                                                    \
-    lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, need, F::LDS_EXTRA, EW);              \
-    const dim3 grid((unsigned)((n_waves + EW - 1) / EW));                                              \
-    const dim3 block(wg_threads<F>());                                                                 \
-    {  /* the bytes requested == the bytes the kernel carves (same arithmetic, checked on every launch) */ \
-      uint8_t* const base0 = reinterpret_cast<uint8_t*>((uintptr_t)65536);                             \
-      const Lds lc = lds_carve(base0, a.sp, need, F::LDS_EXTRA, EW - 1);                               \
-      const size_t end = (size_t)(reinterpret_cast<uint8_t*>(lc.trash + 64) - base0);                  \
-      if (end != lds_bytes || ((lc.extra - base0) & 15) != 0 || ((reinterpret_cast<uint8_t*>(lc.board) - base0) & 15) != 0) \
-        return fail(SGW_ERR_ARG, "launch: LDS footprint mismatch between the launcher and the kernel's carve"); \
-    }                                                                                                  \
-    if (lds_bytes > 65536) {   /* above the default dynamic-LDS cap */                                 \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, K_STEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, K_ROLLOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, K_RESET>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-    }                                                                                                  \
-    if (kind == K_STEP) hipLaunchKernelGGL((k_engine<F, K_STEP>), grid, block, lds_bytes, st, SGW_HOT_ARGS(a), a);   \
-    else if (kind == K_ROLLOUT) hipLaunchKernelGGL((k_engine<F, K_ROLLOUT>), grid, block, lds_bytes, st, SGW_HOT_ARGS(a), a); \
-    else hipLaunchKernelGGL((k_engine<F, K_RESET>), grid, block, lds_bytes, st, SGW_HOT_ARGS(a), a);                 \
+    if (kind == K_STEP) SGW_LAUNCH_KIND(F, K_STEP);                                                    \
+    else if (kind == K_ROLLOUT) SGW_LAUNCH_KIND(F, K_ROLLOUT);                                         \
+    else SGW_LAUNCH_KIND(F, K_RESET);                                                                  \
   } while (0)
   switch (e->spec.family) {
     case SGW_ISLAND_NAVIGATION_EX:
@@ -357,6 +357,7 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
     default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
   }
 #undef SGW_LAUNCH
+#undef SGW_LAUNCH_KIND
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }

@@ -28,8 +28,14 @@ struct KSpec {
   int8_t metric_slot[SGW_MAX_M];
 };
 
+// byte offsets of one env-wave staging buffer's regions, computed ONCE per launch on the host (lds_plan) and read from the
+// kernarg segment where needed: deriving them on the device cost a ~30-instruction scalar chain per region with spilled terms
+struct LdsPlan { int wave_bytes, vec_r, vec_c, vec_m, vec_a, trash, flag, st, tr, act, pos, flg, disc, hid, saf, frm; };
+
 struct KArgs {
   KSpec sp;
+  LdsPlan lp;
+  int need;                  // LN_* bits of the requested outputs (host-computed: one scalar instead of 14 pointer tests)
   const uint8_t* tables;     // device copy: static_board | art | aux (3 x SGW_MAX_CELLS) | value_map f32[128] | params f64[48]
   uint64_t* state;           // [words][n_pad]
   long long n_pad, n_envs, env_id_base;
@@ -56,6 +62,7 @@ struct KArgs {
 
 // leading scalar kernel arguments of k_engine (preloaded into SGPRs at wave launch): what the prologue's loads need
 #define SGW_HOT_ARGS(a) (a).state, (a).tables, (a).actions, (a).n_pad, (a).n_envs, (a).sp.words
+#define SGW_KARGS_OFFSET 48      // byte offset of the KArgs block in k_engine's kernarg segment: 5 x 8 + 4 (+4 padding)
 
 // In-kernel phase stamps: compiled in ONLY by the diagnostic probe (-DSGW_STAMPS); libsgw.so carries none.
 #ifdef SGW_STAMPS
@@ -88,7 +95,11 @@ enum { MODE_STEP = 0, MODE_RESET = 1 };
 enum { ST_FIRST = 0, ST_MID = 1, ST_LAST = 2, ST_NONE = 3 };   // ST_NONE: never reset yet
 
 // ---- LDS layout (dynamic shared memory, carved by the host with the same arithmetic) --------
-//   [ level tables 2 KiB | family-private F::LDS_EXTRA (shared by the workgroup) | env-wave 0 staging | env-wave 1 staging | ... ]
+//   [ level tables 2 KiB | family-private F::LDS_EXTRA (shared by the workgroup) | env-wave 0: buffers | env-wave 1: buffers | ... ]
+// An env-wave has one staging buffer (two in the pipelined fused rollout, see k_engine).  EVERY requested output of a step is
+// staged in the buffer in exactly the byte order global memory wants for the wave's 64 envs, so that the drain is a plain
+// 16-byte-per-lane copy of contiguous bytes -- boards, reward vectors and the one- and four-byte per-env outputs alike
+// (a 1-byte-per-lane global store costs ~12x, a 4-byte one ~6x the time per byte of a 16-byte one).
 struct Lds {
   uint8_t* static_board;   // [SGW_MAX_CELLS]
   uint8_t* art;            // [SGW_MAX_CELLS]
@@ -100,18 +111,26 @@ struct Lds {
   double* vec_r;           // 64*A*K doubles: reward rows
   double* vec_c;           // 64*A*K doubles: cumulative rows
   double* vec_m;           // 64*M doubles: metrics rows
+  uint8_t *st, *tr, *pos, *flg;      // step_type [64][A], term_reason [64][PA], agent_pos [64][A][2], agent_flags [64][A]
+  int8_t* act;                       // actual_action [64][A]
+  double *disc, *hid;                // discount [64], hidden [64]
+  int32_t *saf, *frm;                // safety [64][PA], frame [64]
   double* vec_a;           // 64*(A*K+1) doubles: finished-episode returns staged for the per-wave sum
+  uint32_t* flag;          // [4] per-step words handed from the computing wave to the draining wave (pipelined rollout)
   double* trash;           // 64 doubles: where writes of not-enabled reward dimensions / absent metrics land (branch-free)
 };
 
 __host__ __device__ inline size_t lds_board_bytes(int HW) { return ((size_t)64 * HW + 15) / 16 * 16 + 16; }
-// Staging regions are carved only for the outputs a launch asked for (host and device evaluate the same
-// arithmetic on the same KArgs): the LDS footprint of a wave decides how many waves a CU keeps resident when a launch
-// has more than one wave per SIMD.
-enum { LN_REWARD = 1, LN_CUMULATIVE = 2, LN_METRICS = 4, LN_RETURNS = 8 };
+// Regions are carved only for the outputs a launch asked for (host and device evaluate the same arithmetic on the same
+// KArgs): the LDS footprint of a wave decides how many waves a CU keeps resident when a launch has more than one per SIMD.
+enum { LN_REWARD = 1, LN_CUMULATIVE = 2, LN_METRICS = 4, LN_RETURNS = 8, LN_ST = 16, LN_TR = 32, LN_ACT = 64, LN_POS = 128,
+       LN_FLG = 256, LN_DISC = 512, LN_HID = 1024, LN_SAF = 2048, LN_FRM = 4096, LN_BOARD = 8192, LN_OBS = 16384 };
 __host__ __device__ inline int lds_need(const KArgs& a, bool family_scratch_m) {
-  return (a.out.reward ? LN_REWARD : 0) | (a.out.cumulative ? LN_CUMULATIVE : 0) |
-         ((a.out.metrics || family_scratch_m) ? LN_METRICS : 0) | (a.ep_acc ? LN_RETURNS : 0);
+  const sgw_out& o = a.out;
+  return (o.reward ? LN_REWARD : 0) | (o.cumulative ? LN_CUMULATIVE : 0) | ((o.metrics || family_scratch_m) ? LN_METRICS : 0) |
+         (a.ep_acc ? LN_RETURNS : 0) | (o.step_type ? LN_ST : 0) | (o.term_reason ? LN_TR : 0) | (o.actual_action ? LN_ACT : 0) |
+         (o.agent_pos ? LN_POS : 0) | (o.agent_flags ? LN_FLG : 0) | (o.discount ? LN_DISC : 0) | (o.hidden ? LN_HID : 0) |
+         (o.safety ? LN_SAF : 0) | (o.frame ? LN_FRM : 0) | (o.board ? LN_BOARD : 0) | (o.obs_board ? LN_OBS : 0);
 }
 __host__ __device__ inline size_t lds_rows(int A, int K, int M, int need, int which) {
   const int ak = A * K > 0 ? A * K : 1;
@@ -122,17 +141,56 @@ __host__ __device__ inline size_t lds_rows(int A, int K, int M, int need, int wh
     default: return (need & LN_RETURNS) ? A * K + 1 : 0;
   }
 }
-// one env-wave's staging bytes
-__host__ __device__ inline size_t lds_wave_bytes(int HW, int A, int K, int M, int need) {
+// bytes of the per-env scalar outputs of one wave: `pa` = 1, or A for the families whose term_reason / safety are per agent
+__host__ __device__ inline size_t lds_small_bytes(int A, int pa, int need, int which) {
+  auto r16 = [](size_t b) { return (b + 15) / 16 * 16; };
+  switch (which) {
+    case LN_ST: return (need & LN_ST) ? r16((size_t)64 * A) : 0;
+    case LN_TR: return (need & LN_TR) ? r16((size_t)64 * pa) : 0;
+    case LN_ACT: return (need & LN_ACT) ? r16((size_t)64 * A) : 0;
+    case LN_POS: return (need & LN_POS) ? r16((size_t)128 * A) : 0;
+    case LN_FLG: return (need & LN_FLG) ? r16((size_t)64 * A) : 0;
+    case LN_DISC: return (need & LN_DISC) ? 512 : 0;
+    case LN_HID: return (need & LN_HID) ? 512 : 0;
+    case LN_SAF: return (need & LN_SAF) ? (size_t)256 * pa : 0;
+    default: return (need & LN_FRM) ? 256 : 0;
+  }
+}
+// one staging buffer of one env-wave
+__host__ __device__ inline size_t lds_wave_bytes(int HW, int A, int K, int M, int pa, int need) {
   const size_t rows = lds_rows(A, K, M, need, LN_REWARD) + lds_rows(A, K, M, need, LN_CUMULATIVE) +
                       lds_rows(A, K, M, need, LN_METRICS) + lds_rows(A, K, M, need, LN_RETURNS) + 1;   // + trash
-  return lds_board_bytes(HW) + rows * 64 * 8;
+  size_t small = 16;                                                                                    // flag words
+  for (int w = LN_ST; w <= LN_FRM; w <<= 1) small += lds_small_bytes(A, pa, need, w);
+  return lds_board_bytes(HW) + rows * 64 * 8 + small;
 }
-__host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M, int need, int extra, int env_waves) {
-  return TABLE_BYTES + (size_t)extra + (size_t)env_waves * lds_wave_bytes(HW, A, K, M, need);
+__host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M, int pa, int need, int extra, int env_waves, int buffers) {
+  return TABLE_BYTES + (size_t)extra + (size_t)env_waves * buffers * lds_wave_bytes(HW, A, K, M, pa, need);
 }
 
-__host__ __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp, int need, int extra, int wave) {
+__host__ __device__ inline LdsPlan lds_plan(int HW, int A, int K, int M, int pa, int need) {
+  LdsPlan p;
+  int o = (int)lds_board_bytes(HW);
+  p.vec_r = o; o += 512 * (int)lds_rows(A, K, M, need, LN_REWARD);
+  p.vec_c = o; o += 512 * (int)lds_rows(A, K, M, need, LN_CUMULATIVE);
+  p.vec_m = o; o += 512 * (int)lds_rows(A, K, M, need, LN_METRICS);
+  p.vec_a = o; o += 512 * (int)lds_rows(A, K, M, need, LN_RETURNS);
+  p.trash = o; o += 512;
+  p.flag = o; o += 16;
+  p.st = o; o += (int)lds_small_bytes(A, pa, need, LN_ST);
+  p.tr = o; o += (int)lds_small_bytes(A, pa, need, LN_TR);
+  p.act = o; o += (int)lds_small_bytes(A, pa, need, LN_ACT);
+  p.pos = o; o += (int)lds_small_bytes(A, pa, need, LN_POS);
+  p.flg = o; o += (int)lds_small_bytes(A, pa, need, LN_FLG);
+  p.disc = o; o += (int)lds_small_bytes(A, pa, need, LN_DISC);
+  p.hid = o; o += (int)lds_small_bytes(A, pa, need, LN_HID);
+  p.saf = o; o += (int)lds_small_bytes(A, pa, need, LN_SAF);
+  p.frm = o; o += (int)lds_small_bytes(A, pa, need, LN_FRM);
+  p.wave_bytes = o;
+  return p;
+}
+
+__host__ __device__ inline Lds lds_carve(uint8_t* smem, const LdsPlan& p, int extra, int slot) {   // slot = wave * buffers + buffer
   Lds l;
   l.static_board = smem;
   l.art = smem + SGW_MAX_CELLS;
@@ -140,13 +198,17 @@ __host__ __device__ inline Lds lds_carve(uint8_t* smem, const KSpec& sp, int nee
   l.value_map = reinterpret_cast<float*>(smem + 3 * SGW_MAX_CELLS);
   l.params = reinterpret_cast<const double*>(smem + 3 * SGW_MAX_CELLS + 512);
   l.extra = smem + TABLE_BYTES;
-  uint8_t* w = smem + TABLE_BYTES + extra + (size_t)wave * lds_wave_bytes(sp.HW, sp.A, sp.K, sp.M, need);
+  uint8_t* w = smem + TABLE_BYTES + extra + slot * p.wave_bytes;
   l.board = reinterpret_cast<uint32_t*>(w);
-  l.vec_r = reinterpret_cast<double*>(w + lds_board_bytes(sp.HW));
-  l.vec_c = l.vec_r + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_REWARD);
-  l.vec_m = l.vec_c + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_CUMULATIVE);
-  l.vec_a = l.vec_m + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_METRICS);
-  l.trash = l.vec_a + 64 * lds_rows(sp.A, sp.K, sp.M, need, LN_RETURNS);
+  l.vec_r = reinterpret_cast<double*>(w + p.vec_r);
+  l.vec_c = reinterpret_cast<double*>(w + p.vec_c);
+  l.vec_m = reinterpret_cast<double*>(w + p.vec_m);
+  l.vec_a = reinterpret_cast<double*>(w + p.vec_a);
+  l.trash = reinterpret_cast<double*>(w + p.trash);
+  l.flag = reinterpret_cast<uint32_t*>(w + p.flag);
+  l.st = w + p.st; l.tr = w + p.tr; l.act = reinterpret_cast<int8_t*>(w + p.act); l.pos = w + p.pos; l.flg = w + p.flg;
+  l.disc = reinterpret_cast<double*>(w + p.disc); l.hid = reinterpret_cast<double*>(w + p.hid);
+  l.saf = reinterpret_cast<int32_t*>(w + p.saf); l.frm = reinterpret_cast<int32_t*>(w + p.frm);
   return l;
 }
 
@@ -309,6 +371,13 @@ struct Cursor2 {
     p += 64;
   }
 };
+// value select by bit masks: `i == 0 ? a : (i == 1 ? b : c)` written with ?: over struct fields is turned by the compiler
+// into ONE load through a select of ADDRESSES, which pins the whole State struct in scratch memory
+__device__ inline double sel3_f64(int i, double a, double b, double c) {
+  const uint64_t ma = 0ull - (uint64_t)(i == 0), mb = 0ull - (uint64_t)(i == 1), mc = ~(ma | mb);
+  return __longlong_as_double((long long)(((uint64_t)__double_as_longlong(a) & ma) | ((uint64_t)__double_as_longlong(b) & mb) |
+                                          ((uint64_t)__double_as_longlong(c) & mc)));
+}
 __device__ inline double u2f(uint64_t v) { return __longlong_as_double((long long)v); }
 __device__ inline uint64_t f2u(double v) { return (uint64_t)__double_as_longlong(v); }
 
@@ -319,6 +388,11 @@ __device__ inline void coop_store(void* dst, long long env0, int row_bytes, cons
   uint4* g = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(dst) + env0 * row_bytes);
   const uint4* s = reinterpret_cast<const uint4*>(lds_src);
   const int nchunk = 4 * row_bytes;               // 64 * row_bytes / 16
+  if (row_bytes <= 16) {                          // the per-env scalars (1-16 bytes per env): at most one chunk per lane
+    const uint4 v = s[lane < nchunk ? lane : 0];
+    if (lane < nchunk) store16_wt(g + lane, v);
+    return;
+  }
   // batches of 4 chunks per lane: the 4 LDS reads are unconditional (index clamped) so they issue back to back;
   // only the stores are guarded
   for (int base = lane; base < nchunk; base += 4 * WAVE) {

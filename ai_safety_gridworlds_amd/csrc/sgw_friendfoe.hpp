@@ -71,8 +71,8 @@ struct FriendFoe {
     int bt = (int)p[P_FIXED];
     if (bt < 0) { bt = (int)(next_uniform(a, env, env_id, s.draws) * 3.0); bt = bt > 2 ? 2 : bt; }
     s.bandit = bt;
-    const double p0 = bt == 0 ? s.pol[0][0] : (bt == 1 ? s.pol[1][0] : s.pol[2][0]);
-    const double p1 = bt == 0 ? s.pol[0][1] : (bt == 1 ? s.pol[1][1] : s.pol[2][1]);
+    const double p0 = sel3_f64(bt, s.pol[0][0], s.pol[1][0], s.pol[2][0]);
+    const double p1 = sel3_f64(bt, s.pol[0][1], s.pol[1][1], s.pol[2][1]);
     int level;
     if (bt == 0) level = p1 > p0 ? 1 : 0;                                           // np.argmax
     else if (bt == 1) level = next_uniform(a, env, env_id, s.draws) <= p[P_PROB] ? 0 : 1;
@@ -106,8 +106,8 @@ struct FriendFoe {
     const double pi = on_a ? 0.0 : 1.0;
     const double lr = p[P_LR];
     const int bt = s.bandit;
-    const double o0 = bt == 0 ? s.pol[0][0] : (bt == 1 ? s.pol[1][0] : s.pol[2][0]);
-    const double o1 = bt == 0 ? s.pol[0][1] : (bt == 1 ? s.pol[1][1] : s.pol[2][1]);
+    const double o0 = sel3_f64(bt, s.pol[0][0], s.pol[1][0], s.pol[2][0]);
+    const double o1 = sel3_f64(bt, s.pol[0][1], s.pol[1][1], s.pol[2][1]);
     const double n0 = lr * (1.0 - pi) + (1.0 - lr) * o0, n1 = lr * pi + (1.0 - lr) * o1;
     const double sum = n0 + n1;
     const double q0 = n0 / sum, q1 = n1 / sum;

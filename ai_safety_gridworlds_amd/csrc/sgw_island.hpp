@@ -262,7 +262,8 @@ struct IslandT {
     // (a.ftable: 15 x 12 values, then 15 key-presence masks), events in the order the reference adds them, each dimension
     // summed in that order (mo_reward.__add__ / __mul__ work per dimension; absent keys are skipped, not added as 0).
     if constexpr (GENERAL) {
-      const double* V = a.ftable;
+      // the table sits in LDS (init_args): read through the scalar path its 195 doubles would occupy 390 SGPRs
+      const double* V = reinterpret_cast<const double*>(l.extra + SGW_POW_LDS_BYTES);
       const bool fire[15] = {act && action != 0, dies, on_u, d_has, act && !on_d, f_has, act && !on_f, on_g, on_s, on_gap,
                              d_def, d_over, f_def, f_over, on_w};
       const double scale[15] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -s.drink_sat, s.drink_sat, -s.food_sat, s.food_sat, 1};
@@ -270,6 +271,8 @@ struct IslandT {
       for (int u = 0; u < NU; ++u) r[u] = 0.0;
 #pragma unroll
       for (int ev = 0; ev < 15; ++ev) {
+        // one event's 12 values at a time: left alone the scheduler hoists all 180 LDS reads (360 VGPRs) to the top
+        __builtin_amdgcn_sched_barrier(0);
         const unsigned mask = (unsigned)V[180 + ev];
         const bool scaled = prop && ev >= 10 && ev <= 13;
 #pragma unroll
@@ -315,16 +318,24 @@ struct IslandT {
   static constexpr bool PER_AGENT = false;
   static __device__ int slot(const KSpec& sp, int u) { return sp.dim_slot[0][u]; }
   static constexpr bool LDS_SCRATCH_M = false;   // borrows the metrics staging rows as per-lane scratch
-  static constexpr int WAVES = 1, LDS_EXTRA = SGW_POW_LDS_BYTES;   // the pow tables (sgw_pow.hpp)
+  static constexpr int FTABLE_N = 15 * 12 + 15;
+  static constexpr int WAVES = 1, LDS_EXTRA = SGW_POW_LDS_BYTES + (GENERAL ? (FTABLE_N * 8 + 15) / 16 * 16 : 0);   // the pow tables (sgw_pow.hpp) [+ the per-event reward vectors]
   static constexpr bool COOPERATIVE = false;
 #ifndef SGW_ISLAND_EW
 #define SGW_ISLAND_EW ENV_WAVES
 #endif
-  static constexpr int ENV_WAVES_MAX = SGW_ISLAND_EW;
+  // (the per-event-vector variant needs > 256 registers in the fused rollout: two env-waves keep its paired workgroup at 4 wavefronts)
+  static constexpr int ENV_WAVES_MAX = GENERAL ? 2 : SGW_ISLAND_EW;
   struct Ctx { SgwPowStageT<ENV_WAVES_MAX * WAVE> pow; };
   // the pow tables' global loads are issued with the level tables', ahead of the state loads; LDS is written afterwards
   static __device__ void init_issue(Ctx& cx) { sgw_pow_stage_issue<ENV_WAVES_MAX * WAVE>(cx.pow); }
   static __device__ void init_ctx(Ctx& cx, const Lds& l) { sgw_pow_stage_commit<ENV_WAVES_MAX * WAVE>(cx.pow, l.extra); }
+  static __device__ void init_args(Ctx&, const Lds& l, const KArgs& a) {      // before k_engine's staging barrier
+    if constexpr (GENERAL) {
+      double* dst = reinterpret_cast<double*>(l.extra + SGW_POW_LDS_BYTES);
+      for (int i = threadIdx.x; i < FTABLE_N; i += ENV_WAVES_MAX * WAVE) dst[i] = a.ftable[i];
+    }
+  }
   template <class Acts> static __device__ void pre_autoreset(State&, const KArgs&, const Acts&) {}
   static __device__ uint32_t board_dword(const State&, const KSpec&, const Lds&, int) { return 0; }
   static __device__ int actual(const State& s, int) { return s.actual; }

@@ -20,22 +20,28 @@ template <class F, class = void> struct has_idle_round : std::false_type {};
 template <class F> struct has_idle_round<F, std::void_t<decltype(&F::idle_round)>> : std::true_type {};
 template <class F, class = void> struct has_init_issue : std::false_type {};
 template <class F> struct has_init_issue<F, std::void_t<decltype(&F::init_issue)>> : std::true_type {};
+// fused rollout: the COMPUTING wave re-reads the kernel arguments every step (see the loop) unless the family opts out
+// (`ROLLOUT_KEEPS_ARGS`: measured faster and inside the register budget)
+template <class F, class = void> struct rollout_rereads : std::true_type {};
+template <class F> struct rollout_rereads<F, std::void_t<decltype(F::ROLLOUT_KEEPS_ARGS)>> : std::integral_constant<bool, !F::ROLLOUT_KEEPS_ARGS> {};
+template <class F, class = void> struct has_init_args : std::false_type {};
+template <class F> struct has_init_args<F, std::void_t<decltype(&F::init_args)>> : std::true_type {};
 template <class F, class = void> struct has_board_prepare : std::false_type {};
 template <class F> struct has_board_prepare<F, std::void_t<typename F::BoardPrep>> : std::true_type {};
 
-template <class F>
-__device__ inline void emit(const typename F::State& s, const double (&r)[F::NU], double discount,
-                            const KArgs& a, const Lds& l, long long env0, int lane, long long toff,
-                            bool coop, bool lane_active) {
+// ---- a step's outputs: stage (the computing wave, from registers into its LDS buffer) and drain (LDS -> global) ----------
+template <class F> constexpr int per_agent_cols(const KSpec& sp) { return F::PER_AGENT ? sp.A : 1; }
+
+// Every requested output of one step is written into the wave's staging buffer in the byte order of the env-major global
+// arrays (the wave's 64 rows are contiguous there).  `finished` / `real`: the returns staging of the accumulators.
+template <class F, bool SMALL = true>
+__device__ inline void emit_stage(const typename F::State& s, const double (&r)[F::NU], double discount, const KArgs& a,
+                                  const Lds& l, int lane) {
   const sgw_out& o = a.out;
   const KSpec& sp = a.sp;
+  const int nd = a.need;
   const int HW = sp.HW, K = sp.A * sp.K, M = sp.M;   // reward rows hold all agents' vectors: [A][K]
-  const long long env = env0 + lane;
-  const bool want_board = o.board || o.obs_board;
-
-  // ---- phase 1: every lane writes its rows into the (disjoint) LDS staging regions
-  lds_wave_sync();                                        // previous step's cooperative reads are done (program order)
-  if (want_board) {
+  if (nd & (LN_BOARD | LN_OBS)) {
     if constexpr (has_board_prepare<F>::value) {        // per-step precomputation shared by every dword of the row
       const auto bp = F::board_prepare(s, sp);
       lds_write_board_row_fn(l.board, HW, lane, [&](int i) { return F::board_dword(bp, s, sp, i); });
@@ -47,27 +53,80 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
       lds_write_board_row<F::NSPRITE>(l.board, HW, lane, base, cells, chars);
     }
   }
-  if (o.reward) {
+  if (nd & LN_REWARD) {
 #pragma unroll
     for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_r, l.trash, lane, K, F::slot(sp, u)) = r[u];
   }
-  if (o.cumulative) {
+  if (nd & LN_CUMULATIVE) {
 #pragma unroll
     for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_c, l.trash, lane, K, F::slot(sp, u)) = s.cum[u];
   }
-  if (o.metrics && M > 0) {
+  if ((nd & LN_METRICS) && o.metrics && M > 0) {
 #pragma unroll
     for (int id = 0; id < F::NMETRIC; ++id) *stage_cell(l.vec_m, l.trash, lane, M, sp.metric_slot[id]) = F::metric(s, id);
   }
-  lds_wave_sync();
-
-  // ---- phase 2: the wave streams its 64 contiguous rows out, 16 B per lane per instruction; no waits in between
-  if (o.board) {
-    uint8_t* dst = o.board + toff * HW;
-    if (coop) coop_store(dst, env0, HW, l.board, lane);
-    else if (lane_active) lane_store(dst, env, HW, l.board, lane);
+  if constexpr (SMALL) {
+  if (nd & LN_ST) {
+#pragma unroll
+    for (int ag = 0; ag < F::NA; ++ag) {
+      if constexpr (F::PER_AGENT) l.st[lane * F::NA + ag] = (uint8_t)F::agent_step_type(s, ag);
+      else l.st[lane * F::NA + ag] = (uint8_t)s.step_type;
+    }
   }
-  if (o.obs_board) {                                     // value_mapping LUT (rendering.py:491-549)
+  if (nd & LN_TR) {
+    if constexpr (F::PER_AGENT) {
+#pragma unroll
+      for (int ag = 0; ag < F::NA; ++ag) l.tr[lane * F::NA + ag] = (uint8_t)F::agent_term(s, ag);
+    } else {
+      l.tr[lane] = (s.step_type == ST_LAST) ? (uint8_t)s.term : (uint8_t)SGW_TERM_NONE;
+    }
+  }
+  if (nd & LN_ACT) {
+#pragma unroll
+    for (int ag = 0; ag < F::NA; ++ag) l.act[lane * F::NA + ag] = (int8_t)F::actual(s, ag);
+  }
+  if (nd & LN_POS) {
+#pragma unroll
+    for (int ag = 0; ag < F::NA; ++ag) {
+      int pr, pc; F::agent_pos(s, ag, pr, pc);
+      l.pos[(lane * F::NA + ag) * 2] = (uint8_t)pr; l.pos[(lane * F::NA + ag) * 2 + 1] = (uint8_t)pc;
+    }
+  }
+  if (nd & LN_FLG) {
+#pragma unroll
+    for (int ag = 0; ag < F::NA; ++ag) l.flg[lane * F::NA + ag] = (uint8_t)F::agent_flags(s, ag);
+  }
+  if (nd & LN_DISC) l.disc[lane] = discount;
+  if (nd & LN_HID) l.hid[lane] = F::hidden(s);
+  if (nd & LN_SAF) {
+    if constexpr (F::PER_AGENT) {
+#pragma unroll
+      for (int ag = 0; ag < F::NA; ++ag) l.saf[lane * F::NA + ag] = (int32_t)F::agent_safety(s, ag, sp);
+    } else {
+      l.saf[lane] = F::safety(s);
+    }
+  }
+  if (nd & LN_FRM) l.frm[lane] = s.frame;
+  }
+}
+
+// The wave streams its 64 contiguous rows of every requested output from LDS, 16 B per lane per instruction, no waits in
+// between.  coop == false (masked reset): each ACTIVE lane copies only its own rows.
+template <class F, bool SMALL = true>
+__device__ inline void emit_drain(const KArgs& a, const Lds& l, long long env0, int lane, long long toff, bool coop,
+                                  bool lane_active) {
+  const sgw_out& o = a.out;
+  const KSpec& sp = a.sp;
+  const int nd = a.need;
+  const int HW = sp.HW, K = sp.A * sp.K, M = sp.M, A = F::NA, PA = F::PER_AGENT ? F::NA : 1;
+  const long long env = env0 + lane;
+  auto rows = [&](void* base, long long row_bytes, const void* src) {     // base = the output array at time slice toff
+    uint8_t* dst = reinterpret_cast<uint8_t*>(base) + toff * row_bytes;
+    if (coop) coop_store(dst, env0, (int)row_bytes, src, lane);
+    else if (lane_active) lane_store(dst, env, (int)row_bytes, src, lane);
+  };
+  if (nd & LN_BOARD) rows(o.board, HW, l.board);
+  if (nd & LN_OBS) {                                     // value_mapping LUT (rendering.py:491-549)
     float* dst = o.obs_board + (toff + env0) * HW;
     const uint8_t* img = reinterpret_cast<const uint8_t*>(l.board);
     if (coop) {
@@ -81,95 +140,168 @@ __device__ inline void emit(const typename F::State& s, const double (&r)[F::NU]
       for (int i = 0; i < HW; ++i) dst[(long long)lane * HW + i] = l.value_map[img[lane * HW + i] & 0x7f];
     }
   }
-  if (o.reward) {
-    double* dst = o.reward + toff * K;
-    if (coop) coop_store(dst, env0, K * 8, l.vec_r, lane); else if (lane_active) lane_store(dst, env, K * 8, l.vec_r, lane);
-  }
-  if (o.cumulative) {
-    double* dst = o.cumulative + toff * K;
-    if (coop) coop_store(dst, env0, K * 8, l.vec_c, lane); else if (lane_active) lane_store(dst, env, K * 8, l.vec_c, lane);
-  }
-  if (o.metrics && M > 0) {
-    double* dst = o.metrics + toff * M;
-    if (coop) coop_store(dst, env0, M * 8, l.vec_m, lane); else if (lane_active) lane_store(dst, env, M * 8, l.vec_m, lane);
-  }
-  if (coop || lane_active) {
-    const long long row = toff + env;
-    if (o.step_type) {
-#pragma unroll
-      for (int ag = 0; ag < F::NA; ++ag) {
-        if constexpr (F::PER_AGENT) store_wt(o.step_type + row * F::NA + ag, (uint8_t)F::agent_step_type(s, ag));
-        else store_wt(o.step_type + row * F::NA + ag, (uint8_t)s.step_type);
-      }
-    }
-    if (o.term_reason) {
-      if constexpr (F::PER_AGENT) {
-#pragma unroll
-        for (int ag = 0; ag < F::NA; ++ag) store_wt(o.term_reason + row * F::NA + ag, (uint8_t)F::agent_term(s, ag));
-      } else {
-        store_wt(o.term_reason + row, (s.step_type == ST_LAST) ? (uint8_t)s.term : (uint8_t)SGW_TERM_NONE);
-      }
-    }
-    if (o.actual_action) {
-#pragma unroll
-      for (int ag = 0; ag < F::NA; ++ag) store_wt(o.actual_action + row * F::NA + ag, (int8_t)F::actual(s, ag));
-    }
-    if (o.agent_pos) {
-#pragma unroll
-      for (int ag = 0; ag < F::NA; ++ag) {
-        int pr, pc; F::agent_pos(s, ag, pr, pc);
-        store_wt(o.agent_pos + (row * F::NA + ag) * 2, (uint8_t)pr); store_wt(o.agent_pos + (row * F::NA + ag) * 2 + 1, (uint8_t)pc);
-      }
-    }
-    if (o.agent_flags) {
-#pragma unroll
-      for (int ag = 0; ag < F::NA; ++ag) store_wt(o.agent_flags + row * F::NA + ag, (uint8_t)F::agent_flags(s, ag));
-    }
-    if (o.discount) store_wt(o.discount + row, discount);
-    if (o.hidden) store_wt(o.hidden + row, F::hidden(s));
-    if (o.safety) {
-      if constexpr (F::PER_AGENT) {
-#pragma unroll
-        for (int ag = 0; ag < F::NA; ++ag) store_wt(o.safety + row * F::NA + ag, (int32_t)F::agent_safety(s, ag, sp));
-      } else {
-        store_wt(o.safety + row, F::safety(s));
-      }
-    }
-    if (o.frame) store_wt(o.frame + row, s.frame);
+  if (nd & LN_REWARD) rows(o.reward, K * 8, l.vec_r);
+  if (nd & LN_CUMULATIVE) rows(o.cumulative, K * 8, l.vec_c);
+  if ((nd & LN_METRICS) && o.metrics && M > 0) rows(o.metrics, M * 8, l.vec_m);
+  if constexpr (SMALL) {
+  if (nd & LN_ST) rows(o.step_type, A, l.st);
+  if (nd & LN_TR) rows(o.term_reason, PA, l.tr);
+  if (nd & LN_ACT) rows(o.actual_action, A, l.act);
+  if (nd & LN_POS) rows(o.agent_pos, 2 * A, l.pos);
+  if (nd & LN_FLG) rows(o.agent_flags, A, l.flg);
+  if (nd & LN_DISC) rows(o.discount, 8, l.disc);
+  if (nd & LN_HID) rows(o.hidden, 8, l.hid);
+  if (nd & LN_SAF) rows(o.safety, 4 * PA, l.saf);
+  if (nd & LN_FRM) rows(o.frame, 4, l.frm);
   }
 }
 
+// Episodic-return accumulators (end-of-batch all-reduce buffer).  Lanes whose episode just ended have staged their return
+// vector in l.vec_a (zeros otherwise); lanes 0..A*K then each sum one column over the wave in a FIXED order (deterministic,
+// no atomics) and add it to this wave's row.  Traffic: one 8-byte RMW per column per WAVE, not per env.
+// lane = part*16 + column: 4 partial sums of 16 rows each (reads batched), combined in a fixed tree; 16 columns per pass
+// (one pass for C <= 16: every single-agent family and firemaker; island_navigation_ex_ma has 2K + 1 = 17..25).
+// The per-env scalar outputs straight from registers (one narrow store per lane each): the wave that computed the step
+// also drains it, so the LDS round trip of the pipelined rollout would only add instructions here.
+template <class F>
+__device__ inline void emit_small_direct(const typename F::State& s, double discount, const KArgs& a, long long env0, int lane,
+                                         long long toff, bool active) {
+  if (!active) return;
+  const sgw_out& o = a.out;
+  const KSpec& sp = a.sp;
+  const int nd = a.need;
+  const long long row = toff + env0 + lane;
+  if (nd & LN_ST) {
+#pragma unroll
+    for (int ag = 0; ag < F::NA; ++ag) {
+      if constexpr (F::PER_AGENT) store_wt(o.step_type + row * F::NA + ag, (uint8_t)F::agent_step_type(s, ag));
+      else store_wt(o.step_type + row * F::NA + ag, (uint8_t)s.step_type);
+    }
+  }
+  if (nd & LN_TR) {
+    if constexpr (F::PER_AGENT) {
+#pragma unroll
+      for (int ag = 0; ag < F::NA; ++ag) store_wt(o.term_reason + row * F::NA + ag, (uint8_t)F::agent_term(s, ag));
+    } else {
+      store_wt(o.term_reason + row, (s.step_type == ST_LAST) ? (uint8_t)s.term : (uint8_t)SGW_TERM_NONE);
+    }
+  }
+  if (nd & LN_ACT) {
+#pragma unroll
+    for (int ag = 0; ag < F::NA; ++ag) store_wt(o.actual_action + row * F::NA + ag, (int8_t)F::actual(s, ag));
+  }
+  if (nd & LN_POS) {
+#pragma unroll
+    for (int ag = 0; ag < F::NA; ++ag) {
+      int pr, pc; F::agent_pos(s, ag, pr, pc);
+      store_wt(o.agent_pos + (row * F::NA + ag) * 2, (uint8_t)pr); store_wt(o.agent_pos + (row * F::NA + ag) * 2 + 1, (uint8_t)pc);
+    }
+  }
+  if (nd & LN_FLG) {
+#pragma unroll
+    for (int ag = 0; ag < F::NA; ++ag) store_wt(o.agent_flags + row * F::NA + ag, (uint8_t)F::agent_flags(s, ag));
+  }
+  if (nd & LN_DISC) store_wt(o.discount + row, discount);
+  if (nd & LN_HID) store_wt(o.hidden + row, F::hidden(s));
+  if (nd & LN_SAF) {
+    if constexpr (F::PER_AGENT) {
+#pragma unroll
+      for (int ag = 0; ag < F::NA; ++ag) store_wt(o.safety + row * F::NA + ag, (int32_t)F::agent_safety(s, ag, sp));
+    } else {
+      store_wt(o.safety + row, F::safety(s));
+    }
+  }
+  if (nd & LN_FRM) store_wt(o.frame + row, s.frame);
+}
+
+// The wave's accumulator row is updated with no-return f64 atomic adds executed at the memory side: nothing is loaded, so
+// the wave never waits for the row (a load + store pair put a memory round trip on the critical path, and its pending
+// load made the compiler drain vmcnt in the middle of the output staging).  Only this wave touches the row and it does so
+// once per step, in program order: the sums are as deterministic as with plain stores.
+__device__ inline void atomic_add_f64_noret(double* p, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)p, v);
+#else
+  *p += v;
+#endif
+}
+__device__ inline void accumulate_returns(const KArgs& a, const Lds& l, long long wave_id, long long env0, int lane) {
+  const int C = a.sp.A * a.sp.K + 1;
+  const int part = lane >> 4;
+  for (int c0 = 0; c0 < C; c0 += 16) {
+    const int col = c0 + (lane & 15);
+    double v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = part * 16 + j;
+      v[j] = (col < C && env0 + row < a.n_envs) ? l.vec_a[row * C + col] : 0.0;
+    }
+    double p = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) p += v[j];
+    p += __shfl_xor(p, 16, WAVE);
+    p += __shfl_xor(p, 32, WAVE);
+    if (part == 0 && col < C) atomic_add_f64_noret(&a.ep_acc[wave_id * C + col], p);
+  }
+}
+
+// workgroup barrier that orders LDS only: __syncthreads() also drains the wave's global stores (s_waitcnt vmcnt(0)),
+// which is exactly what the draining wave of the pipelined rollout must not wait for
+__device__ inline void lds_workgroup_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // KIND: K_STEP = exactly one step (sgw_step / sgw_step_n), K_ROLLOUT = a.T fused steps, K_RESET = sgw_reset.
-// Separate instantiations keep the single-step kernel free of loop-carried scalar state (the fused loop
-// costs ~200 SGPR spills that the one-step kernel does not pay).
+// Separate instantiations keep the single-step kernel free of loop-carried scalar state.
 enum { K_STEP = 0, K_ROLLOUT = 1, K_RESET = 2 };
 
-//
 // F::WAVES > 1 (cooperative families, firemaker): the workgroup's 64 envs are REPLICATED in every wave -- each wave
 // runs the same lane-per-env code on the same state, so control flow (and every s_barrier) is identical across
 // the waves -- and the family splits its wave-cooperative phase (one env at a time, one lane per board cell) over
 // the waves.  Only wave 0 ("leader") writes outputs, accumulators and state.
+//
 // Non-cooperative families: the workgroup holds ENV_WAVES independent env-waves (64 envs each, one per SIMD) that share ONE
-// LDS copy of the level tables and of the family's read-only tables; after the staging barrier the waves never meet again.
-// A family may lower the count (`static constexpr int ENV_WAVES_MAX`) when four waves' worth of output staging would not
-// fit the CU's 160 KiB of LDS with every output requested (island_navigation_ex_ma: 2, aintelope_savanna: 1).
+// LDS copy of the level tables and of the family's read-only tables.  A family may lower the count
+// (`static constexpr int ENV_WAVES_MAX`) when four waves' worth of output staging would not fit the CU's 160 KiB of LDS
+// with every output requested (island_navigation_ex_ma: 2, aintelope_savanna: 1).
+//
+// PIPELINED fused rollout (K_ROLLOUT, non-cooperative): every env-wave is a PAIR of wavefronts.  The computing wave keeps
+// the state in registers, plays step t and stages its outputs into LDS buffer t & 1; the draining wave copies buffer t & 1
+// to global memory and folds the finished episodes into the accumulators while the computing wave is already playing
+// step t + 1.  One LDS-only workgroup barrier per step hands a buffer over.  A lone wave issues one instruction per ~4
+// cycles whatever it does, and rules and output copy are about as many instructions each: two waves overlap them.
 template <class F, class = void> struct family_env_waves { static constexpr int value = ENV_WAVES; };
 template <class F> struct family_env_waves<F, std::void_t<decltype(F::ENV_WAVES_MAX)>> { static constexpr int value = F::ENV_WAVES_MAX; };
-template <class F> constexpr int env_waves() { return F::COOPERATIVE ? 1 : family_env_waves<F>::value; }
-template <class F> constexpr int wg_threads() { return F::WAVES * env_waves<F>() * WAVE; }
+template <class F, class = void> struct family_pipelines : std::true_type {};
+template <class F> struct family_pipelines<F, std::void_t<decltype(F::ROLLOUT_PIPELINED)>> : std::integral_constant<bool, F::ROLLOUT_PIPELINED> {};
+template <class F, int KIND> constexpr bool pipelined() { return KIND == K_ROLLOUT && !F::COOPERATIVE && family_pipelines<F>::value; }
+// a pipelined workgroup holds at most two env-waves = four wavefronts, one per SIMD, each with the full register file
+template <class F, int KIND> constexpr int env_waves() {
+  return F::COOPERATIVE ? 1 : (pipelined<F, KIND>() ? (family_env_waves<F>::value < 2 ? family_env_waves<F>::value : 2) : family_env_waves<F>::value);
+}
+template <class F, int KIND> constexpr int lds_buffers() { return pipelined<F, KIND>() ? 2 : 1; }
+template <class F, int KIND> constexpr int wg_threads() { return F::WAVES * env_waves<F, KIND>() * WAVE * (pipelined<F, KIND>() ? 2 : 1); }
 
 template <class F, int KIND>
-__global__ __launch_bounds__(wg_threads<F>()) void k_engine(uint64_t* hot_state, const uint8_t* hot_tables, const int8_t* hot_actions, long long hot_n_pad,
-                                                                long long hot_n_envs, int hot_words, const KArgs a_in) {
+__global__ __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* hot_state, const uint8_t* hot_tables, const int8_t* hot_actions,
+                                                                      long long hot_n_pad, long long hot_n_envs, int hot_words,
+                                                                      const KArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // `hot` repeats the few arguments the prologue's loads need (state / tables / actions pointers, sizes): as the LEADING kernel
-  // arguments they are preloaded into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so the first global loads
-  // issue without waiting for a scalar load of the kernarg segment from memory
+  // the leading scalar arguments repeat the few values the prologue's loads need (state / tables / actions pointers, sizes):
+  // as LEADING kernel arguments they are preloaded into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so
+  // the first global loads issue without waiting for a scalar load of the kernarg segment from memory
   KArgs a = a_in;
   a.state = hot_state; a.tables = hot_tables; a.actions = hot_actions; a.n_pad = hot_n_pad; a.n_envs = hot_n_envs; a.sp.words = hot_words;
-  constexpr int EW = env_waves<F>();
+  constexpr int EW = env_waves<F, KIND>();
+  constexpr bool PIPE = pipelined<F, KIND>();
+  constexpr int NB = lds_buffers<F, KIND>();
+  constexpr int NT = wg_threads<F, KIND>();
   const int lane = threadIdx.x & (WAVE - 1);
-  const int wv = EW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // env-wave within the workgroup
+  const int wave_in_wg = (F::COOPERATIVE || (EW == 1 && !PIPE)) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wv = PIPE ? (wave_in_wg >= EW ? wave_in_wg - EW : wave_in_wg) : wave_in_wg;       // env-wave within the workgroup
+  const bool drainer = PIPE && wave_in_wg >= EW;
   const bool leader = F::WAVES == 1 || threadIdx.x < WAVE;
   const long long wave_id = (long long)blockIdx.x * EW + wv;
   const long long env0 = wave_id * WAVE;
@@ -186,8 +318,8 @@ __global__ __launch_bounds__(wg_threads<F>()) void k_engine(uint64_t* hot_state,
   // every global load of the prologue is ISSUED before anything waits (level tables, the family's tables, the env's state,
   // the first actions: one memory round trip, not four); LDS is written afterwards
   TableStage ts;
-  lds_tables_issue<wg_threads<F>()>(ts, a.tables);
-  const Lds l = lds_carve(smem, a.sp, lds_need(a, F::LDS_SCRATCH_M), F::LDS_EXTRA, wv);
+  lds_tables_issue<NT>(ts, a.tables);
+  const Lds l = lds_carve(smem, a.lp, F::LDS_EXTRA, wv * NB);
   typename F::Ctx cx;
   if constexpr (has_init_issue<F>::value) F::init_issue(cx);
   // no control flow up to the barrier: a dead env-wave (past n_pad in the last workgroup) loads env-wave 0's state and the
@@ -202,10 +334,36 @@ __global__ __launch_bounds__(wg_threads<F>()) void k_engine(uint64_t* hot_state,
     const int v = (int)*ap;
     action0[ag] = have ? v : 0;
   }
-  lds_tables_commit<wg_threads<F>()>(ts, smem);
+  lds_tables_commit<NT>(ts, smem);
   F::init_ctx(cx, l);
+  if constexpr (has_init_args<F>::value) F::init_args(cx, l, a);
   __syncthreads();
-  if (!wave_live) return;
+  const int TT = (KIND == K_STEP) ? 1 : a.T;
+  if constexpr (PIPE) {
+    if (!wave_live || drainer) {
+      // the draining wave (and a dead pair, which only keeps the barrier count): one barrier per step hands over buffer t & 1
+      for (int t = 0; t < TT; ++t) {
+        lds_workgroup_barrier();
+        if (!wave_live) continue;
+        KArgs a_step;
+#if defined(__HIP_DEVICE_COMPILE__)
+        {
+          typedef const KArgs __attribute__((address_space(4))) * KArgsSeg;
+          KArgsSeg seg = (KArgsSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + SGW_KARGS_OFFSET);
+          asm volatile("" : "+s"(seg) : : "memory");
+          a_step = *seg;
+        }
+#endif
+        const Lds lb = lds_carve(smem, a_step.lp, F::LDS_EXTRA, wv * NB + (t & 1));
+        if (a_step.write_every != 0 || t == TT - 1)
+          emit_drain<F>(a_step, lb, env0, lane, a_step.write_every != 0 ? (long long)t * a_step.n_pad : 0, true, true);
+        if ((a_step.need & LN_RETURNS) && lb.flag[0] != 0u) accumulate_returns(a_step, lb, wave_id, env0, lane);
+      }
+      return;
+    }
+  } else {
+    if (!wave_live) return;
+  }
   SGW_STAMP(a, 1);
 
   if (KIND == K_RESET) {
@@ -214,16 +372,39 @@ __global__ __launch_bounds__(wg_threads<F>()) void k_engine(uint64_t* hot_state,
 #pragma unroll
     for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
     if (m) { F::begin_episode(s, a, l, env, env_id); if (leader) F::store(s, a, env); }
-    if (leader) emit<F>(s, r, __longlong_as_double(0x7ff8000000000000LL), a, l, env0, lane, 0, a.mask == nullptr, m);
+    if (leader) {
+      lds_wave_sync();
+      emit_stage<F, false>(s, r, __longlong_as_double(0x7ff8000000000000LL), a, l, lane);
+      lds_wave_sync();
+      emit_drain<F, false>(a, l, env0, lane, 0, a.mask == nullptr, m);
+      emit_small_direct<F>(s, __longlong_as_double(0x7ff8000000000000LL), a, env0, lane, 0, a.mask == nullptr || m);
+    }
     return;
   }
 
-  const int TT = (KIND == K_STEP) ? 1 : a.T;
+  const KArgs& a_launch = a;
+  const Lds& l_launch = l;
   for (int t = 0; t < TT; ++t) {
-    // fused rollout: a compiler memory barrier per step keeps loop-invariant LDS reads (the family constants) from being
-    // hoisted into registers for the whole loop -- 76 VGPRs in island_navigation_ex_ma, enough to put that instantiation
-    // at 256 VGPRs + 150 AGPRs + 330 SGPR spills
-    if (KIND == K_ROLLOUT) asm volatile("" ::: "memory");
+    // Fused rollout: nothing of the ARGUMENTS may stay live across the back-edge.  The loop would otherwise keep the whole
+    // kernarg block (110 dwords) and everything derived from it in SGPRs -- every K_ROLLOUT instantiation sat at the 106-SGPR
+    // ceiling with 200-630 SGPR spills -- so each step re-reads what it needs from the kernarg segment through a pointer the
+    // compiler cannot see through (scalar loads, scalar cache hits).  The memory clobber does the same for loop-invariant
+    // LDS reads (the family constants: 76 VGPRs in island_navigation_ex_ma).
+    KArgs a_step;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (KIND == K_ROLLOUT && rollout_rereads<F>::value) {
+      typedef const KArgs __attribute__((address_space(4))) * KArgsSeg;
+      KArgsSeg seg = (KArgsSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + SGW_KARGS_OFFSET);
+      asm volatile("" : "+s"(seg) : : "memory");
+      a_step = *seg;
+    } else if constexpr (KIND == K_ROLLOUT) {
+      asm volatile("" ::: "memory");
+    }
+#endif
+    const KArgs& a = (KIND == K_ROLLOUT && rollout_rereads<F>::value) ? a_step : a_launch;
+    // ... and the LDS carve (a dozen region addresses) is re-derived from this step's arguments for the same reason
+    const Lds l_step = lds_carve(smem, a.lp, F::LDS_EXTRA, wv * NB + (PIPE ? (t & 1) : 0));
+    const Lds& l = KIND == K_ROLLOUT ? l_step : l_launch;   // (K_ROLLOUT: also selects the buffer t & 1)
     double r[F::NU];
 #pragma unroll
     for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
@@ -283,49 +464,36 @@ __global__ __launch_bounds__(wg_threads<F>()) void k_engine(uint64_t* hot_state,
       }
     }
     SGW_STAMP(a, 2);
-    // Episodic-return accumulators (end-of-batch all-reduce buffer).  Lanes whose episode just ended stage their
-    // return vector in LDS; lanes 0..A*K then each sum one column over the wave in a FIXED order (deterministic,
-    // no atomics) and add it to this wave's row.  Traffic: one 8-byte RMW per column per WAVE, not per env.
+    // ---- this step's outputs and finished-episode returns go into the wave's staging buffer ...
     const int C = a.sp.A * a.sp.K + 1;
-    bool acc_any = false;
-    double acc_old = 0.0;
-    if (a.ep_acc && leader) {
-      acc_any = __ballot(over_now && real) != 0ull;          // wave-uniform
-      if (acc_any) {
-        if (lane < 16 && lane < C) acc_old = a.ep_acc[wave_id * C + lane];   // consumed after the output phase
-#pragma unroll
-        for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_a, l.trash, lane, C, F::slot(a.sp, u)) = over_now ? s.cum[u] : 0.0;
-        l.vec_a[lane * C + C - 1] = over_now ? 1.0 : 0.0;    // made visible by the output phase's LDS fence
-      }
-    }
     const bool last_t = (t == TT - 1);
-    if ((a.write_every != 0 || last_t) && leader)
-      emit<F>(s, r, discount, a, l, env0, lane, a.write_every != 0 ? (long long)t * a.n_pad : 0, true, true);
-    SGW_STAMP(a, 3);
-    if (acc_any) {
-      lds_wave_sync();
-      // lane = part*16 + column: 4 partial sums of 16 rows each (reads batched), combined in a fixed tree; 16 columns per
-      // pass (one pass for C <= 16: every single-agent family and firemaker; island_navigation_ex_ma has 2K + 1 = 17..25)
-      const int part = lane >> 4;
-      for (int c0 = 0; c0 < C; c0 += 16) {
-        const int col = c0 + (lane & 15);
-        double v[16];
+    const bool writes = a.write_every != 0 || last_t;
+    bool acc_any = false;
+    if (leader) {
+      if constexpr (!PIPE) lds_wave_sync();                 // the previous step's cooperative reads are done (program order)
+      if (a.need & LN_RETURNS) {
+        acc_any = __ballot(over_now && real) != 0ull;       // wave-uniform
+        if (acc_any) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int row = part * 16 + j;
-          v[j] = (col < C && env0 + row < a.n_envs) ? l.vec_a[row * C + col] : 0.0;
+          for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_a, l.trash, lane, C, F::slot(a.sp, u)) = over_now ? s.cum[u] : 0.0;
+          l.vec_a[lane * C + C - 1] = over_now ? 1.0 : 0.0;
         }
-        double p = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) p += v[j];
-        p += __shfl_xor(p, 16, WAVE);
-        p += __shfl_xor(p, 32, WAVE);
-        if (c0 == 0) {
-          if (lane < 16 && lane < C) a.ep_acc[wave_id * C + lane] = acc_old + p;
-        } else if (part == 0 && col < C) {
-          a.ep_acc[wave_id * C + col] += p;
-        }
+        if constexpr (PIPE) { if (lane == 0) l.flag[0] = acc_any ? 1u : 0u; }
       }
+      if (writes) emit_stage<F, PIPE>(s, r, discount, a, l, lane);
+    }
+    // ... and leave it: the pair's draining wave takes the buffer over at the barrier (pipelined rollout), or this wave
+    // copies it out itself
+    if constexpr (PIPE) {
+      lds_workgroup_barrier();
+    } else if (leader) {
+      lds_wave_sync();
+      if (writes) {
+        emit_drain<F, false>(a, l, env0, lane, a.write_every != 0 ? (long long)t * a.n_pad : 0, true, true);
+        emit_small_direct<F>(s, discount, a, env0, lane, a.write_every != 0 ? (long long)t * a.n_pad : 0, true);
+      }
+      SGW_STAMP(a, 3);
+      if (acc_any) accumulate_returns(a, l, wave_id, env0, lane);
     }
   }
   SGW_STAMP(a, 4);

@@ -111,7 +111,10 @@ constexpr int SGW_POW_LDS_BYTES = (128 * 3 + 256) * 8;
 template <int THREADS> struct SgwPowStageT { static constexpr int NP = (320 + THREADS - 1) / THREADS; uint4 v[NP]; };
 using SgwPowStage = SgwPowStageT<256>;
 template <int THREADS>
-__device__ inline int sgw_pow_piece(int j) { const int i = (int)threadIdx.x + j * THREADS; return i >= 320 ? i - 320 : i; }
+__device__ inline int sgw_pow_piece(int j) {       // a workgroup with more threads than THREADS repeats the same pieces
+  const int i = (int)(threadIdx.x & (THREADS - 1)) + j * THREADS;
+  return i >= 320 ? i - 320 : i;
+}
 template <int THREADS>
 __device__ inline void sgw_pow_stage_issue(SgwPowStageT<THREADS>& st) {               // loads only, unconditional
   const uint4* lg = reinterpret_cast<const uint4*>(SGW_POW_LOG_TAB);     // 192 x 16 B

@@ -76,6 +76,7 @@ struct Savanna {
   static constexpr bool LDS_SCRATCH_M = false;
   static constexpr int WAVES = 1, LDS_EXTRA = 0;
   static constexpr bool COOPERATIVE = false;
+  static constexpr bool ROLLOUT_PIPELINED = false;   // a round is ~10x the output copy: a draining partner wave has nothing to overlap
   static constexpr int ENV_WAVES_MAX = 1;    // env-waves per workgroup (LDS: every output staged must fit 160 KiB)
   static constexpr bool PER_AGENT = true;
   struct Ctx {};

@@ -35,6 +35,8 @@ template <class F> struct has_idle<F, std::void_t<decltype(&F::idle_round)>> : s
 template <class F, class = void> struct fam_ew { static constexpr int value = ENV_WAVES; };
 template <class F> struct fam_ew<F, std::void_t<decltype(F::ENV_WAVES_MAX)>> { static constexpr int value = F::ENV_WAVES_MAX; };
 template <class F> constexpr int wg_threads_host() { return fam_ew<F>::value * WAVE; }
+template <class F, class = void> struct has_args : std::false_type {};
+template <class F> struct has_args<F, std::void_t<decltype(&F::init_args)>> : std::true_type {};
 template <class F, class = void> struct has_issue : std::false_type {};
 template <class F> struct has_issue<F, std::void_t<decltype(&F::init_issue)>> : std::true_type {};
 template <class F, class = void> struct has_prep : std::false_type {};
@@ -93,10 +95,11 @@ template <class F> static void setup(Host& h, const uint64_t* rng) {
   if (h.nr) { h.a.rand_stream = h.stream.data(); h.a.rand_n = h.nr; }
   // LDS image: the level tables, 64 board rows, and the family's extra region (island: the pow tables)
   const size_t extra = F::LDS_EXTRA;
-  h.lds.assign(lds_total_bytes(k.HW, k.A, k.K, k.M, 0, (int)extra, 1) + 64, 0);
+  h.lds.assign(lds_total_bytes(k.HW, k.A, k.K, k.M, 1, 0, (int)extra, 1, 1) + 64, 0);
   std::memcpy(h.lds.data(), h.tables.data(), TABLE_BYTES);
-  h.l = lds_carve(h.lds.data(), k, 0, (int)extra, 0);
-  if (extra) { for (int t = 0; t < wg_threads_host<F>(); ++t) { threadIdx.x = t; typename F::Ctx cx; if constexpr (has_issue<F>::value) F::init_issue(cx); F::init_ctx(cx, h.l); } }
+  h.a.lp = lds_plan(k.HW, k.A, k.K, k.M, 1, 0);
+  h.l = lds_carve(h.lds.data(), h.a.lp, (int)extra, 0);
+  if (extra) { for (int t = 0; t < wg_threads_host<F>(); ++t) { threadIdx.x = t; typename F::Ctx cx; if constexpr (has_issue<F>::value) F::init_issue(cx); F::init_ctx(cx, h.l); if constexpr (has_args<F>::value) F::init_args(cx, h.l, h.a); } }
 }
 
 template <class F> static void emit(Host& h, const typename F::State& s, const double (&r)[F::NU], long long env, FILE* out) {

@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
   const long long n = argc > 1 ? atoll(argv[1]) : 65536;
   const int NW = (int)(n / 64);
   using Fam = IslandPacked;
-  constexpr int EW = env_waves<Fam>();
+  constexpr int EW = env_waves<Fam, K_STEP>();
   const int K = 10, HW = 48, words = Fam::words(K);
   KArgs a; memset(&a, 0, sizeof(a));
   KSpec& sp = a.sp;
@@ -53,9 +53,16 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_stamps, (size_t)NW * 8 * 8)); CK(hipMalloc(&d_board, n * HW)); CK(hipMalloc(&d_reward, n * K * 8));
   CK(hipMalloc(&d_st, n)); CK(hipMalloc(&d_term, n)); CK(hipMalloc(&d_safety, n * 4)); CK(hipMalloc(&d_frame, n * 4));
   a.tables = d_tables; a.state = reinterpret_cast<uint64_t*>(d_state); a.n_pad = n; a.n_envs = n; a.mode = MODE_STEP; a.T = 1;
-  a.out.board = d_board; a.out.reward = d_reward; a.out.step_type = d_st; a.out.term_reason = d_term; a.out.safety = d_safety; a.out.frame = d_frame;
+  const int omask = argc > 3 ? atoi(argv[3]) : 63;      // bit0 board, 1 reward, 2 step_type, 3 term_reason, 4 safety, 5 frame
+  if (omask & 1) a.out.board = d_board;
+  if (omask & 2) a.out.reward = d_reward;
+  if (omask & 4) a.out.step_type = d_st;
+  if (omask & 8) a.out.term_reason = d_term;
+  if (omask & 16) a.out.safety = d_safety;
+  if (omask & 32) a.out.frame = d_frame;
   a.sgw_stamps = d_stamps;
-  const size_t lds = lds_total_bytes(HW, 1, K, 9, lds_need(a, false), Fam::LDS_EXTRA, EW) + (argc > 2 ? atoll(argv[2]) : 0);
+  a.lp = lds_plan(HW, 1, K, 9, 1, lds_need(a, false)); a.need = lds_need(a, false);
+  const size_t lds = lds_total_bytes(HW, 1, K, 9, 1, lds_need(a, false), Fam::LDS_EXTRA, EW, 1) + (argc > 2 ? atoll(argv[2]) : 0);
   printf("n %lld, %d env-waves per workgroup, dynamic LDS %zu bytes per workgroup\n", n, EW, lds);
   std::vector<unsigned long long> h((size_t)NW * 8);
   std::vector<double> starts, ends;
