@@ -553,7 +553,6 @@ int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agen
   if (!e || !board_dev || !agent_pos_dev || !views_dev) return fail(SGW_ERR_ARG, "sgw_agent_views: null argument");
   ViewSpec v = make_viewspec(e);
   if (v.total <= 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_agent_views: the spec defines no agent views");
-  for (int a = 0; a < v.A; ++a) if (v.vw[a] <= 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_agent_views: every agent needs a view");
   if (check_rotation(e, v, agent_flags_dev)) return SGW_ERR_UNSUPPORTED;
   HIP_TRY(hipSetDevice(e->device));
   long long total = e->n_envs * v.total;

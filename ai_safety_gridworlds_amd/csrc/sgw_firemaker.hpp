@@ -25,7 +25,10 @@
 //   18 validity bits of the 9 offsets (as integer) 19 button countdown reload (1 + 1 + duration)
 //   20..24 allowed-target mask words 25..29 territory mask words (bit patterns stored in the f64 slots)
 // spec.aux: per-cell class bits: 1 wall, 2 territory (extended), 4 workshop, 8 stop button
-// spec.flags: bit0 randomize_agent_actions_order
+// spec.flags: bit0 randomize_agent_actions_order, bit1 worker '2' absent, bit2 supervisor 'S' absent (amount_agents 2 / 1:
+//   FM:160, 330-337).  The layout always has the three columns ('1','2','S'); an absent agent is parked on the wall cell (0, 0)
+//   by the spec's start cells, never plays, is never drawn, and its character stays in the art as a BACKDROP tile (aux bits
+//   16 / 32): '2' under the grown workshop territory (passable, not an external tile), 'S' drawn and impassable unless it burns
 // reward slots: [agent][3]: workers [ENERGY, WORKSHOP, -], supervisor [ENERGY, EXTERNAL_FIRE, TRESPASSING]
 // metrics ids (FM:123-140): 0-2 ExternalVisits_{1,2,S} 3-5 Internal 6-8 Workshop 9-11 Fire 12-14 StopButton 15 countdown
 // state words: 0 core | 1 positions | 2 rng buffer | 3-6 PCG64 state/inc | 7-11 fire | 12-15 visits | 16-24 cumulative
@@ -63,10 +66,13 @@ struct Firemaker {
   static __device__ int slot(const KSpec& sp, int u) { return sp.dim_slot[0][u]; }
   static constexpr bool LDS_SCRATCH_M = false;
   static constexpr int W = 17, H = 17, CELLS = 289;
-  enum { F_SHUFFLE = 1 };
+  enum { F_SHUFFLE = 1, F_NO_AGENT2 = 2, F_NO_SUP = 4 };
   enum P { P_AGENT_MOVE, P_AGENT_WORK, P_AGENT_WS_ENERGY, P_SUP_MOVE, P_SUP_EXT_FIRE, P_SUP_TRESPASS, P_SUP_BUTTON,
            P_SUP_WORKSHOP, P_CONTINUE, P_SPREAD0, P_VALID = 18, P_RELOAD = 19, P_ALLOWED0 = 20, P_TERR0 = 25 };
-  enum { C_WALL = 1, C_TERR = 2, C_WORKSHOP = 4, C_BUTTON = 8 };
+  enum { C_WALL = 1, C_TERR = 2, C_WORKSHOP = 4, C_BUTTON = 8, C_GHOST = 16 /* a drawn agent character without a sprite */,
+         C_NOT_GAP = 32 /* the backdrop under this cell is not ' ' */ };
+  static __device__ bool present(const KSpec& sp, int ag) { return ag == 0 || !(sp.flags & (ag == 1 ? F_NO_AGENT2 : F_NO_SUP)); }
+  static __device__ int n_present(const KSpec& sp) { return 3 - ((sp.flags & F_NO_AGENT2) ? 1 : 0) - ((sp.flags & F_NO_SUP) ? 1 : 0); }
 
   struct State {
     int frame, step_type, term, countdown, n_ext, at_ws;   // at_ws: bit a = agent a stands on a workshop tile
@@ -166,7 +172,11 @@ struct Firemaker {
 
   // The step after LAST still shuffles the (discarded) actions before it resets (PM:177-180, 211-221)
   static __device__ void pre_autoreset(State& s, const KArgs& a, const int (&)[NA]) {
-    if ((a.sp.flags & F_SHUFFLE) && s.step_type == ST_LAST) { interval(s, 2); interval(s, 1); }
+    if ((a.sp.flags & F_SHUFFLE) && s.step_type == ST_LAST) {        // Generator.shuffle of the n submitted actions, n > 1
+      const int n = n_present(a.sp);
+      if (n == 3) interval(s, 2);
+      if (n >= 2) interval(s, 1);
+    }
   }
 
   // ---- 289-bit masks -----------------------------------------------------------------------------
@@ -351,7 +361,7 @@ struct Firemaker {
   }
 
   // FireDrape.update (FM:536-629).  Runs with all 64 lanes of all 4 waves active (see k_engine).
-  static __device__ void fire_update(State& s, const Lds& l, double (&r)[NU], bool live, Ctx& cx) {
+  static __device__ void fire_update(State& s, const KSpec& sp, const Lds& l, double (&r)[NU], bool live, Ctx& cx) {
     const double* p = l.params;
     const int lane = cx.lane;
 #pragma unroll
@@ -451,11 +461,15 @@ struct Firemaker {
                   __builtin_popcountll(s.fire.c & ~pword(l, P_TERR0 + 2)) + __builtin_popcountll(s.fire.d & ~pword(l, P_TERR0 + 3)) +
                   __builtin_popcountll(s.fire.e & ~pword(l, P_TERR0 + 4));
     s.n_ext = live ? n : s.n_ext;                               // FM:624-629
-    r[2 * 3 + 1] += live ? (double)n * p[P_SUP_EXT_FIRE] : 0.0;
+    // the supervisor's penalty; with no supervisor it goes to the lone worker (FM:626-629), whose third reward unit it is
+    const double ext = live ? (double)n * p[P_SUP_EXT_FIRE] : 0.0;
+    const bool sup = !(sp.flags & F_NO_SUP);
+    r[2 * 3 + 1] += sup ? ext : 0.0;
+    r[0 * 3 + 2] += sup ? 0.0 : ext;
   }
 
   // one Engine.play({agent: {"step": action}})
-  static __device__ void play_one(State& s, int ag, int action, const Lds& l, double (&r)[NU], bool live, Ctx& cx) {
+  static __device__ void play_one(State& s, int ag, int action, const KSpec& sp, const Lds& l, double (&r)[NU], bool live, Ctx& cx) {
     const double* p = l.params;
     if (live) {
       s.frame += 1;
@@ -467,7 +481,7 @@ struct Firemaker {
       const int nr = cr + dr, nc = cc + dc;
       const bool inside = (nr >= 0) & (nr < H) & (nc >= 0) & (nc < W);
       const int ncell = inside ? nr * W + nc : 0;
-      bool blocked = !inside || (l.aux[ncell] & C_WALL);
+      bool blocked = !inside || (l.aux[ncell] & C_WALL) || ((l.aux[ncell] & C_GHOST) && !get_bit(s.fire, ncell));   // the walker reads the last rendering
 #pragma unroll
       for (int b = 0; b < 3; ++b) blocked |= (b != ag) & (s.row[b] == nr) & (s.col[b] == nc);
       const bool moved = ((dr | dc) != 0) & !blocked;
@@ -485,7 +499,7 @@ struct Firemaker {
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         const uint32_t me = (b == ag) ? 1u : 0u;
-        s.visits[0 + b] += me & (uint32_t)((cls & C_WALL) == 0);     // unoccluded gap layer == backdrop ' ' (Q19)
+        s.visits[0 + b] += me & (uint32_t)((cls & (C_WALL | C_NOT_GAP)) == 0);     // unoccluded gap layer == backdrop ' ' (Q19)
         s.visits[3 + b] += me & (uint32_t)((cls & C_TERR) != 0);
         s.visits[6 + b] += me & (uint32_t)((cls & C_WORKSHOP) != 0);
         s.visits[9 + b] += me & (uint32_t)on_fire;
@@ -509,11 +523,11 @@ struct Firemaker {
         if (b == 2) r[2 * 3 + 2] += (at && sup_quiet) ? p[P_SUP_WORKSHOP] : 0.0;
         const bool work = at && !sup_quiet && (s.countdown == 0);
         r[0 * 3 + 1] += work ? p[P_AGENT_WORK] : 0.0;
-        r[1 * 3 + 1] += work ? p[P_AGENT_WORK] : 0.0;             // amount_agents > 2 (FM:509-510)
+        r[1 * 3 + 1] += (work && !(sp.flags & F_NO_AGENT2)) ? p[P_AGENT_WORK] : 0.0;             // amount_agents > 2 (FM:509-510)
         r[b * 3 + 0] += work ? p[P_AGENT_WS_ENERGY] : 0.0;
       }
     }
-    fire_update(s, l, r, live, cx);
+    fire_update(s, sp, l, r, live, cx);
     // WorkshopTerritoryDrape.update FM:702-709
     r[2 * 3 + 2] += (live && (l.aux[s.row[2] * W + s.col[2]] & C_TERR) && s.n_ext == 0) ? p[P_SUP_TRESPASS] : 0.0;
   }
@@ -522,20 +536,27 @@ struct Firemaker {
   // firemaker has no terminating entity; the episode ends through max_iterations).
   static __device__ double play(State& s, const int (&actions)[3], const KArgs& a, const Lds& l, double (&r)[NU],
                                 long long env, bool live, Ctx& cx) {
-    int o0 = 0, o1 = 1, o2 = 2;
-    if (live && (a.sp.flags & F_SHUFFLE)) {                     // Generator.shuffle(list): i = 2, then i = 1
-      int j = interval(s, 2);
-      int t2 = j == 0 ? o0 : (j == 1 ? o1 : o2);
-      o0 = j == 0 ? o2 : o0; o1 = j == 1 ? o2 : o1; o2 = t2;
-      j = interval(s, 1);
-      int t1 = j == 0 ? o0 : o1;
-      o0 = j == 0 ? o1 : o0; o1 = t1;
+    // the agents that exist, in update-schedule order ('1', '2', 'S'); Generator.shuffle(list of n): i = n - 1 .. 1
+    const KSpec& sp = a.sp;
+    const int n = n_present(sp);
+    int o0 = 0, o1 = (sp.flags & F_NO_AGENT2) ? 2 : 1, o2 = 2;
+    if (live && (sp.flags & F_SHUFFLE)) {
+      if (n == 3) {
+        const int j = interval(s, 2);
+        const int t2 = j == 0 ? o0 : (j == 1 ? o1 : o2);
+        o0 = j == 0 ? o2 : o0; o1 = j == 1 ? o2 : o1; o2 = t2;
+      }
+      if (n >= 2) {
+        const int j = interval(s, 1);
+        const int t1 = j == 0 ? o0 : o1;
+        o0 = j == 0 ? o1 : o0; o1 = t1;
+      }
     }
 #pragma nounroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < n; ++i) {
       const int ag = i == 0 ? o0 : (i == 1 ? o1 : o2);
       const int act = ag == 0 ? actions[0] : (ag == 1 ? actions[1] : actions[2]);
-      play_one(s, ag, act, l, r, live, cx);
+      play_one(s, ag, act, sp, l, r, live, cx);
     }
     return 1.0;
   }
@@ -550,7 +571,7 @@ struct Firemaker {
 #pragma unroll
     for (int ag = 0; ag < 3; ++ag) {
       const int cell = s.row[ag] * W + s.col[ag];
-      if ((cell >> 2) == i) {
+      if ((cell >> 2) == i && present(sp, ag)) {
         const int sh = (cell & 3) * 8;
         const uint32_t ch = ag == 0 ? '1' : (ag == 1 ? '2' : 'S');
         v = (v & ~(0xffu << sh)) | (ch << sh);

@@ -282,7 +282,10 @@ class BatchedEngine(object):
       if k not in self._bufs or self._T != 1:
         raise N.SgwError("derived_stats needs the 'reward', 'cumulative' and 'frame' outputs of a single step")
     if sp.A > 1:
-      ks = [len(sp.agent_dim_names[c]) for c in sp.agent_chars]
+      slots = getattr(sp, "agent_slots", list(range(len(sp.agent_chars))))
+      ks = [0] * sp.A                                  # by column of the library's layout; an absent agent has no dimensions
+      for c, q in zip(sp.agent_chars, slots):
+        ks[q] = len(sp.agent_dim_names[c])
     else:
       ks = [sp.K]
     karr = (C.c_int32 * N.MAX_AGENTS)(*(ks + [0] * (N.MAX_AGENTS - len(ks))))

@@ -475,9 +475,10 @@ def _firemaker_spec(kwargs):
   for flag, default in FIREMAKER_DEFAULTS.items():
     if isinstance(default, dict):
       cfg[flag] = _parse_reward(cfg[flag], default, flag)
-  if int(cfg["amount_agents"]) != 3:
-    raise NotImplementedError("firemaker_ex_ma: the batched engine implements amount_agents=3 (workers '1','2' + "
-                              "supervisor 'S', the reference's maximum, firemaker_ex_ma.py:113-118)")
+  amount = int(cfg["amount_agents"])
+  if amount not in (1, 2, 3):
+    raise ValueError("firemaker_ex_ma: amount_agents must be 1 (worker '1'), 2 ('1' + supervisor 'S', the reference's default) "
+                     "or 3 ('1', '2', 'S'): firemaker_ex_ma.py:113-118, 160, 330-337")
   if cfg["observation_direction_mode"] != 0 or cfg["action_direction_mode"] != 0:
     raise NotImplementedError("firemaker_ex_ma: only direction mode 0 (fixed) is implemented")
   if int(cfg["level"]) != 0:
@@ -487,7 +488,9 @@ def _firemaker_spec(kwargs):
   flat = "".join(art)
   if any(c != '#' for c in art[0] + art[-1]) or any(r[0] != '#' or r[-1] != '#' for r in art):
     raise NotImplementedError("firemaker_ex_ma: the fire kernel assumes a walled border")
-  agents = ['1', '2', 'S']
+  slots = ['1', '2', 'S']                 # the library's fixed column layout (actions, per-agent outputs)
+  agents = {1: ['1'], 2: ['1', 'S'], 3: ['1', '2', 'S']}[amount]       # update-schedule order, firemaker_ex_ma.py:352-355
+  ghosts = [c for c in slots if c not in agents]    # characters without a sprite stay in the art as BACKDROP tiles
   territory = [c == '-' for c in flat]
   for r in range(H):                      # WorkshopTerritoryDrape.__init__ (firemaker_ex_ma.py:690-699)
     for c in range(W):
@@ -500,11 +503,14 @@ def _firemaker_spec(kwargs):
   aux = []
   for k, ch in enumerate(flat):
     base = '#' if ch == '#' else ' '
-    if territory[k]: base = '-'
+    ghost = ch in ghosts
+    if ghost: base = ch                   # drawn unless a drape covers it ...
+    if territory[k]: base = '-'           # ... as the grown workshop territory covers the '2' inside the workshop
     if ch == 'W': base = 'W'
     if ch == 'B': base = 'B'
     static_board.append(base)
-    aux.append((1 if ch == '#' else 0) | (2 if territory[k] else 0) | (4 if ch == 'W' else 0) | (8 if ch == 'B' else 0))
+    aux.append((1 if ch == '#' else 0) | (2 if territory[k] else 0) | (4 if ch == 'W' else 0) | (8 if ch == 'B' else 0) |
+               (16 if ghost and base == ch else 0) | (32 if ghost else 0))
   maxd = float(cfg["FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE"])
   if math.ceil(maxd) > 3:
     raise NotImplementedError("firemaker_ex_ma: FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE > 3 (window > 5x5) is not implemented")
@@ -527,9 +533,20 @@ def _firemaker_spec(kwargs):
   params += _mask_words([(a & (1 | 4 | 8)) == 0 for a in aux]) + _mask_words(territory)
   lo, n = (0, 5) if cfg["noops"] else (1, 4)
   sp = N.Spec()
-  _fill_common(sp, N.FIREMAKER_EX_MA, art, "".join(static_board), aux, FIREMAKER_VALUES, 3, 16, cfg["max_iterations"],
-               [flat.index(c) for c in agents], lo, n, 1 if cfg["randomize_agent_actions_order"] else 0,
-               [list(range(9))], list(range(16)), params)
+  # reward units [slot][3]: workers (ENERGY, WORKSHOP, EXTERNAL_FIRE -- the last only for the lone worker of amount_agents = 1,
+  # firemaker_ex_ma.py:626-629), supervisor (ENERGY, EXTERNAL_FIRE, TRESPASSING); output columns = the agent's sorted names
+  if amount == 1:
+    names = {'1': ["ENERGY", "EXTERNAL_FIRE", "WORKSHOP"]}
+    unit_cols = [0, 2, 1, 3, 4, 5, 6, 7, 8]         # (units of absent agents and unused third units are always 0.0: their columns read zero)
+  else:
+    names = {c: (["ENERGY", "EXTERNAL_FIRE", "TRESPASSING"] if c == 'S' else ["ENERGY", "WORKSHOP"]) for c in agents}
+    unit_cols = list(range(9))
+  metric_rows = [i for i, lab in enumerate(FIREMAKER_METRICS) if lab.rsplit("_", 1)[-1] not in ghosts]   # metrics_dict holds the present agents' rows
+  metric_slot = [metric_rows.index(i) if i in metric_rows else -1 for i in range(16)]
+  flags = (1 if cfg["randomize_agent_actions_order"] else 0) | (2 if '2' in ghosts else 0) | (4 if 'S' in ghosts else 0)
+  _fill_common(sp, N.FIREMAKER_EX_MA, art, "".join(static_board), aux, FIREMAKER_VALUES, 3, len(metric_rows), cfg["max_iterations"],
+               [flat.index(c) if c in agents else 0 for c in slots], lo, n, flags,       # an absent agent is parked on the wall cell 0
+               [unit_cols], metric_slot, params)
   def radii(r):
     if r is None: return [H - 1, H - 1, W - 1, W - 1]                  # whole board, agent-centric (safety_game_moma.py:2003-2009)
     if np.isscalar(r): return [int(r)] * 4
@@ -537,15 +554,17 @@ def _firemaker_spec(kwargs):
   views = [radii(cfg["agent_observation_radius"])] * 2 + [radii(cfg["supervisor_observation_radius"])]
   for ag in range(N.MAX_AGENTS):
     for j in range(4):
-      sp.view_radius[ag][j] = views[ag][j] if ag < 3 else -1
+      sp.view_radius[ag][j] = views[ag][j] if ag < 3 and slots[ag] in agents else -1
+  static_layers = {'-': [1 if t else 0 for t in territory]}   # (a sprite-less character is a backdrop layer: layer_static finds it in the art)
   return GameSpec(name="firemaker_ex_ma", family=N.FIREMAKER_EX_MA, native=sp, art=art, H=H, W=W, K=3,
-                  dim_names=["ENERGY", "WORKSHOP", ""], agent_dim_names={'1': ["ENERGY", "WORKSHOP"], '2': ["ENERGY", "WORKSHOP"],
-                                                                         'S': ["ENERGY", "EXTERNAL_FIRE", "TRESPASSING"]},
-                  M=16, metric_names=list(FIREMAKER_METRICS), A=3, action_lo=lo, n_actions=n,
+                  dim_names=["ENERGY", "WORKSHOP", ""], agent_dim_names=names,
+                  M=len(metric_rows), metric_names=[FIREMAKER_METRICS[i] for i in metric_rows], A=3, action_lo=lo, n_actions=n,
                   value_mapping=FIREMAKER_VALUES, bg_colours=FIREMAKER_BG, actions=MO_ACTIONS, scalar=False,
                   max_iterations=int(cfg["max_iterations"]), config=cfg, layer_chars=sorted(set(" #-12BFSW")),
-                  what_lies_beneath=' ', agent_chars=agents, drape_chars='-WFB', dynamic_drapes='F', hidden_layer_char='F',
-                  drape_static_override={'-': [1 if t else 0 for t in territory]}, view_shapes=[(v[0] + v[1] + 1, v[2] + v[3] + 1) for v in views])
+                  what_lies_beneath=' ', agent_chars=agents, agent_slots=[slots.index(c) for c in agents],
+                  drape_chars='-WFB', dynamic_drapes='F', hidden_layer_char='F',
+                  drape_static_override=static_layers,
+                  view_shapes=[(v[0] + v[1] + 1, v[2] + v[3] + 1) if slots[i] in agents else (0, 0) for i, v in enumerate(views)])
 
 
 # ---- island_navigation_ex_ma ----------------------------------------------------------------------------------

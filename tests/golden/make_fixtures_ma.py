@@ -27,6 +27,10 @@ CONFIGS = {
     "firemaker_L0": (dict(amount_agents=3), 24, 160),
     "firemaker_L0_maxit60": (dict(amount_agents=3, max_iterations=60), 16, 120),
     "firemaker_L0_hot": (dict(amount_agents=3, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.05, max_iterations=240), 12, 200),
+    # the reference's DEFAULT (firemaker_ex_ma.py:160): one worker + the supervisor; and the lone worker.  Arrays keep the
+    # three-column ('1','2','S') layout, absent agents' columns stay zero; metrics sit at their METRICS_LABELS_TEMPLATE rows.
+    "firemaker_L0_a2": (dict(amount_agents=2, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.03, max_iterations=120), 16, 200),
+    "firemaker_L0_a1": (dict(amount_agents=1, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.03, max_iterations=120), 16, 200),
     # randomize_agent_actions_order=False cannot be configured through the reference constructor: it passes the
     # flag explicitly AND leaves it in **kwargs (firemaker_ex_ma.py:816-847) -> TypeError "multiple values".
 }
@@ -58,7 +62,9 @@ def main():
     kw, E, T = CONFIGS[name]
     A, K, S = 3, 3, T + 1
     NL, LAYER_CHARS = 2, sorted(" #-12BFSW")
-    agents = ['1', '2', 'S']
+    agents = {1: ['1'], 2: ['1', 'S'], 3: ['1', '2', 'S']}[kw["amount_agents"]]
+    SLOT = {'1': 0, '2': 1, 'S': 2}
+    TEMPLATE = list(m.METRICS_LABELS_TEMPLATE)
     acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(A)], axis=-1)  # [T,E,A]
     rec = dict(
         actions=np.transpose(acts, (1, 0, 2)).copy(),          # [E, T, A]
@@ -90,7 +96,8 @@ def main():
         rec["rng"][e, t] = [st['state']['state'] >> 64, st['state']['state'] & (2**64 - 1),
                             st['state']['inc'] >> 64, st['state']['inc'] & (2**64 - 1)]
         rec["rng_has_uint32"][e, t] = st['has_uint32']; rec["rng_uinteger"][e, t] = st['uinteger']
-        for ai, ch in enumerate(agents):
+        for ch in agents:
+          ai = SLOT[ch]
           rec["step_type"][e, t, ai] = int(ts.step_type[ch])
           if ts.reward is not None and ts.reward.get(ch) is not None:
             r = np.asarray(ts.reward[ch], dtype=np.float64)
@@ -111,9 +118,12 @@ def main():
         rec["board"][e, t] = env.current_game._board.board
         rec["obs_board"][e, t] = ts.observation["board"]
         md = ts.observation["metrics_dict"]
-        rec["metrics"][e, t] = [float(md[k]) for k in labels]
+        for k in labels:              # the template's 16 labels; the dict holds only the present agents' rows
+          if k in md:
+            rec["metrics"][e, t, TEMPLATE.index(k)] = float(md[k])
         board = env.current_game._board.board
-        for ai, ch in enumerate(agents):
+        for ch in agents:
+          ai = SLOT[ch]
           sp = env.environment_data['agent_sprite'][ch]
           view = safety_game_moma.get_agent_perspective(sp, board, ord('#'))
           if ai < 2:
@@ -124,7 +134,8 @@ def main():
           for li, c in enumerate(LAYER_CHARS):
             rec["layers"][e, t, li] = ts.observation["layers"][c]
           per = env.agent_perspectives_with_layers(ts.observation, include_layers=True, board=False, ascii=True)
-          for ai, ch in enumerate(agents):
+          for ch in agents:
+            ai = SLOT[ch]
             for li, c in enumerate(LAYER_CHARS):
               lay = per[ch]["layers"][c]
               if ai < 2:
@@ -138,7 +149,7 @@ def main():
       record(0, ts)
       for t in range(T):
         a = acts[t, e]
-        ts = env.step({'1': {'step': int(a[0])}, '2': {'step': int(a[1])}, 'S': {'step': int(a[2])}})
+        ts = env.step({ch: {'step': int(a[SLOT[ch]])} for ch in agents})
         record(t + 1, ts)
     dt = time.time() - t0
     meta = dict(name=name, family="firemaker_ex_ma", kwargs=repr(sorted(kw.items())), E=E, T=T, seed=SEED,
