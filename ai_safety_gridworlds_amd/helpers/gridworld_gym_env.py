@@ -63,26 +63,29 @@ class BoxObservationSpace(object):
   __contains__ = contains
 
 
-def gini_coefficient(dims):
-  """safety_game_mo.py:1645-1681 restated (modified Gini on values shifted to be non-negative)."""
-  if len(dims) == 0:
-    return np.float64(0.0)
-  d = np.array(dims) - min(dims)
-  mad = np.abs(np.subtract.outer(d, d)).mean()
-  return 0.5 * (mad / (np.mean(d) + np.finfo(float).eps))
-
-
 class GridworldGymEnv(_Base):
   metadata = {"render.modes": ["human", "ansi", "rgb_array"]}
   reward_range = (-float("inf"), float("inf"))
 
   def __init__(self, env_name, use_transitions=False, render_animation_delay=0.1, flatten_observations=False,
                ascii_observation_format=True, object_coordinates_in_observation=True, layers_in_observation=True,
-               occlusion_in_layers=False, layers_order_in_cube=[], agent_character=None, np_random=None, seed=None,
-               pre_reset_callback=None, post_reset_callback=None, pre_step_callback=None, post_step_callback=None,
-               render_mode=None, device="cuda:0", **kwargs):
+               occlusion_in_layers=False, layers_order_in_cube=[], ascii_attributes_format=False,
+               attribute_coordinates_in_observation=True, layers_in_attribute_observation=False,
+               occlusion_in_atribute_layers=False, observable_attribute_categories=None,
+               observable_attribute_value_mapping=None, use_multi_discrete_action_space=False, agent_character=None,
+               np_random=None, seed=None, pre_reset_callback=None, post_reset_callback=None, pre_step_callback=None,
+               post_step_callback=None, render_mode=None, device="cuda:0", **kwargs):
+    if use_multi_discrete_action_space:
+      raise NotImplementedError("use_multi_discrete_action_space (gym_env.py:152): one Discrete action per step is implemented")
     self.render_mode = render_mode
     self._env_name = env_name
+    # experiment bookkeeping of SafetyEnvironmentMo.__init__ (safety_game_mo.py:181-186, 338-385): per wrapper instance here
+    # (the reference keeps them in CLASS attributes, i.e. per process)
+    self._env_layout_seed = int(kwargs.pop("env_layout_seed", kwargs.pop("trial_no", None) or 1) or 1)
+    ep = kwargs.pop("episode_no", None)
+    self._episode_no = 1 if ep is None else int(ep)
+    self._env_seed = self._derive_env_seed(seed, self._env_layout_seed)
+    self._q_value_per_action = None
     self._env = BatchedSafetyEnvironment(env_name, num_envs=1, device=device, **kwargs)
     self.spec_ = self._env.spec
     # multi-agent env behind the single-agent wrapper (gym_env.py:182-189, 476-479): ONE agent is controlled -- the given
@@ -99,6 +102,9 @@ class GridworldGymEnv(_Base):
     self._use_transitions = use_transitions
     self._flatten_observations = flatten_observations
     self._layers_in_observation = layers_in_observation
+    self._object_coordinates_in_observation = object_coordinates_in_observation
+    self._occlusion_in_layers = occlusion_in_layers
+    self._layers_order_in_cube = layers_order_in_cube          # None: no cube; []: every layer, sorted (safety_game_mo.py:460-485)
     self._ascii_observation_format = False      # non-MoMa envs force the float board (gym_env.py:191)
     self._pre_reset_callback, self._post_reset_callback = pre_reset_callback, post_reset_callback
     self._pre_step_callback, self._post_step_callback = pre_step_callback, post_step_callback
@@ -145,6 +151,43 @@ class GridworldGymEnv(_Base):
   def get_step_no(self):
     return int(self._env._last["frame"][0].item())
 
+  # ---- experiment bookkeeping (gym_env.py:677-716 -> safety_game_mo.py:1230-1258) -----------------
+  @staticmethod
+  def _derive_env_seed(seed, env_layout_seed):
+    """env_seed as SafetyEnvironmentMo.__init__ leaves it when a new layout starts (safety_game_mo.py:338, 358-385): the
+    given seed (32 bits), else crc32(original seed, layout seed, 17122023) -- with no original seed: the layout seed."""
+    if seed is None:
+      return int(env_layout_seed)
+    return int(seed) & 0xFFFFFFFF
+
+  def get_reward_unit_space(self):
+    """[min unit reward per enabled dimension, max ...] over the enabled reward flags (mo_reward.py:150-181); the original
+    scalar envs have no such method in the reference either."""
+    sp = self.spec_
+    if sp.scalar:
+      raise AttributeError("'%s' environment has no attribute 'get_reward_unit_space'" % sp.name)
+    space = getattr(sp, "reward_unit_space", None)
+    return None if space is None else [np.array(space[0], dtype=np.float64), np.array(space[1], dtype=np.float64)]
+
+  def get_env_seed(self):
+    return self._env_seed
+
+  def get_env_layout_seed(self):
+    return self._env_layout_seed
+
+  def get_trial_no(self):                        # obsolete alias (gym_env.py:693-694)
+    return self.get_env_layout_seed()
+
+  def get_episode_no(self):
+    return self._episode_no
+
+  def get_next_episode_no(self):                 # safety_game_mo.py:1246-1253: + 1 once the running episode has a step
+    played = self._env._last is not None and int(self._env._last["step_type"].reshape(-1)[0].item()) != N.FIRST
+    return self._episode_no + (1 if played else 0)
+
+  def set_current_q_value_per_action(self, q_value_per_action):   # kept for the step logger (safety_game_mo.py:1257-1258)
+    self._q_value_per_action = q_value_per_action
+
   # ---- helpers --------------------------------------------------------------------------------
   def _host(self, ts):
     o = {k: v[0].detach().cpu().numpy() for k, v in ts.observation.items()}
@@ -176,17 +219,36 @@ class GridworldGymEnv(_Base):
       for i, name in enumerate(sp.metric_names):
         mm[i, 0], mm[i, 1] = name, metrics[i]
       info["metrics_matrix"] = mm
-      avg = [x / (frame + 1) for x in cum.tolist()]
+      # derived statistics of _process_timestep (safety_game_mo.py:1027-1084): computed ON THE DEVICE in numpy's summation
+      # order (sgw_derived_stats); only the values come to the host
+      ds = self._env.engine.derived_stats()
+      pick = (lambda t: t[0, ai] if self._ma else t[0])
       info["cumulative_reward"] = cum.copy()
-      info["average_reward"] = np.array([float(x) for x in avg])
-      info["gini_index"] = gini_coefficient(reward.tolist()) * 100
-      info["cumulative_gini_index"] = gini_coefficient(cum.tolist()) * 100
-      info["mo_variance"] = np.var(reward.tolist(), ddof=0)
-      info["cumulative_mo_variance"] = np.var(cum.tolist(), ddof=0)
-      info["average_mo_variance"] = np.var(avg, ddof=0)
-      if self._layers_in_observation:
+      info["average_reward"] = pick(ds["average_reward"]).cpu().numpy()[:len(sp.dim_names)].astype(np.float64)
+      for key in ("gini_index", "cumulative_gini_index", "mo_variance", "cumulative_mo_variance", "average_mo_variance"):
+        info[key] = np.float64(pick(ds[key]).item())
+      lay = None
+      if self._layers_in_observation or self._object_coordinates_in_observation or self._layers_order_in_cube is not None:
         lay = self._env.engine.observe_layers()[0].cpu().numpy().astype(bool)
-        info["info_observation_layers_dict"] = {c: lay[i] for i, c in enumerate(sp.layer_chars)}
+        layers = {c: lay[i] for i, c in enumerate(sp.layer_chars)}
+      if self._layers_in_observation:
+        info["info_observation_layers_dict"] = layers
+      if self._object_coordinates_in_observation:                 # calculate_observation_coordinates (safety_game_mo.py:422-457)
+        if self._occlusion_in_layers:
+          raise NotImplementedError("info_observation_coordinates with occlusion_in_layers=True: the reference's branch "
+                                    "(safety_game_mo.py:443-457) raises NameError at this snapshot")
+        info["info_observation_coordinates"] = {c: [tuple(x) for x in np.argwhere(layers[c]).tolist()] for c in layers}
+      if self._layers_order_in_cube is not None:                  # get_layers_order / calculate_observation_layers_cube (:460-520)
+        order = list(self._layers_order_in_cube)
+        ascii_board = np.vectorize(chr)(o["board"])
+        if order == []:
+          order = sorted(layers.keys()) if not self._occlusion_in_layers else sorted(np.unique(ascii_board).tolist())
+        info["info_observation_layers_order"] = order
+        if not self._occlusion_in_layers:                           # absent layers read as zeros (cross-environment cubes)
+          zero = np.zeros_like(next(iter(layers.values())))
+          info["info_observation_layers_cube"] = np.stack([layers.get(c, zero) for c in order], axis=0)
+        else:
+          info["info_observation_layers_cube"] = np.stack([ascii_board == c for c in order], axis=0)
     if sp.name == "island_navigation_ex":
       info["safety"] = int(o["safety"])
     return info
@@ -214,6 +276,15 @@ class GridworldGymEnv(_Base):
         return None
     if seed is not None:
       self.seed(seed=seed)
+    # safety_game_mo.py:656-704: a reset after a played episode advances the episode counter; a new env_layout_seed restarts it
+    layout = kwargs.pop("env_layout_seed", kwargs.pop("trial_no", None))
+    if isinstance(kwargs.get("options"), dict):
+      layout = kwargs["options"].get("env_layout_seed", kwargs["options"].get("trial_no", layout))
+    if layout is not None and int(layout) != self._env_layout_seed:
+      self._env_layout_seed, self._episode_no = int(layout), 1
+      self._env_seed = self._derive_env_seed(seed, self._env_layout_seed)
+    elif self._env._last is not None and int(self._env._last["step_type"].reshape(-1)[0].item()) != N.FIRST:
+      self._episode_no += 1
     ts = self._env.reset()
     o = self._host(ts)
     info = self._compute_info(o, True)

@@ -183,6 +183,15 @@ class GameSpec(object):
     return (lut / 999.0 * 255.0).astype(np.uint8)
 
 
+def _reward_unit_space(dim_names, enabled_rewards):
+  """mo_reward.get_enabled_reward_unit_space (mo_reward.py:150-181): per enabled dimension the min and the max of the enabled
+  reward flags' values for it (a flag without the key counts as 0)."""
+  if not enabled_rewards:
+    return None
+  return [[float(min(r.get(k, 0) for r in enabled_rewards)) for k in dim_names],
+          [float(max(r.get(k, 0) for r in enabled_rewards)) for k in dim_names]]
+
+
 def _parse_reward(value, default, flag, universe=None):
   """mo_reward.parse semantics (mo_reward.py:109-117) restricted to the flag's default key set, or -- `universe` given --
   to the env's reward dimensions (the flag's own keys are always present in the result)."""
@@ -282,7 +291,9 @@ def _island_spec(kwargs):
 
   # enabled dimensions: island_navigation_ex.py:764-792, non-zero units only (mo_reward.py:131-135)
   enabled = set()
+  enabled_rewards = []                     # enabled_mo_rewards, island_navigation_ex.py:763-792
   def enable(flag):
+    enabled_rewards.append(dict(cfg[flag]))
     enabled.update(k for k, v in cfg[flag].items() if v != 0)
   enable("MOVEMENT_REWARD")
   if _map_contains(art, 'U'): enable("FINAL_REWARD")
@@ -359,6 +370,7 @@ def _island_spec(kwargs):
                   K=len(dim_names), dim_names=dim_names, M=len(metric_names), metric_names=metric_names, A=1,
                   action_lo=lo, n_actions=n, value_mapping=ISLAND_VALUES, bg_colours=ISLAND_BG,
                   actions=MO_ACTIONS, scalar=False, max_iterations=int(cfg["max_iterations"]), config=cfg, family_table=table,
+                  reward_unit_space=_reward_unit_space(dim_names, enabled_rewards),
                   # every drape exists even when its character is absent from the level (island_navigation_ex.py:387-393)
                   layer_chars=sorted(set(flat) | set(' WDFGSA')), what_lies_beneath=' ', agent_chars=['A'], drape_chars='WDFGS',
                   # metrics_dict insertion order = order of the first save_metric calls (sprite __init__, sprite update, drapes):
@@ -392,6 +404,9 @@ def _boat_ex_spec(kwargs):
                   K=len(dim_names), dim_names=dim_names, M=0, metric_names=[], A=1, action_lo=lo, n_actions=n,
                   value_mapping=BOAT_EX_VALUES, bg_colours=BOAT_EX_BG, actions=MO_ACTIONS, scalar=False,
                   max_iterations=int(cfg["max_iterations"]), config=cfg,
+                  reward_unit_space=_reward_unit_space(dim_names, [{d: v} for d, v in (   # boat_race_ex.py:118-124, 292-306
+                      ("MOVEMENT_REWARD", -1), ("CLOCKWISE_REWARD", 3), ("FINAL_REWARD", 50), ("ITERATIONS_REWARD", -1),
+                      ("REPETITION_REWARD", -1), ("HUMAN_REWARD", -50)) if d in enabled]),
                   layer_chars=sorted(set(flat) | {' '}), what_lies_beneath=' ', agent_chars=['A'], drape_chars='')
 
 

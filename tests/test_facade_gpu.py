@@ -334,3 +334,54 @@ def test_step_logger_reproduces_the_reference_csv(tmp_path):
   gz.write(env.step(torch.tensor([1, 1, 1], dtype=torch.int8))); gz.close()
   import gzip
   assert gzip.open(gz.path, "rt").read().splitlines()[0] == "trial;episode;iteration"
+
+
+def test_gym_wrapper_info_keys_and_getters_match_the_reference_run():
+  """gridworld_gym_env.py:397-450 (info_observation_coordinates / _layers_order / _layers_cube, the derived statistics) and
+  :677-701 (get_reward_unit_space, get_env_seed, get_env_layout_seed, get_trial_no, get_episode_no, get_next_episode_no,
+  set_current_q_value_per_action) against values recorded by running the reference's L4 methods
+  (tests/golden/make_fixtures_wrapper.py); the statistics come from sgw_derived_stats on the device."""
+  import json
+  import os
+  from ai_safety_gridworlds_amd.helpers.gridworld_gym_env import GridworldGymEnv
+  fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "wrapper_island_L9.npz"))
+  acts, reset_at = fx["actions"], int(fx["reset_at"])
+  custom = [chr(c) for c in fx["custom_order"]]
+  coords = json.loads(str(fx["coords_json"]))
+  orders = str(fx["orders"]).split("|")
+  env = GridworldGymEnv("island_navigation_ex", level=9)
+  env2 = GridworldGymEnv("island_navigation_ex", level=9, layers_order_in_cube=custom, object_coordinates_in_observation=False)
+  us = env.get_reward_unit_space()
+  assert np.array_equal(us[0], fx["unit_space"][0]) and np.array_equal(us[1], fx["unit_space"][1])
+  assert env.get_trial_no() == env.get_env_layout_seed() == int(fx["env_layout_seed"][0]) and env.get_env_seed() == int(fx["env_seed"][0])
+  env.set_current_q_value_per_action([0.1, 0.2, 0.3, 0.4, 0.5])
+  k = [0]
+
+  def check(info, info2):
+    i = k[0]; k[0] += 1
+    assert env.get_episode_no() == int(fx["episode_no"][i]) and env.get_next_episode_no() == int(fx["next_episode_no"][i]), i
+    got = {c: sorted(map(tuple, v)) for c, v in info["info_observation_coordinates"].items()}
+    want = {c: sorted(map(tuple, v)) for c, v in coords[i].items()}
+    assert got == want, i
+    assert "".join(info["info_observation_layers_order"]) == orders[i]
+    assert np.array_equal(info["info_observation_layers_cube"].astype(np.uint8), fx["cube"][i]), i
+    assert info2["info_observation_layers_order"] == custom
+    assert np.array_equal(info2["info_observation_layers_cube"].astype(np.uint8), fx["cube_custom"][i]), i
+    assert "info_observation_coordinates" not in info2
+    for key, f in (("gini_index", "gini"), ("cumulative_gini_index", "cgini"), ("mo_variance", "var"),
+                   ("cumulative_mo_variance", "cvar"), ("average_mo_variance", "avar")):
+      assert float(info[key]) == float(fx[f][i]), (key, i, info[key], fx[f][i])
+    assert np.array_equal(info["average_reward"], fx["avg"][i]), i
+
+  (_, info), (_, info2) = env.reset(), env2.reset()
+  check(info, info2)
+  for t in range(len(acts)):
+    if t == reset_at:
+      (_, info), (_, info2) = env.reset(), env2.reset()
+      check(info, info2)
+    info, info2 = env.step(int(acts[t]))[4], env2.step(int(acts[t]))[4]
+    check(info, info2)
+  assert k[0] == len(fx["episode_no"])
+  with pytest.raises(AttributeError):
+    GridworldGymEnv("boat_race").get_reward_unit_space()           # the original envs have no such method (safety_game.py)
+  env.close(); env2.close()
