@@ -43,6 +43,8 @@ class GridworldZooParallelEnv(_Base):
     self._use_transitions, self._flatten_observations = use_transitions, flatten_observations
     self._test_death, self._test_death_probability = test_death, test_death_probability
     chars = sp.agent_chars if self._ma else ['0']
+    # column of each agent in the library's per-agent arrays (firemaker_ex_ma keeps the ('1','2','S') layout whatever amount_agents is)
+    self._slots = list(getattr(sp, "agent_slots", range(len(chars))))
     self.possible_agents = ["agent_%s" % c for c in chars]
     self.agent_name_mapping = dict(zip(self.possible_agents, chars))
     self._np_random = np_random if np_random is not None else np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
@@ -57,7 +59,7 @@ class GridworldZooParallelEnv(_Base):
     vals = list(sp.value_mapping.values())
     self._observation_spaces = {}
     for i, a in enumerate(self.possible_agents):
-      h, w = sp.view_shapes[i] if self._ma else (sp.H, sp.W)
+      h, w = sp.view_shapes[self._slots[i]] if self._ma else (sp.H, sp.W)
       self._observation_spaces[a] = BoxObservationSpace((2 if use_transitions else 1, h, w), min(vals), max(vals))
 
   def _seed_env(self, seed):
@@ -113,7 +115,7 @@ class GridworldZooParallelEnv(_Base):
       views = [o["board"]]
     states = {}
     for i, a in enumerate(self.possible_agents):
-      b = self._format(views[i])
+      b = self._format(views[self._slots[i]] if self._ma else views[i])
       if self._use_transitions:
         prev = np.zeros_like(b) if first else self._last_agent_boards[a]
         st = np.stack([prev, b], axis=0)
@@ -139,9 +141,10 @@ class GridworldZooParallelEnv(_Base):
         info["extra_observations"]["termination_reason"] = int(o["term_reason"])
       if self._ma:
         names = sp.agent_dim_names[sp.agent_chars[i]]
-        info["reward_dict"] = dict(zip(names, o["reward"].reshape(sp.A, sp.K)[i, :len(names)].tolist()))
-        info["cumulative_reward_dict"] = dict(zip(names, o["cumulative"].reshape(sp.A, sp.K)[i, :len(names)].tolist()))
-        info["info_agent_position"] = tuple(int(x) for x in o["agent_pos"].reshape(sp.A, 2)[i])
+        q = self._slots[i]
+        info["reward_dict"] = dict(zip(names, o["reward"].reshape(sp.A, sp.K)[q, :len(names)].tolist()))
+        info["cumulative_reward_dict"] = dict(zip(names, o["cumulative"].reshape(sp.A, sp.K)[q, :len(names)].tolist()))
+        info["info_agent_position"] = tuple(int(x) for x in o["agent_pos"].reshape(sp.A, 2)[q])
       infos[a] = info
     return infos
 
@@ -156,15 +159,15 @@ class GridworldZooParallelEnv(_Base):
 
   def step(self, actions, *args, **kwargs):
     sp = self.spec_
-    acts = []
-    for a in self.possible_agents:
+    acts = [0] * sp.A                     # by column of the library's layout (absent agents / the unused second savanna column: 0)
+    for i, a in enumerate(self.possible_agents):
+      q = self._slots[i]
       if self._dones[a] and not all(self._dones.values()):
         if a in actions:
           raise ValueError("Agent %s is done" % self.agent_name_mapping[a])      # pycolab_interface_ma.py:218
-        acts.append(0)
         continue
       if a not in actions and getattr(sp, "per_agent", False):
-        acts.append(-1)                    # not in the submitted dict: the agent does not play this round (PM:173-246)
+        acts[q] = -1                       # not in the submitted dict: the agent does not play this round (PM:173-246)
         continue
       v = actions.get(a, 0)
       if isinstance(v, dict):
@@ -172,8 +175,7 @@ class GridworldZooParallelEnv(_Base):
           raise RuntimeError("A pycolab EnvironmentMa adapter's step method was called with actions that were "
                              "not compatible with what the pycolab game expects.")
         v = v["step"]
-      acts.append(int(np.asarray(v).item()))
-    acts += [0] * (sp.A - len(acts))      # aintelope_savanna with one agent: the library's layout always holds two
+      acts[q] = int(np.asarray(v).item())
     ts = self._env.step(torch.tensor(acts, dtype=torch.int8))
     first = int(ts.step_type.reshape(-1)[0].item()) == N.FIRST
     o, states = self._observe(ts, first)
@@ -184,10 +186,10 @@ class GridworldZooParallelEnv(_Base):
       first = bool((st_all == N.FIRST).all())
     rewards, dones = {}, {}
     for i, a in enumerate(self.possible_agents):
-      done = int(st_all[i if per_agent else 0]) in (N.LAST, N.DEAD)
+      done = int(st_all[self._slots[i] if per_agent else 0]) in (N.LAST, N.DEAD)
       if self._ma:
         k = len(sp.agent_dim_names[sp.agent_chars[i]])
-        r = 0.0 if first else o["reward"].reshape(sp.A, sp.K)[i, :k].astype(np.float64).copy()
+        r = 0.0 if first else o["reward"].reshape(sp.A, sp.K)[self._slots[i], :k].astype(np.float64).copy()
       elif sp.scalar:
         r = 0.0 if first else float(o["reward"].reshape(-1)[0])
       else:
