@@ -232,8 +232,12 @@ struct Firemaker {
   // waves and the results are exchanged through LDS with one barrier per update.
   static constexpr int WAVES = 8;
   static constexpr bool COOPERATIVE = true;
-  static constexpr int X_JUMP = 0, X_DRAWS = 2112, X_EXCH = X_DRAWS + WAVES * 128 * 8, X_TICKET = X_EXCH + 2 * 7 * 64 * 8, LDS_EXTRA = X_TICKET + 16;
-  struct Ctx { const uint64_t* jump; double* draws; uint64_t* exch; uint32_t* ticket; int wave, lane, parity; uint32_t base; };
+  // per-wave scratch of the cooperative phase: the spreading env's old-fire words (one zero word in front, two behind) | its
+  // candidate cells compacted, ascending (u16 [320]) | its new fire mask (u32 [10], + pad)
+  static constexpr int SCR_FIRE = 0, SCR_LIST = 64, SCR_NEW = 64 + 640, SCR_BYTES = 768;
+  static constexpr int X_JUMP = 0, X_DRAWS = 2112, X_EXCH = X_DRAWS + WAVES * 128 * 8, X_TICKET = X_EXCH + 2 * 7 * 64 * 8,
+                       X_SCR = X_TICKET + 16, LDS_EXTRA = X_SCR + WAVES * SCR_BYTES;
+  struct Ctx { const uint64_t* jump; double* draws; uint64_t* exch; uint32_t* ticket; uint8_t* scr; int wave, lane, parity; uint32_t base; };
   static __device__ void init_ctx(Ctx& cx, const Lds& l) {
     cx.lane = threadIdx.x & 63;
     cx.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -244,6 +248,7 @@ struct Firemaker {
     cx.exch = reinterpret_cast<uint64_t*>(l.extra + X_EXCH);
     cx.parity = 0;
     cx.ticket = reinterpret_cast<uint32_t*>(l.extra + X_TICKET);
+    cx.scr = l.extra + X_SCR + cx.wave * SCR_BYTES;
     if (threadIdx.x == 0) *cx.ticket = 0u;
     cx.base = 0u;
   }
@@ -277,41 +282,6 @@ struct Firemaker {
     asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"((uint32_t)(b >> 32)), "v"((uint32_t)(a >> 32)), "s"(m));
     return __longlong_as_double((long long)((uint64_t)lo | ((uint64_t)hi << 32)));
   }
-  // bits [64*wi + off, 64*wi + off + 64) of a 320-bit scalar mask (zero outside): "is cell t+off set" for the pass's 64 cells
-  template <int WI, int OFF>
-  static __device__ uint64_t window(const uint64_t (&o)[5]) {
-    constexpr int pos = WI * 64 + OFF;
-    constexpr int q = pos >= 0 ? pos / 64 : -((-pos + 63) / 64);
-    constexpr int sh = pos - q * 64;
-    uint64_t v = 0;
-    if constexpr (q >= 0 && q <= 4) v = o[q] >> sh;
-    if constexpr (sh != 0 && q + 1 >= 0 && q + 1 <= 4) v |= o[q + 1] << (64 - sh);
-    return v;
-  }
-  // One source offset applied to all five passes at once: five INDEPENDENT dependency chains of straight-line code
-  // (no scalar branch around an empty mask: v_cndmask with m == 0 keeps cum), so the f64 pipeline always has work.
-  template <int DR, int DC>
-  static __device__ void spread_from(double (&cum)[5], const uint64_t (&o)[5], const uint64_t (&c)[5], const uint64_t (&vm)[9],
-                                     const double (&q)[9]) {
-    constexpr int adr = DR < 0 ? -DR : DR, adc = DC < 0 ? -DC : DC, k = adr * 3 + adc;
-    if constexpr (k != 0) {
-      constexpr int off = DR * W + DC;
-      const uint64_t m0 = window<0, off>(o) & c[0] & vm[k], m1 = window<1, off>(o) & c[1] & vm[k],
-                     m2 = window<2, off>(o) & c[2] & vm[k], m3 = window<3, off>(o) & c[3] & vm[k],
-                     m4 = window<4, off>(o) & c[4] & vm[k];
-      cum[0] = sel_mask(m0, 1.0 - (1.0 - cum[0]) * q[k], cum[0]);      // FM:601-609, sources in row-major order
-      cum[1] = sel_mask(m1, 1.0 - (1.0 - cum[1]) * q[k], cum[1]);
-      cum[2] = sel_mask(m2, 1.0 - (1.0 - cum[2]) * q[k], cum[2]);
-      cum[3] = sel_mask(m3, 1.0 - (1.0 - cum[3]) * q[k], cum[3]);
-      cum[4] = sel_mask(m4, 1.0 - (1.0 - cum[4]) * q[k], cum[4]);
-    }
-  }
-  template <int DR>
-  static __device__ void spread_row(double (&cum)[5], const uint64_t (&o)[5], const uint64_t (&c)[5], const uint64_t (&vm)[9],
-                                    const double (&q)[9]) {
-    spread_from<DR, -2>(cum, o, c, vm, q); spread_from<DR, -1>(cum, o, c, vm, q); spread_from<DR, 0>(cum, o, c, vm, q);
-    spread_from<DR, 1>(cum, o, c, vm, q); spread_from<DR, 2>(cum, o, c, vm, q);
-  }
   struct Ring { U128 xa, xb, a64, c64; int blk, consumed; };        // xa / xb: this lane's state in draw blocks blk / blk+1
   // make draws [consumed, consumed + 64) readable: block b lives in ring slot b & 1
   static __device__ void ring_ready(Ring& g, Ctx& cx) {
@@ -323,31 +293,86 @@ struct Firemaker {
     }
     lds_wave_sync();
   }
-  template <int WI>
-  static __device__ void draw_pass(double cum, uint64_t cw, uint64_t (&nf)[5], uint32_t valid, uint32_t ws, const Lds& l, Ring& g, Ctx& cx) {
-    if (cw == 0) return;
-    if (ws & 3u) {                                                     // then the virtual workshop sources, agent order
-      const int t = WI * 64 + cx.lane, tr = (t * 241) >> 12, tc = t - tr * W;
-      const bool is_cand = (cw >> cx.lane) & 1ull;
+  // ---- the env's CANDIDATE targets, compacted: one lane per candidate cell ---------------------------------------
+  // A burning env has ~100 candidate targets among its 289 cells, each with ~11 of the 24 possible sources.  One lane per
+  // BOARD cell (5 passes x 24 offsets) spends 120 masked f64 chain steps on them; one lane per CANDIDATE (usually 2 passes)
+  // spends 48.  Each lane gathers its own 5 x 5 neighbourhood of the old fire mask from LDS as 25 bits, then walks the 24
+  // offsets in the reference's row-major source order (FM:562-609): cum <- 1 - (1 - cum)(1 - p) where the bit is set.
+  // Offsets that wrap around a board row land on the wall column (never burning: the spec requires a walled border).
+  static __device__ uint32_t valid25(uint32_t valid) {                  // bit i = (dr + 2) * 5 + (dc + 2): is that distance inside the radius?
+    uint32_t m = 0;
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        if ((ws >> a) & 1u) {
-          const int wc = (int)((ws >> (8 + 9 * a)) & 0x1ffu), wr = (wc * 241) >> 12;
-          const int adr = abs(wr - tr), adc = abs(wc - wr * W - tc);
-          const bool near = is_cand && adr <= 2 && adc <= 2;
-          const int k = near ? adr * 3 + adc : 0;
-          if (near && ((valid >> k) & 1u)) cum = 1.0 - (1.0 - cum) * (1.0 - l.params[P_SPREAD0 + k]);
+    for (int i = 0; i < 25; ++i) {
+      const int dr = i / 5 - 2, dc = i % 5 - 2, k = (dr < 0 ? -dr : dr) * 3 + (dc < 0 ? -dc : dc);
+      if (i != 12) m |= ((valid >> k) & 1u) << i;
+    }
+    return m;
+  }
+  static __device__ void spread_compact(const uint64_t (&o)[5], const uint64_t (&c)[5], uint64_t (&nf)[5], uint32_t v25, uint32_t valid,
+                                        uint32_t ws, const double (&q)[9], const Lds& l, Ring& g, Ctx& cx) {
+    const int lane = cx.lane;
+    uint64_t* fw = reinterpret_cast<uint64_t*>(cx.scr + SCR_FIRE);
+    uint16_t* list = reinterpret_cast<uint16_t*>(cx.scr + SCR_LIST);
+    uint32_t* nfw = reinterpret_cast<uint32_t*>(cx.scr + SCR_NEW);
+    lds_wave_sync();                                                   // the previous env's reads of the scratch are done
+    fw[0] = 0ull; fw[1] = o[0]; fw[2] = o[1]; fw[3] = o[2]; fw[4] = o[3]; fw[5] = o[4]; fw[6] = 0ull; fw[7] = 0ull;   // uniform stores
+#pragma unroll
+    for (int j = 0; j < 5; ++j) reinterpret_cast<uint64_t*>(nfw)[j] = o[j];
+    int nc = 0;                                                        // scalar
+#pragma unroll
+    for (int wi = 0; wi < 5; ++wi) {
+      const uint64_t cw = c[wi];
+      const int rank = nc + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cw, 0u));
+      if ((cw >> lane) & 1ull) list[rank] = (uint16_t)(wi * 64 + lane);
+      nc += __builtin_popcountll(cw);
+    }
+    lds_wave_sync();
+    for (int p0 = 0; p0 < nc; p0 += 64) {                              // scalar loop: 64 candidates at a time, ascending cells
+      const bool act = p0 + lane < nc;
+      const int t = act ? (int)list[p0 + lane] : 0;
+      uint32_t nb = 0;                                                 // the 25 neighbourhood bits of the OLD fire mask
+#pragma unroll
+      for (int dr = -2; dr <= 2; ++dr) {
+        const int pos = t + dr * W - 2 + 64;                           // + 64: fw[] carries one zero word in front
+        const int w = pos >> 6, sh = pos & 63;
+        const uint64_t lo = fw[w], hi = fw[w + 1];
+        const uint64_t bits = (lo >> sh) | ((hi << 1) << (63 - sh));
+        nb |= ((uint32_t)bits & 31u) << (5 * (dr + 2));
+      }
+      nb = act ? (nb & v25) : 0u;
+      double cum = 0.0;
+#pragma unroll
+      for (int i = 0; i < 25; ++i) {
+        if (i == 12) continue;
+        const int dr = i / 5 - 2, dc = i % 5 - 2, k = (dr < 0 ? -dr : dr) * 3 + (dc < 0 ? -dc : dc);
+        const double nv = 1.0 - (1.0 - cum) * q[k];                    // FM:601-609
+        cum = ((nb >> i) & 1u) ? nv : cum;
+      }
+      if (ws & 3u) {                                                   // then the virtual workshop sources, agent order (FM:550-554)
+        const int tr = (t * 241) >> 12, tc = t - tr * W;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          if ((ws >> a) & 1u) {
+            const int wc = (int)((ws >> (8 + 9 * a)) & 0x1ffu), wr = (wc * 241) >> 12;
+            const int adr = abs(wr - tr), adc = abs(wc - wr * W - tc);
+            const bool near = act && adr <= 2 && adc <= 2;
+            const int k = near ? adr * 3 + adc : 0;
+            if (near && ((valid >> k) & 1u)) cum = 1.0 - (1.0 - cum) * (1.0 - l.params[P_SPREAD0 + k]);
+          }
         }
       }
+      const uint64_t need = __ballot(act && cum > 0.0);                // FM:612: one draw per target with p > 0, row-major
+      if (need) {
+        ring_ready(g, cx);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+        const double u = cx.draws[(g.consumed + rank) & 127];
+        if (act && cum > 0.0 && u < cum) atomicOr(&nfw[t >> 5], 1u << (t & 31));
+        g.consumed += __builtin_popcountll(need);
+      }
     }
-    const uint64_t need = __ballot(cum > 0.0);                        // FM:612: one draw per target with p > 0, row-major
-    if (need) {
-      ring_ready(g, cx);
-      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-      const double u = cx.draws[(g.consumed + rank) & 127];
-      nf[WI] |= __ballot(cum > 0.0 && u < cum);
-      g.consumed += __builtin_popcountll(need);
-    }
+    lds_wave_sync();
+#pragma unroll
+    for (int j = 0; j < 5; ++j) nf[j] = uniform_u64(reinterpret_cast<const uint64_t*>(nfw)[j]);
   }
   template <int WI>
   static __device__ void continue_pass(const uint64_t (&o)[5], uint64_t (&nf)[5], double cont, Ring& g, Ctx& cx) {
@@ -398,10 +423,10 @@ struct Firemaker {
     if (n_work) {
       const uint32_t valid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p[P_VALID]);
       const double cont = uniform_f64(p[P_CONTINUE]);
+      const uint32_t v25 = valid25(valid);
       double q[9];
-      uint64_t vm[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) { q[k] = uniform_f64(1.0 - p[P_SPREAD0 + k]); vm[k] = ((valid >> k) & 1u) ? ~0ull : 0ull; }
+      for (int k = 0; k < 9; ++k) q[k] = uniform_f64(1.0 - p[P_SPREAD0 + k]);
       const uint64_t* jt = cx.jump + (lane + 1) * 4;
       const U128 aj = {jt[0], jt[1]}, gj = {jt[2], jt[3]};
       Ring g;
@@ -425,12 +450,7 @@ struct Firemaker {
         g.blk = 0; g.consumed = 0;
         lds_wave_sync();
         cx.draws[lane] = pcg_double(g.xa); cx.draws[64 + lane] = pcg_double(g.xb);
-        double cum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        spread_row<-2>(cum, o, c, vm, q); spread_row<-1>(cum, o, c, vm, q); spread_row<0>(cum, o, c, vm, q);
-        spread_row<1>(cum, o, c, vm, q); spread_row<2>(cum, o, c, vm, q);
-        draw_pass<0>(cum[0], c[0], nf, valid, wse, l, g, cx); draw_pass<1>(cum[1], c[1], nf, valid, wse, l, g, cx);
-        draw_pass<2>(cum[2], c[2], nf, valid, wse, l, g, cx); draw_pass<3>(cum[3], c[3], nf, valid, wse, l, g, cx);
-        draw_pass<4>(cum[4], c[4], nf, valid, wse, l, g, cx);
+        spread_compact(o, c, nf, v25, valid, wse, q, l, g, cx);
         continue_pass<0>(o, nf, cont, g, cx); continue_pass<1>(o, nf, cont, g, cx); continue_pass<2>(o, nf, cont, g, cx);
         continue_pass<3>(o, nf, cont, g, cx); continue_pass<4>(o, nf, cont, g, cx);
         U128 fin = st;

@@ -52,6 +52,11 @@ CONFIGS = {
     "island_L9_nooversat": ("island_ex", dict(level=9, penalise_oversatiation=False), 64, 200, 0, 5),
     "island_L9_prop": ("island_ex", dict(level=9, use_satiation_proportional_reward=True), 64, 200, 0, 5),
     "island_L9_maxit20": ("island_ex", dict(level=9, max_iterations=20), 64, 120, 0, 5),
+    # action VALUES outside the env's action_spec (0..4): the reference's step() does not validate them
+    # (pycolab_interface_mo.py:157-196; array_spec.validate is only applied to observations), an unknown value is
+    # "no move, but update_reward(action)" (safety_game_mo_base.py:713-725).  Values 0..8 here (5-8 = the turn actions of
+    # action_direction_mode 2, inert in mode 0; 9 would be QUIT).
+    "island_L9_oob": ("island_ex", dict(level=9), 32, 120, 0, 9),
     # a "lazy" stream (mostly NOOP) exercises regrowth/pow and max_iterations
     "island_L9_lazy": ("island_ex", dict(level=9), 64, 300, 0, 5),
     "island_L6_lazy": ("island_ex", dict(level=6), 64, 300, 0, 5),
