@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/sgw.h"
 #include "sgw_boat.hpp"
@@ -64,7 +65,17 @@ struct sgw_engine {
   int rng_set;
   double* ftable_dev;      // sgw_set_family_table
   long long ftable_n;
+  // sgw_step_n: the T launches of one (actions, T, outputs) call, captured once and replayed as a hipGraph (see step_n_graph)
+  struct StepGraph { const int8_t* actions; int T, write_every, accumulate, has_out; long long last_use; sgw_out out; hipGraphExec_t exec; };
+  long long graph_tick;
+  std::vector<StepGraph> graphs;
+  hipStream_t capture_stream;
 };
+
+static void drop_graphs(sgw_engine* e) {      // any setter that changes what a launch's arguments hold invalidates the captures
+  for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  e->graphs.clear();
+}
 
 // island_navigation_ex: the packed (i16) state when the spec proves it exact (sgw_island.hpp); SGW_ISLAND_PLAIN_STATE in the
 // environment forces the plain f64 state (tests run every fixture through both).
@@ -164,7 +175,7 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   e->n_envs = n_envs;
   e->n_pad = (n_envs + SGW_ENV_ALIGN - 1) / SGW_ENV_ALIGN * SGW_ENV_ALIGN;
   e->env_id_base = env_id_base;
-  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0; e->rand_stream = nullptr; e->rand_n = 0; e->rand_seed = 0; e->acc_dev = nullptr; e->rng_set = 0; e->ftable_dev = nullptr; e->ftable_n = 0;
+  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0; e->rand_stream = nullptr; e->rand_n = 0; e->rand_seed = 0; e->acc_dev = nullptr; e->rng_set = 0; e->ftable_dev = nullptr; e->ftable_n = 0; e->capture_stream = nullptr; e->graph_tick = 0;
 
   KSpec& k = e->ks;
   memset(&k, 0, sizeof(k));
@@ -214,6 +225,8 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
 
 int sgw_destroy(sgw_engine* e) {
   if (!e) return SGW_OK;
+  drop_graphs(e);
+  if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
   if (e->tables_dev) (void)hipFree(e->tables_dev);
   if (e->state_dev) (void)hipFree(e->state_dev);
   if (e->acc_dev) (void)hipFree(e->acc_dev);
@@ -231,6 +244,7 @@ int sgw_set_episode_bits(sgw_engine* e, const uint8_t* bits_dev, int n_per_env, 
   if (!e) return fail(SGW_ERR_ARG, "sgw_set_episode_bits: null engine");
   if (bits_dev && n_per_env <= 0) return fail(SGW_ERR_ARG, "sgw_set_episode_bits: n_per_env must be positive");
   e->ep_bits = bits_dev; e->ep_bits_n = bits_dev ? n_per_env : 0; e->ep_seed = seed;
+  drop_graphs(e);
   return SGW_OK;
 }
 
@@ -238,6 +252,7 @@ int sgw_set_random_stream(sgw_engine* e, const double* u_dev, int n_per_env, uin
   if (!e) return fail(SGW_ERR_ARG, "sgw_set_random_stream: null engine");
   if (u_dev && n_per_env <= 0) return fail(SGW_ERR_ARG, "sgw_set_random_stream: n_per_env must be positive");
   e->rand_stream = u_dev; e->rand_n = u_dev ? n_per_env : 0; e->rand_seed = seed;
+  drop_graphs(e);
   return SGW_OK;
 }
 
@@ -265,6 +280,7 @@ int sgw_set_family_table(sgw_engine* e, const double* table_host, int64_t n) {
   if (island_general && n != 15 * 12 + 15)
     return fail(SGW_ERR_ARG, "sgw_set_family_table: island_navigation_ex per-event reward vectors are 15 x 12 values + 15 masks");
   HIP_TRY(hipSetDevice(e->device));
+  drop_graphs(e);
   if (e->ftable_dev) { (void)hipFree(e->ftable_dev); e->ftable_dev = nullptr; e->ftable_n = 0; }
   HIP_TRY(hipMalloc((void**)&e->ftable_dev, (size_t)n * 8));
   HIP_TRY(hipMemcpy(e->ftable_dev, table_host, (size_t)n * 8, hipMemcpyHostToDevice));
@@ -398,19 +414,73 @@ static void offset_out(sgw_out& o, const sgw_spec& sp, long long n_pad, long lon
   if (o.agent_flags) o.agent_flags += r * A;
 }
 
-int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out,
-               int accumulate, void* stream) {
-  if (!e) return fail(SGW_ERR_ARG, "sgw_step_n: null engine");
-  if (!actions_dev || T < 1) return fail(SGW_ERR_ARG, "sgw_step_n: bad argument");
-  if (accumulate) { int rc = ensure_acc(e, (hipStream_t)stream); if (rc) return rc; }
+static int step_n_launches(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out,
+                           int accumulate, hipStream_t st) {
   for (int t = 0; t < T; ++t) {
     KArgs a; memset(&a, 0, sizeof(a));
     a.mode = MODE_STEP; a.T = 1; a.ep_acc = accumulate ? e->acc_dev : nullptr;
     a.actions = actions_dev + (long long)t * e->n_envs * e->spec.A;
     if (out) { a.out = *out; if (write_every) offset_out(a.out, e->spec, e->n_pad, t); }
-    int rc = launch(e, a, (hipStream_t)stream);
+    int rc = launch(e, a, st);
     if (rc) return rc;
   }
+  return SGW_OK;
+}
+
+// One host launch costs ~5 us of CPU on this runtime -- as much as the smaller families' whole step kernel, and three times
+// that for a mixed suite issued from one thread.  A caller that steps from the same device buffers again (the usual loop:
+// one actions buffer refilled in place) gets its T launches captured into a hipGraph the second time the same arguments are
+// seen and replayed from then on.  SGW_STEP_GRAPHS=0 turns this off.
+static int step_graphs_min_T() {
+  static int v = -1;
+  if (v < 0) { const char* s = getenv("SGW_STEP_GRAPHS"); v = (s && atoi(s) == 0) ? (1 << 30) : 8; }
+  return v;
+}
+
+int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out,
+               int accumulate, void* stream) {
+  if (!e) return fail(SGW_ERR_ARG, "sgw_step_n: null engine");
+  if (!actions_dev || T < 1) return fail(SGW_ERR_ARG, "sgw_step_n: bad argument");
+  const hipStream_t st = (hipStream_t)stream;
+  if (accumulate) { int rc = ensure_acc(e, st); if (rc) return rc; }
+  if (T < step_graphs_min_T()) return step_n_launches(e, actions_dev, T, write_every, out, accumulate, st);
+  sgw_out key_out; memset(&key_out, 0, sizeof(key_out));
+  if (out) key_out = *out;
+  sgw_engine::StepGraph* hit = nullptr;
+  for (auto& g : e->graphs)
+    if (g.actions == actions_dev && g.T == T && g.write_every == (write_every != 0) && g.accumulate == (accumulate != 0) &&
+        g.has_out == (out != nullptr) && memcmp(&g.out, &key_out, sizeof(key_out)) == 0) { hit = &g; break; }
+  if (!hit) {                                   // first sighting: remember the arguments, launch directly
+    if (e->graphs.size() >= 256) {              // bounded: drop the least recently used capture
+      size_t worst = 0;
+      for (size_t i = 1; i < e->graphs.size(); ++i) if (e->graphs[i].last_use < e->graphs[worst].last_use) worst = i;
+      if (e->graphs[worst].exec) (void)hipGraphExecDestroy(e->graphs[worst].exec);
+      e->graphs.erase(e->graphs.begin() + worst);
+    }
+    sgw_engine::StepGraph g; memset(&g, 0, sizeof(g));
+    g.actions = actions_dev; g.T = T; g.write_every = write_every != 0; g.accumulate = accumulate != 0; g.has_out = out != nullptr;
+    g.out = key_out; g.exec = nullptr; g.last_use = ++e->graph_tick;
+    e->graphs.push_back(g);
+    return step_n_launches(e, actions_dev, T, write_every, out, accumulate, st);
+  }
+  hit->last_use = ++e->graph_tick;
+  if (!hit->exec) {                             // second sighting: capture (on the engine's own stream; nothing executes) and instantiate
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->capture_stream) HIP_TRY(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = step_n_launches(e, actions_dev, T, write_every, out, accumulate, e->capture_stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(e->capture_stream, &graph);
+    if (rc || ec != hipSuccess || !graph) {
+      if (graph) (void)hipGraphDestroy(graph);
+      if (rc) return rc;
+      return fail(SGW_ERR_HIP, "sgw_step_n: stream capture of the step launches failed");
+    }
+    const hipError_t ei = hipGraphInstantiate(&hit->exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { hit->exec = nullptr; return fail(SGW_ERR_HIP, "sgw_step_n: hipGraphInstantiate failed"); }
+  }
+  HIP_TRY(hipGraphLaunch(hit->exec, st));
   return SGW_OK;
 }
 

@@ -33,7 +33,8 @@ def test_spec_tables_match_reference_fixture(name):
   if meta["K"] > 1:
     assert spec.dim_names == meta["dim_names"]
   assert spec.metric_names == meta["metric_labels"]
-  assert (spec.action_lo, spec.n_actions) == (meta["action_lo"], meta["n_actions"])
+  if not name.endswith("_oob"):        # the _oob fixtures drive the env with action VALUES beyond its action_spec on purpose
+    assert (spec.action_lo, spec.n_actions) == (meta["action_lo"], meta["n_actions"])
   board = fx["board"]
   # value_mapping LUT (observation['board']) and RGB LUT reproduce the reference's distiller output
   vm = np.array([spec.native.value_map[i] for i in range(128)], np.float32)

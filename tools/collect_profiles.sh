@@ -23,5 +23,7 @@ for n in 131072 262144 1048576; do
   python3 $R/bench.py --envs $n --steps 500 --warmup 50 --no-cpu-baseline > $OUT/bench_island_n$n.json 2> $OUT/bench_island_n$n.err || exit 1
 done
 if [ -x $R/tools/diag/stamp_probe.bin ]; then $R/tools/diag/stamp_probe.bin 65536 > $OUT/phase_stamps.txt 2>&1; $R/tools/diag/stamp_probe.bin 1048576 >> $OUT/phase_stamps.txt 2>&1; fi
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_fm -- python3 $R/bench.py --workload firemaker_ex_ma --steps 60 --warmup 10 --no-cpu-baseline --no-fused > $OUT/pmc_fm.log 2>&1 || exit 1
+for wl in firemaker_ex_ma aintelope_savanna; do
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_$wl -- python3 $R/bench.py --workload $wl --steps 60 --warmup 10 --min-seconds 0 --no-cpu-baseline --no-fused > $OUT/pmc_$wl.log 2>&1 || exit 1
+done
 echo done

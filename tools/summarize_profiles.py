@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise gpurun_out/<tag>/ (tools/collect_profiles.sh) into profiles/: kernel stats CSV copy, PMC table,
-r01_traffic.json (HBM bytes per launch of the step kernel, corrected as MI355X_MICROARCH.md §HBM prescribes)."""
+r<NN>_traffic.json (HBM bytes per launch of the step kernel, corrected as MI355X_MICROARCH.md §HBM prescribes)."""
 import csv, glob, json, os, shutil, statistics, sys
 
 tag, rnd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r01")
@@ -34,6 +34,7 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
   out["hbm_bytes_per_launch"] = (2 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024
   out["hbm_bytes_per_launch_uncorrected"] = (pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024
   out["algorithmic_bytes_per_launch"] = 299 * 65536
+  out["layout"] = "80-byte packed i16 state, pairs of words per lane (16-byte accesses)"
 json.dump(out, open(os.path.join("profiles", "%s_%s_pmc.json" % (rnd, tag)), "w"), indent=1)
 if "hbm_bytes_per_launch" in out:
   json.dump({"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": "%s_%s_pmc.json" % (rnd, tag)},
@@ -42,16 +43,19 @@ for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
   shutil.copy(f, os.path.join("profiles", "%s_%s_%s" % (rnd, tag, os.path.basename(f))))
 if os.path.exists(os.path.join(src, "phase_stamps.txt")):
   shutil.copy(os.path.join(src, "phase_stamps.txt"), os.path.join("profiles", "%s_%s_phase_stamps.txt" % (rnd, tag)))
-fm = {}
-for f in glob.glob(os.path.join(src, "pmc_fm", "*", "*_counter_collection.csv")):
-  acc = {}
-  for r in csv.DictReader(open(f)):
-    if "Firemaker" in r["Kernel_Name"] and "Li0E" in r["Kernel_Name"]:
-      acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-  fm = {k: statistics.median(v[len(v) // 5:]) for k, v in acc.items()}
-if fm:
-  json.dump({"kernel": "sgw::k_engine<sgw::Firemaker, K_STEP> (16384 envs, 256 workgroups x 8 waves)", "pmc_median_per_launch": fm},
-            open(os.path.join("profiles", "%s_%s_pmc_firemaker.json" % (rnd, tag)), "w"), indent=1)
+for wl, kname in (("firemaker_ex_ma", "Firemaker"), ("aintelope_savanna", "Savanna")):
+  fm = {}
+  for f in glob.glob(os.path.join(src, "pmc_" + wl, "*", "*_counter_collection.csv")) + \
+           (glob.glob(os.path.join(src, "pmc_fm", "*", "*_counter_collection.csv")) if wl == "firemaker_ex_ma" else []):
+    acc = {}
+    for r in csv.DictReader(open(f)):
+      if kname in r["Kernel_Name"] and (", 0>(" in r["Kernel_Name"] or "Li0E" in r["Kernel_Name"]):
+        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    fm = {k: statistics.median(v[len(v) // 5:]) for k, v in acc.items()}
+  if fm:
+    body = {"kernel": "sgw::k_engine<sgw::%s, K_STEP> (bench.py --workload %s)" % (kname, wl), "tag": tag, "pmc_median_per_launch": fm}
+    json.dump(body, open(os.path.join("profiles", "%s_%s_pmc_%s.json" % (rnd, tag, wl)), "w"), indent=1)
+    json.dump(body, open(os.path.join("profiles", "%s_pmc_%s.json" % (rnd, wl)), "w"), indent=1)     # the copy bench.py reads
 if "hbm_bytes_per_launch" in out:      # the bench ran before this tag's PMC passes were summarised: carry their traffic figure
   line = json.loads(open(bench_dst).read().strip().splitlines()[-1])
   line["roofline"]["traffic"] = out["hbm_bytes_per_launch"]
