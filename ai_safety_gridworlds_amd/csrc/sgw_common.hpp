@@ -30,7 +30,7 @@ struct KSpec {
 
 // byte offsets of one env-wave staging buffer's regions, computed ONCE per launch on the host (lds_plan) and read from the
 // kernarg segment where needed: deriving them on the device cost a ~30-instruction scalar chain per region with spilled terms
-struct LdsPlan { int wave_bytes, vec_r, vec_c, vec_m, vec_a, trash, flag, st, tr, act, pos, flg, disc, hid, saf, frm; };
+struct LdsPlan { int wave_bytes, vec_r, vec_c, vec_m, vec_a, trash, flag, ain, st, tr, act, pos, flg, disc, hid, saf, frm; };
 
 struct KArgs {
   KSpec sp;
@@ -117,6 +117,7 @@ struct Lds {
   int32_t *saf, *frm;                // safety [64][PA], frame [64]
   double* vec_a;           // 64*(A*K+1) doubles: finished-episode returns staged for the per-wave sum
   uint32_t* flag;          // [4] per-step words handed from the computing wave to the draining wave (pipelined rollout)
+  int8_t* ain;             // [A][64] synthetic actions handed from the draining wave to the computing wave (pipelined rollout)
   double* trash;           // 64 doubles: where writes of not-enabled reward dimensions / absent metrics land (branch-free)
 };
 
@@ -160,7 +161,7 @@ __host__ __device__ inline size_t lds_small_bytes(int A, int pa, int need, int w
 __host__ __device__ inline size_t lds_wave_bytes(int HW, int A, int K, int M, int pa, int need) {
   const size_t rows = lds_rows(A, K, M, need, LN_REWARD) + lds_rows(A, K, M, need, LN_CUMULATIVE) +
                       lds_rows(A, K, M, need, LN_METRICS) + lds_rows(A, K, M, need, LN_RETURNS) + 1;   // + trash
-  size_t small = 16;                                                                                    // flag words
+  size_t small = 16 + (size_t)(64 * A + 15) / 16 * 16;                  // flag words + the synthetic-action inbox (pipelined rollout)
   for (int w = LN_ST; w <= LN_FRM; w <<= 1) small += lds_small_bytes(A, pa, need, w);
   return lds_board_bytes(HW) + rows * 64 * 8 + small;
 }
@@ -177,6 +178,7 @@ __host__ __device__ inline LdsPlan lds_plan(int HW, int A, int K, int M, int pa,
   p.vec_a = o; o += 512 * (int)lds_rows(A, K, M, need, LN_RETURNS);
   p.trash = o; o += 512;
   p.flag = o; o += 16;
+  p.ain = o; o += (64 * A + 15) / 16 * 16;
   p.st = o; o += (int)lds_small_bytes(A, pa, need, LN_ST);
   p.tr = o; o += (int)lds_small_bytes(A, pa, need, LN_TR);
   p.act = o; o += (int)lds_small_bytes(A, pa, need, LN_ACT);
@@ -206,6 +208,7 @@ __host__ __device__ inline Lds lds_carve(uint8_t* smem, const LdsPlan& p, int ex
   l.vec_a = reinterpret_cast<double*>(w + p.vec_a);
   l.trash = reinterpret_cast<double*>(w + p.trash);
   l.flag = reinterpret_cast<uint32_t*>(w + p.flag);
+  l.ain = reinterpret_cast<int8_t*>(w + p.ain);
   l.st = w + p.st; l.tr = w + p.tr; l.act = reinterpret_cast<int8_t*>(w + p.act); l.pos = w + p.pos; l.flg = w + p.flg;
   l.disc = reinterpret_cast<double*>(w + p.disc); l.hid = reinterpret_cast<double*>(w + p.hid);
   l.saf = reinterpret_cast<int32_t*>(w + p.saf); l.frm = reinterpret_cast<int32_t*>(w + p.frm);

@@ -337,6 +337,19 @@ __global__ __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* ho
   lds_tables_commit<NT>(ts, smem);
   F::init_ctx(cx, l);
   if constexpr (has_init_args<F>::value) F::init_args(cx, l, a);
+  // pipelined rollout with synthetic actions: the Philox stream (~100 instructions per agent and step) is the draining wave's
+  // work -- it writes step t + 2's actions into buffer t & 1's inbox while the computing wave plays step t + 1
+  if constexpr (PIPE) {
+    if (drainer && a.actions == nullptr) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const Lds lb = lds_carve(smem, a.lp, F::LDS_EXTRA, wv * NB + b);
+#pragma unroll
+        for (int ag = 0; ag < F::NA; ++ag)
+          lb.ain[ag * WAVE + lane] = (int8_t)synth_action(a.seed, env_id, a.step0 + b, ag, a.sp.action_lo, a.sp.n_actions);
+      }
+    }
+  }
   __syncthreads();
   const int TT = (KIND == K_STEP) ? 1 : a.T;
   if constexpr (PIPE) {
@@ -358,6 +371,12 @@ __global__ __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* ho
         if (a_step.write_every != 0 || t == TT - 1)
           emit_drain<F>(a_step, lb, env0, lane, a_step.write_every != 0 ? (long long)t * a_step.n_pad : 0, true, true);
         if ((a_step.need & LN_RETURNS) && lb.flag[0] != 0u) accumulate_returns(a_step, lb, wave_id, env0, lane);
+        if (a_step.actions == nullptr && t + 2 < TT) {      // the computing wave read this inbox before the barrier above
+#pragma unroll
+          for (int ag = 0; ag < F::NA; ++ag)
+            lb.ain[ag * WAVE + lane] = (int8_t)synth_action(a_step.seed, a_step.env_id_base + env, a_step.step0 + t + 2, ag,
+                                                            a_step.sp.action_lo, a_step.sp.n_actions);
+        }
       }
       return;
     }
@@ -417,6 +436,7 @@ __global__ __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* ho
         if constexpr (KIND == K_STEP) action[ag] = action0[ag];          // sgw_step / sgw_step_n: the caller's actions, always
         else if (a.actions) action[ag] = (t == 0) ? action0[ag]
                                                   : (real ? (int)a.actions[((long long)t * a.n_envs + env) * F::NA + ag] : 0);
+        else if constexpr (PIPE) action[ag] = (int)l.ain[ag * WAVE + lane];     // the draining wave's Philox (see the prologue)
         else action[ag] = synth_action(a.seed, env_id, a.step0 + t, ag, a.sp.action_lo, a.sp.n_actions);
       }
       bool idle = false;
