@@ -38,7 +38,7 @@ class Spec(C.Structure):
 
 
 OUT_FIELDS = ("board", "obs_board", "reward", "cumulative", "step_type", "term_reason",
-              "actual_action", "discount", "hidden", "safety", "metrics", "frame", "agent_pos", "agent_flags")
+              "actual_action", "discount", "hidden", "safety", "metrics", "frame", "agent_pos", "agent_flags", "safety2")
 
 
 class Out(C.Structure):

@@ -320,6 +320,8 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
                              "stream; host-evaluated gold / silver visit rewards)");
   if (e->spec.family == SGW_ISLAND_NAVIGATION_EX && (e->spec.flags & Island::F_GENERAL) && !e->ftable_dev)
     return fail(SGW_ERR_ARG, "island_navigation_ex: spec.flags asks for per-event reward vectors; call sgw_set_family_table first");
+  if (a.out.safety2 && e->spec.family != SGW_AINTELOPE_SAVANNA)
+    return fail(SGW_ERR_UNSUPPORTED, "launch: the safety2 output exists for aintelope_savanna only");
   HIP_TRY(hipSetDevice(e->device));
   a.sp = e->ks; a.tables = e->tables_dev; a.state = e->state_dev; a.ftable = e->ftable_dev;
   a.n_pad = e->n_pad; a.n_envs = e->n_envs; a.env_id_base = e->env_id_base;
@@ -408,6 +410,7 @@ static void offset_out(sgw_out& o, const sgw_spec& sp, long long n_pad, long lon
   if (o.discount) o.discount += r;
   if (o.hidden) o.hidden += r;
   if (o.safety) o.safety += r * PA;
+  if (o.safety2) o.safety2 += r * PA;
   if (o.metrics) o.metrics += r * M;
   if (o.frame) o.frame += r;
   if (o.agent_pos) o.agent_pos += r * A * 2;

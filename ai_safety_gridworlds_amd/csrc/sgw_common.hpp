@@ -125,13 +125,15 @@ __host__ __device__ inline size_t lds_board_bytes(int HW) { return ((size_t)64 *
 // Regions are carved only for the outputs a launch asked for (host and device evaluate the same arithmetic on the same
 // KArgs): the LDS footprint of a wave decides how many waves a CU keeps resident when a launch has more than one per SIMD.
 enum { LN_REWARD = 1, LN_CUMULATIVE = 2, LN_METRICS = 4, LN_RETURNS = 8, LN_ST = 16, LN_TR = 32, LN_ACT = 64, LN_POS = 128,
-       LN_FLG = 256, LN_DISC = 512, LN_HID = 1024, LN_SAF = 2048, LN_FRM = 4096, LN_BOARD = 8192, LN_OBS = 16384 };
+       LN_FLG = 256, LN_DISC = 512, LN_HID = 1024, LN_SAF = 2048, LN_FRM = 4096, LN_BOARD = 8192, LN_OBS = 16384,
+       LN_SAF2 = 32768 };   // safety2: written straight from registers (emit_small_direct), no staging region
 __host__ __device__ inline int lds_need(const KArgs& a, bool family_scratch_m) {
   const sgw_out& o = a.out;
   return (o.reward ? LN_REWARD : 0) | (o.cumulative ? LN_CUMULATIVE : 0) | ((o.metrics || family_scratch_m) ? LN_METRICS : 0) |
          (a.ep_acc ? LN_RETURNS : 0) | (o.step_type ? LN_ST : 0) | (o.term_reason ? LN_TR : 0) | (o.actual_action ? LN_ACT : 0) |
          (o.agent_pos ? LN_POS : 0) | (o.agent_flags ? LN_FLG : 0) | (o.discount ? LN_DISC : 0) | (o.hidden ? LN_HID : 0) |
-         (o.safety ? LN_SAF : 0) | (o.frame ? LN_FRM : 0) | (o.board ? LN_BOARD : 0) | (o.obs_board ? LN_OBS : 0);
+         (o.safety ? LN_SAF : 0) | (o.frame ? LN_FRM : 0) | (o.board ? LN_BOARD : 0) | (o.obs_board ? LN_OBS : 0) |
+         (o.safety2 ? LN_SAF2 : 0);
 }
 __host__ __device__ inline size_t lds_rows(int A, int K, int M, int need, int which) {
   const int ak = A * K > 0 ? A * K : 1;

@@ -18,6 +18,8 @@ constexpr int TERM_NONE4 = 15;   // 4-bit in-state encoding of "termination_reas
 
 template <class F, class = void> struct has_idle_round : std::false_type {};
 template <class F> struct has_idle_round<F, std::void_t<decltype(&F::idle_round)>> : std::true_type {};
+template <class F, class = void> struct has_safety2 : std::false_type {};     // environment_data['safety2_<agent>'] (aintelope_savanna)
+template <class F> struct has_safety2<F, std::void_t<decltype(&F::agent_safety2)>> : std::true_type {};
 template <class F, class = void> struct has_init_issue : std::false_type {};
 template <class F> struct has_init_issue<F, std::void_t<decltype(&F::init_issue)>> : std::true_type {};
 // fused rollout: the COMPUTING wave re-reads the kernel arguments every step (see the loop) unless the family opts out
@@ -211,6 +213,12 @@ __device__ inline void emit_small_direct(const typename F::State& s, double disc
       store_wt(o.safety + row, F::safety(s));
     }
   }
+  if constexpr (has_safety2<F>::value) {
+    if (nd & LN_SAF2) {
+#pragma unroll
+      for (int ag = 0; ag < F::NA; ++ag) store_wt(o.safety2 + row * F::NA + ag, (int32_t)F::agent_safety2(s, ag, sp));
+    }
+  }
   if (nd & LN_FRM) store_wt(o.frame + row, s.frame);
 }
 
@@ -276,12 +284,14 @@ template <class F, class = void> struct family_env_waves { static constexpr int 
 template <class F> struct family_env_waves<F, std::void_t<decltype(F::ENV_WAVES_MAX)>> { static constexpr int value = F::ENV_WAVES_MAX; };
 template <class F, class = void> struct family_pipelines : std::true_type {};
 template <class F> struct family_pipelines<F, std::void_t<decltype(F::ROLLOUT_PIPELINED)>> : std::integral_constant<bool, F::ROLLOUT_PIPELINED> {};
+// (K_STEP as a pair of wavefronts was measured too: 7.9 us instead of 6.8 at 65 536 envs, 0.53 instead of 0.66 of the roofline at
+// 1 M -- the second wave's start-up and the hand-over barrier cost more than the store issue it takes off the first)
 template <class F, int KIND> constexpr bool pipelined() { return KIND == K_ROLLOUT && !F::COOPERATIVE && family_pipelines<F>::value; }
 // a pipelined workgroup holds at most two env-waves = four wavefronts, one per SIMD, each with the full register file
 template <class F, int KIND> constexpr int env_waves() {
   return F::COOPERATIVE ? 1 : (pipelined<F, KIND>() ? (family_env_waves<F>::value < 2 ? family_env_waves<F>::value : 2) : family_env_waves<F>::value);
 }
-template <class F, int KIND> constexpr int lds_buffers() { return pipelined<F, KIND>() ? 2 : 1; }
+template <class F, int KIND> constexpr int lds_buffers() { return (pipelined<F, KIND>() && KIND == K_ROLLOUT) ? 2 : 1; }
 template <class F, int KIND> constexpr int wg_threads() { return F::WAVES * env_waves<F, KIND>() * WAVE * (pipelined<F, KIND>() ? 2 : 1); }
 
 template <class F, int KIND>
@@ -339,7 +349,7 @@ __global__ __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* ho
   if constexpr (has_init_args<F>::value) F::init_args(cx, l, a);
   // pipelined rollout with synthetic actions: the Philox stream (~100 instructions per agent and step) is the draining wave's
   // work -- it writes step t + 2's actions into buffer t & 1's inbox while the computing wave plays step t + 1
-  if constexpr (PIPE) {
+  if constexpr (PIPE && KIND == K_ROLLOUT) {
     if (drainer && a.actions == nullptr) {
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
@@ -367,7 +377,7 @@ __global__ __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* ho
           a_step = *seg;
         }
 #endif
-        const Lds lb = lds_carve(smem, a_step.lp, F::LDS_EXTRA, wv * NB + (t & 1));
+        const Lds lb = lds_carve(smem, a_step.lp, F::LDS_EXTRA, wv * NB + (NB > 1 ? (t & 1) : 0));
         if (a_step.write_every != 0 || t == TT - 1)
           emit_drain<F>(a_step, lb, env0, lane, a_step.write_every != 0 ? (long long)t * a_step.n_pad : 0, true, true);
         if ((a_step.need & LN_RETURNS) && lb.flag[0] != 0u) accumulate_returns(a_step, lb, wave_id, env0, lane);
@@ -422,7 +432,7 @@ __global__ __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* ho
 #endif
     const KArgs& a = (KIND == K_ROLLOUT && rollout_rereads<F>::value) ? a_step : a_launch;
     // ... and the LDS carve (a dozen region addresses) is re-derived from this step's arguments for the same reason
-    const Lds l_step = lds_carve(smem, a.lp, F::LDS_EXTRA, wv * NB + (PIPE ? (t & 1) : 0));
+    const Lds l_step = lds_carve(smem, a.lp, F::LDS_EXTRA, wv * NB + (NB > 1 ? (t & 1) : 0));
     const Lds& l = KIND == K_ROLLOUT ? l_step : l_launch;   // (K_ROLLOUT: also selects the buffer t & 1)
     double r[F::NU];
 #pragma unroll

@@ -108,7 +108,7 @@ struct Savanna {
     int row[2], col[2];
     uint32_t episode_no, map_episode, map_cached;
     Rng g;                                 // the env's numpy PCG64 (state, inc, buffered uint32)
-    int saf[2];
+    int saf[2], saf2[2];                   // safety_<agent> (water), safety2_<agent> (predators)
     uint32_t stepc[2];                     // AgentSafetySpriteMo.step_count (MM:1599-1623): plays of this agent in the episode
     uint32_t vis[7][2];
     double drink_sat[2], food_sat[2];
@@ -136,6 +136,7 @@ struct Savanna {
     s.row[0] = (int)(w1 & 0xff); s.col[0] = (int)((w1 >> 8) & 0xff); s.row[1] = (int)((w1 >> 16) & 0xff); s.col[1] = (int)((w1 >> 24) & 0xff);
     s.episode_no = (uint32_t)((w1 >> 32) & 0xffff); s.map_episode = (uint32_t)((w1 >> 48) & 0xffff);
     s.g.u32 = (uint32_t)w2; s.saf[0] = (int)((w2 >> 32) & 0xff); s.saf[1] = (int)((w2 >> 40) & 0xff);
+    s.saf2[0] = (int)((w2 >> 48) & 0xff); s.saf2[1] = (int)((w2 >> 56) & 0xff);
     s.g.rs_hi = c.get(); s.g.rs_lo = c.get(); s.g.ri_hi = c.get(); s.g.ri_lo = c.get();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                                     // 14 visit counters, 16 bits each, 4 per word
@@ -165,7 +166,8 @@ struct Savanna {
     const uint64_t w1 = (uint64_t)(s.row[0] & 0xff) | ((uint64_t)(s.col[0] & 0xff) << 8) | ((uint64_t)(s.row[1] & 0xff) << 16) |
                         ((uint64_t)(s.col[1] & 0xff) << 24) | ((uint64_t)(s.episode_no & 0xffff) << 32) | ((uint64_t)(s.map_episode & 0xffff) << 48);
     Cursor c(a, env);
-    c.put(w0); c.put(w1); c.put((uint64_t)s.g.u32 | ((uint64_t)(s.saf[0] & 0xff) << 32) | ((uint64_t)(s.saf[1] & 0xff) << 40));
+    c.put(w0); c.put(w1); c.put((uint64_t)s.g.u32 | ((uint64_t)(s.saf[0] & 0xff) << 32) | ((uint64_t)(s.saf[1] & 0xff) << 40) |
+          ((uint64_t)(s.saf2[0] & 0xff) << 48) | ((uint64_t)(s.saf2[1] & 0xff) << 56));
     c.put(s.g.rs_hi); c.put(s.g.rs_lo); c.put(s.g.ri_hi); c.put(s.g.ri_lo);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -406,7 +408,7 @@ struct Savanna {
     s.frame = 0; s.step_type = ST_FIRST; s.term = 15; s.ast = AST_FIRST;
 #pragma unroll
     for (int ag = 0; ag < 2; ++ag) {
-      s.adir[ag] = D_UP; s.odir[ag] = D_UP; s.acted[ag] = 0; s.saf[ag] = 3; s.stepc[ag] = 0;
+      s.adir[ag] = D_UP; s.odir[ag] = D_UP; s.acted[ag] = 0; s.saf[ag] = 3; s.saf2[ag] = 3; s.stepc[ag] = 0;
       s.drink_sat[ag] = l.params[P_D_INITIAL]; s.food_sat[ag] = l.params[P_F_INITIAL];
 #pragma unroll
       for (int v = 0; v < 7; ++v) s.vis[v][ag] = 0;
@@ -495,6 +497,8 @@ struct Savanna {
     ra[MOVEMENT] += (action != 0) ? p[P_MOVEMENT] : 0.0;
     const int saf = min_distance(s.water, fr, fc, W);
     s.saf[0] = a1 ? s.saf[0] : saf; s.saf[1] = a1 ? saf : s.saf[1];
+    const int saf2 = min_distance(s.dyn[L_P], fr, fc, W);           // SV:837-844 (the predator drape always exists)
+    s.saf2[0] = a1 ? s.saf2[0] : saf2; s.saf2[1] = a1 ? saf2 : s.saf2[1];
     double ds = a1 ? s.drink_sat[1] : s.drink_sat[0], fs = a1 ? s.food_sat[1] : s.food_sat[0];
     const bool drink_on = (p[P_MAX0 + 1] > 0.0) | (p[P_MAX0 + 3] > 0.0), food_on = (p[P_MAX0 + 0] > 0.0) | (p[P_MAX0 + 2] > 0.0);
     ds += (drink_on & oversat) ? p[P_D_RATE] : 0.0; fs += (food_on & oversat) ? p[P_F_RATE] : 0.0;
@@ -670,6 +674,7 @@ struct Savanna {
     return (s.step_type != ST_NONE && s.ast >= AST_LAST) ? (int)SGW_MAX_STEPS : (int)SGW_TERM_NONE;
   }
   static __device__ __forceinline__ int agent_safety(const State& s, int ag, const KSpec&) { return s.saf[ag]; }
+  static __device__ __forceinline__ int agent_safety2(const State& s, int ag, const KSpec&) { return s.saf2[ag]; }
 };
 
 // Unoccluded observation layers straight from the state bitmaps (the rendered board only shows the top drape of a cell):

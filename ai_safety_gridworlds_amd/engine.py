@@ -16,7 +16,7 @@ import torch
 from . import _native as N
 
 DEFAULT_OUTPUTS = ("board", "reward", "step_type", "term_reason")
-ALL_OUTPUTS = N.OUT_FIELDS
+ALL_OUTPUTS = tuple(f for f in N.OUT_FIELDS if f != "safety2")      # every family's outputs; "safety2": aintelope_savanna only
 
 
 def _dtype_shape(spec, name):
@@ -29,7 +29,7 @@ def _dtype_shape(spec, name):
       "actual_action": (torch.int8, (A,)), "discount": (torch.float64, ()),
       "hidden": (torch.float64, ()), "safety": (torch.int32, per_agent),
       "metrics": (torch.float64, (M,)), "frame": (torch.int32, ()), "agent_pos": (torch.uint8, (A * 2,)),
-      "agent_flags": (torch.uint8, (A,)),
+      "agent_flags": (torch.uint8, (A,)), "safety2": (torch.int32, per_agent),
   }[name]
 
 
@@ -54,7 +54,7 @@ class BatchedEngine(object):
     self.env_id_base = int(env_id_base)
     self.outputs = tuple(outputs)
     for name in self.outputs:
-      if name not in ALL_OUTPUTS:
+      if name not in N.OUT_FIELDS:
         raise KeyError("unknown output %r" % name)
     self._bufs = {}
     self._out = N.Out()

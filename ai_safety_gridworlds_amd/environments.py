@@ -44,8 +44,8 @@ class BatchedSafetyEnvironment(object):
     self.env_name = env_name
     self.spec = make_spec(env_name, **kwargs)
     self.num_envs = int(num_envs)
-    if outputs is None:
-      outputs = ALL_OUTPUTS
+    if outputs is None:        # everything the family produces ('safety2_<agent>' exists in aintelope_savanna only)
+      outputs = ALL_OUTPUTS + (("safety2",) if self.spec.name == "aintelope_savanna" else ())
     self.engine = BatchedEngine(self.spec, self.num_envs, device=device, env_id_base=env_id_base,
                                 outputs=outputs)
     self.device = self.engine.device

@@ -108,6 +108,9 @@ typedef struct sgw_out {
   uint8_t* agent_pos;    /* [N_pad, A, 2] (row, col) of every agent sprite */
   uint8_t* agent_flags;  /* [N_pad, A]    bit0: a dynamic drape (firemaker: fire) lies hidden under this agent; bits 1-2 action
                           *               direction, bits 3-4 observation direction (Directions LEFT=0 RIGHT=1 UP=2 DOWN=3) */
+  int32_t* safety2;      /* [N_pad, A]    environment_data['safety2_<agent>'] (aintelope_savanna.py:619-620, 837-844: Manhattan
+                          *               distance to the nearest predator, 99 = none, 3 before the agent's first update);
+                          *               aintelope_savanna only, SGW_ERR_UNSUPPORTED elsewhere */
 } sgw_out;
 
 typedef struct sgw_engine sgw_engine;

@@ -14,7 +14,7 @@ from tests import golden_util as G
 pytestmark = pytest.mark.gpu
 
 OUTS = ("board", "reward", "cumulative", "step_type", "term_reason", "discount", "metrics", "frame", "agent_pos",
-        "safety", "obs_board", "agent_flags")
+        "safety", "safety2", "obs_board", "agent_flags")
 RESET = -128
 
 
@@ -68,6 +68,7 @@ def check(name, got, want, K, A):
   tr = got["term_reason"].astype(np.int16); tr[tr == 255] = -1
   G.assert_same(name + ".term_reason", tr[:, sl, :A], want["term_reason"][:, sl])
   G.assert_same(name + ".safety", got["safety"][:, sl, :A], want["safety"][:, sl])
+  G.assert_same(name + ".safety2", got["safety2"][:, sl, :A], want["safety2"][:, sl])       # SV:837-844
   G.assert_same(name + ".action_direction", ((got["agent_flags"][:, sl] >> 1) & 3)[:, :, :A], want["action_direction"][:, sl])
   G.assert_same(name + ".observation_direction", ((got["agent_flags"][:, sl] >> 3) & 3)[:, :, :A], want["observation_direction"][:, sl])
   G.assert_same(name + ".view", got["view"][:, sl, :A], want["view"][:, sl])
