@@ -84,7 +84,8 @@ struct Savanna {
 
   enum { COOP, DRINK, DRINK_DEF, DRINK_OVER, FINAL, FOOD, FOOD_DEF, FOOD_OVER, GOLD, INJURY, MOVEMENT, SILVER, DEATH };
   enum { F_SUSTAIN = 1, F_OVERSAT = 4, F_PROP = 8, F_SHUFFLE = 16, F_ADIR = 32, F_ODIR = 64, F_TWO = 128, F_MRF_SHIFT = 8,
-         F_DRINK_METRIC_ONLY = 1024, F_FOOD_METRIC_ONLY = 2048 };
+         F_DRINK_METRIC_ONLY = 1024, F_FOOD_METRIC_ONLY = 2048,
+         F_ADIR_TURN = 4096, F_ODIR_TURN = 8192 };   // direction mode 2: the turning actions 5-8 (MA:608-634, 674-697, 733-758)
   enum P {
     P_MOVEMENT, P_DRINK_DEF, P_FOOD_DEF, P_DRINK, P_FOOD, P_SDRINK, P_SFOOD, P_NON_DRINK, P_NON_FOOD,
     P_GAP_FOOD, P_GAP_DRINK, P_GAP_GOLD, P_GAP_SILVER, P_DANGER, P_PREDATOR, P_PRED_PROB, P_COOP, P_SCOOP,
@@ -467,13 +468,17 @@ struct Savanna {
     s.frame += 1;
     // ---- AgentSprite.update
     const int cur_od = a1 ? s.odir[1] : s.odir[0], cur_ad = a1 ? s.adir[1] : s.adir[0];
-    const int new_od = (odir_rel && action != 0) ? (adir_rel ? rotate_dir(action, cur_od) : cur_od) : cur_od;
+    const bool adir_turn = (sp.flags & F_ADIR_TURN) != 0, odir_turn = (sp.flags & F_ODIR_TURN) != 0;
+    // a turning action uses mode 1's table of the move it is named after: 5 = left, 6 = right, 7 / 8 = backwards
+    const int turn = action == 5 ? 1 : (action == 6 ? 2 : (((action == 7) | (action == 8)) ? 4 : 3));
+    const int new_od = odir_turn ? rotate_dir(turn, cur_od)
+                                 : ((odir_rel && action != 0) ? (adir_rel ? rotate_dir(action, cur_od) : cur_od) : cur_od);
     int absolute = action;
-    if (adir_rel && action >= 1 && action <= 4) {
+    if ((adir_rel || adir_turn) && action >= 1 && action <= 4) {
       const int d = rotate_dir(action, cur_ad);
       absolute = d == D_LEFT ? 1 : (d == D_RIGHT ? 2 : (d == D_UP ? 3 : 4));
     }
-    const int new_ad = (adir_rel && action != 0) ? rotate_dir(action, cur_ad) : cur_ad;
+    const int new_ad = adir_turn ? rotate_dir(turn, cur_ad) : ((adir_rel && action != 0) ? rotate_dir(action, cur_ad) : cur_ad);
     const int dr = (absolute == 4) - (absolute == 3), dc = (absolute == 2) - (absolute == 1);
     const int cr = a1 ? s.row[1] : s.row[0], cc = a1 ? s.col[1] : s.col[0];
     const int orow = a1 ? s.row[0] : s.row[1], ocol = a1 ? s.col[0] : s.col[1];

@@ -183,6 +183,18 @@ class GameSpec(object):
     return (lut / 999.0 * 255.0).astype(np.uint8)
 
 
+def _check_direction_modes(env, cfg):
+  """Direction modes (safety_game_ma.py:515-761): 0 fixed, 1 relative to the last move, 2 separate turning actions.  The
+  reference only survives a turning action with action_direction_mode 2 and observation_direction_mode 0 or 2: mode 1 of either
+  asserts the action is a move (MA:652, 723), observation mode 2 with action mode 0 raises (MA:670)."""
+  adm, odm = cfg["action_direction_mode"], cfg["observation_direction_mode"]
+  if adm not in (0, 1, 2) or odm not in (0, 1, 2):
+    raise ValueError("%s: direction modes are 0, 1 or 2" % env)
+  if (adm == 2 or odm == 2) and not (adm == 2 and odm in (0, 2)):
+    raise NotImplementedError("%s: turning actions need action_direction_mode=2 with observation_direction_mode 0 or 2 "
+                              "(every other combination raises in the reference on the first turning action)" % env)
+
+
 def _reward_unit_space(dim_names, enabled_rewards):
   """mo_reward.get_enabled_reward_unit_space (mo_reward.py:150-181): per enabled dimension the min and the max of the enabled
   reward flags' values for it (a flag without the key counts as 0)."""
@@ -628,8 +640,7 @@ def _island_ma_spec(kwargs):
   if int(cfg["amount_agents"]) != 2:
     raise NotImplementedError("island_navigation_ex_ma: the batched engine implements amount_agents=2 (the reference's AGENT_CHRS)")
   _check_regrowth_exponent("DRINK_REGROWTH_EXPONENT", cfg["DRINK_REGROWTH_EXPONENT"])
-  if cfg["action_direction_mode"] not in (0, 1) or cfg["observation_direction_mode"] not in (0, 1):
-    raise NotImplementedError("island_navigation_ex_ma: direction mode 2 (separate turning actions) is not implemented")
+  _check_direction_modes("island_navigation_ex_ma", cfg)
   if cfg["map_width"] is not None or cfg["map_height"] is not None:
     raise NotImplementedError("island_navigation_ex_ma: map resizing is not implemented")
   if cfg["remove_unused_tile_types_from_layers"]:
@@ -701,8 +712,11 @@ def _island_ma_spec(kwargs):
   params += [struct.unpack("<d", struct.pack("<Q", w))[0] for w in words]
   flags = ((1 if cfg["sustainability_challenge"] else 0) | (2 if death else 0) | (4 if oversat else 0) |
            (8 if cfg["use_satiation_proportional_reward"] else 0) | (16 if cfg["randomize_agent_actions_order"] else 0) |
-           (32 if cfg["action_direction_mode"] == 1 else 0) | (64 if cfg["observation_direction_mode"] == 1 else 0) | (mrf << 8))
+           (32 if cfg["action_direction_mode"] == 1 else 0) | (64 if cfg["observation_direction_mode"] == 1 else 0) | (mrf << 8) |
+           (4096 if cfg["action_direction_mode"] == 2 else 0) | (8192 if cfg["observation_direction_mode"] == 2 else 0))
   lo, n = (0, 5) if cfg["noops"] else (1, 4)
+  if cfg["action_direction_mode"] == 2:                # the action set gains TURN_LEFT_90 .. TURN_RIGHT_180 = 5..8 (IM:944-945)
+    n = 9 - lo
   sp = N.Spec()
   _fill_common(sp, N.ISLAND_NAVIGATION_EX_MA, art, static_board, [0] * len(flat), ISLAND_MA_VALUES, K, len(metric_names),
                cfg["max_iterations"], [flat.index('1'), flat.index('2')], lo, n, flags, slots, metric_slots, params)
@@ -803,8 +817,7 @@ def _savanna_spec(kwargs):
   if cfg["thirst_hunger_death"]:
     raise NotImplementedError("aintelope_savanna: thirst_hunger_death raises NameError in the reference "
                               "(safety_game_moma.py:1636 refers to safety_game_ma, which is never imported)")
-  if cfg["action_direction_mode"] not in (0, 1) or cfg["observation_direction_mode"] not in (0, 1):
-    raise NotImplementedError("aintelope_savanna: direction mode 2 (separate turning actions) is not implemented")
+  _check_direction_modes("aintelope_savanna", cfg)
   if cfg["remove_unused_tile_types_from_layers"]:
     raise NotImplementedError("aintelope_savanna: remove_unused_tile_types_from_layers is not implemented")
   mrf = int(cfg["map_randomization_frequency"])
@@ -970,10 +983,13 @@ def _savanna_spec(kwargs):
            (16 if cfg["randomize_agent_actions_order"] else 0) | (32 if cfg["action_direction_mode"] == 1 else 0) |
            (64 if cfg["observation_direction_mode"] == 1 else 0) | (128 if A == 2 else 0) | (mrf << 8) |
            (1024 if cfg["use_drink_availability_metric_instead_of_spawning_tiles"] else 0) |
-           (2048 if cfg["use_food_availability_metric_instead_of_spawning_tiles"] else 0))
+           (2048 if cfg["use_food_availability_metric_instead_of_spawning_tiles"] else 0) |
+           (4096 if cfg["action_direction_mode"] == 2 else 0) | (8192 if cfg["observation_direction_mode"] == 2 else 0))
   lo, n = (0, 5) if cfg["noops"] else (1, 4)
   if level in (2, 3, 4):                              # :1625-1632: LEFT only / LEFT and RIGHT
     lo, n = (0 if cfg["noops"] else 1), (2 if level == 2 else 3) if cfg["noops"] else (1 if level == 2 else 2)
+  if cfg["action_direction_mode"] == 2:                # the action set gains TURN_LEFT_90 .. TURN_RIGHT_180 = 5..8 (SV:1646-1647)
+    n = 9 - lo
   values = dict(SAVANNA_VALUES)
   for ag in range(A):
     values["01"[ag]] = float(len(SAVANNA_VALUES) + ag)

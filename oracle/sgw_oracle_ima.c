@@ -225,6 +225,14 @@ static int rotate_dir(int action, int cur) {                       /* MA:566-606
   return cur;
 }
 static int dir_to_action(int d) { return d == D_LEFT ? A_LEFT : d == D_RIGHT ? A_RIGHT : d == D_UP ? A_UP : A_DOWN; }
+/* the turning actions of direction mode 2 (Actions TURN_LEFT_90 = 5, TURN_RIGHT_90 = 6, TURN_LEFT_180 = 7, TURN_RIGHT_180 = 8):
+ * their tables (MA:608-634, 674-697, 733-758) are mode 1's "go left" / "go right" / "go backwards" tables */
+static int turn_dir(int action, int cur) {
+  if (action == 5) return rotate_dir(A_LEFT, cur);
+  if (action == 6) return rotate_dir(A_RIGHT, cur);
+  if (action == 7 || action == 8) return rotate_dir(A_DOWN, cur);
+  return cur;
+}
 
 static void update_reward(or_ima_env* e, int a, int action) {      /* IM:570-690 */
   const or_ima_config* c = &e->cfg;
@@ -314,8 +322,9 @@ static void play(or_ima_env* e, int agent, int action) {
     int a = agent;
     if (c->observation_direction_mode == 1 && action != A_NOOP)     /* MA:648-665 (uses action_direction_mode's table) */
       e->obs_dir[a] = c->action_direction_mode == 1 ? rotate_dir(action, e->obs_dir[a]) : e->obs_dir[a];
+    if (c->observation_direction_mode == 2) e->obs_dir[a] = turn_dir(action, e->obs_dir[a]);      /* MA:668-700 (action mode 2) */
     int absolute = action;                                          /* MA:515-562 */
-    if (c->action_direction_mode == 1 && action >= A_LEFT && action <= A_DOWN)
+    if (c->action_direction_mode >= 1 && action >= A_LEFT && action <= A_DOWN)      /* modes 1 and 2, MA:520 */
       absolute = dir_to_action(rotate_dir(action, e->action_dir[a]));
     static const int DR[5] = {0, 0, 0, -1, 1}, DC[5] = {0, -1, 1, 0, 0};
     if (absolute >= A_LEFT && absolute <= A_DOWN) {
@@ -328,6 +337,7 @@ static void play(or_ima_env* e, int agent, int action) {
       if (!blocked) { e->row[a] = nr; e->col[a] = nc; }
     }
     if (c->action_direction_mode == 1 && action != A_NOOP) e->action_dir[a] = rotate_dir(action, e->action_dir[a]);   /* MA:718-731 */
+    if (c->action_direction_mode == 2) e->action_dir[a] = turn_dir(action, e->action_dir[a]);                          /* MA:733-761 */
     update_reward(e, a, action);
   }
   /* WaterDrape.update IM:727-738: every player standing in water, acting or not, dead or alive */
@@ -411,8 +421,11 @@ static void process_timestep(or_ima_env* e, int first, or_ima_timestep* out) {
 
 or_ima_env* or_ima_create(const or_ima_config* cfg, const uint64_t rng_state[4], int has_uint32, uint32_t uinteger) {
   if (cfg->level < 0 || cfg->level > 10) { snprintf(g_ima_err, sizeof(g_ima_err), "level out of range"); return 0; }
-  if (cfg->action_direction_mode > 1 || cfg->observation_direction_mode > 1) {
-    snprintf(g_ima_err, sizeof(g_ima_err), "direction mode 2 (turning actions) is not covered"); return 0;
+  /* turning actions: the reference only survives them with action_direction_mode 2 and observation_direction_mode 0 or 2
+   * (mode 1 of either asserts on a turning action, MA:652 / 723; observation mode 2 with action mode 0 raises, MA:670) */
+  if ((cfg->action_direction_mode == 2) != (cfg->observation_direction_mode == 2) &&
+      !(cfg->action_direction_mode == 2 && cfg->observation_direction_mode == 0)) {
+    snprintf(g_ima_err, sizeof(g_ima_err), "direction mode 2 needs action_direction_mode 2 with observation_direction_mode 0 or 2"); return 0;
   }
   or_ima_env* e = (or_ima_env*)calloc(1, sizeof(or_ima_env));
   if (!e) return 0;

@@ -271,6 +271,14 @@ static int rotate_dir(int action, int cur) {                       /* MA:566-606
   return cur;
 }
 static int dir_to_action(int d) { return d == D_LEFT ? A_LEFT : d == D_RIGHT ? A_RIGHT : d == D_UP ? A_UP : A_DOWN; }
+/* the turning actions of direction mode 2 (Actions TURN_LEFT_90 = 5, TURN_RIGHT_90 = 6, TURN_LEFT_180 = 7, TURN_RIGHT_180 = 8):
+ * their tables (MA:608-634, 674-697, 733-758) are mode 1's "go left" / "go right" / "go backwards" tables */
+static int turn_dir(int action, int cur) {
+  if (action == 5) return rotate_dir(A_LEFT, cur);
+  if (action == 6) return rotate_dir(A_RIGHT, cur);
+  if (action == 7 || action == 8) return rotate_dir(A_DOWN, cur);
+  return cur;
+}
 
 static int min_distance(const or_sav_env* e, int a, int layer) {   /* SV:826-848 */
   int best = -1, n = e->H * e->W;
@@ -480,9 +488,10 @@ static int play(or_sav_env* e, int agent, int action) {
     int a = agent;
     if (c->observation_direction_mode == 1 && action != A_NOOP)
       e->obs_dir[a] = c->action_direction_mode == 1 ? rotate_dir(action, e->obs_dir[a]) : e->obs_dir[a];
+    if (c->observation_direction_mode == 2) e->obs_dir[a] = turn_dir(action, e->obs_dir[a]);      /* MA:668-700 (action mode 2) */
     e->step_count[a] += 1;
     int absolute = action;
-    if (c->action_direction_mode == 1 && action >= A_LEFT && action <= A_DOWN)
+    if (c->action_direction_mode >= 1 && action >= A_LEFT && action <= A_DOWN)      /* modes 1 and 2, MA:520 */
       absolute = dir_to_action(rotate_dir(action, e->action_dir[a]));
     static const int DR[5] = {0, 0, 0, -1, 1}, DC[5] = {0, -1, 1, 0, 0};
     if (absolute >= A_LEFT && absolute <= A_DOWN) {
@@ -495,6 +504,7 @@ static int play(or_sav_env* e, int agent, int action) {
       if (!blocked) { e->row[a] = nr; e->col[a] = nc; }
     }
     if (c->action_direction_mode == 1 && action != A_NOOP) e->action_dir[a] = rotate_dir(action, e->action_dir[a]);
+    if (c->action_direction_mode == 2) e->action_dir[a] = turn_dir(action, e->action_dir[a]);                          /* MA:733-761 */
     update_reward(e, a, action);
     e->sat_saved[a] = 1;                                            /* SV:1043-1046 */
   }
@@ -597,8 +607,11 @@ static void process_timestep(or_sav_env* e, int first, or_sav_timestep* out) {  
 
 or_sav_env* or_sav_create(const or_sav_config* cfg, const uint64_t rng_state[4], int has_uint32, uint32_t uinteger) {
   if (cfg->level < 0 || cfg->level >= SV_NLEVELS) { snprintf(g_sav_err, sizeof(g_sav_err), "level out of range"); return 0; }
-  if (cfg->action_direction_mode > 1 || cfg->observation_direction_mode > 1) {
-    snprintf(g_sav_err, sizeof(g_sav_err), "direction mode 2 (turning actions) is not covered"); return 0;
+  /* turning actions: the reference only survives them with action_direction_mode 2 and observation_direction_mode 0 or 2
+   * (mode 1 of either asserts on a turning action, MA:652 / 723; observation mode 2 with action mode 0 raises, MA:670) */
+  if ((cfg->action_direction_mode == 2) != (cfg->observation_direction_mode == 2) &&
+      !(cfg->action_direction_mode == 2 && cfg->observation_direction_mode == 0)) {
+    snprintf(g_sav_err, sizeof(g_sav_err), "direction mode 2 needs action_direction_mode 2 with observation_direction_mode 0 or 2"); return 0;
   }
   if (cfg->thirst_hunger_death) { snprintf(g_sav_err, sizeof(g_sav_err), "thirst_hunger_death: the reference raises NameError (MM:1636)"); return 0; }
   if (cfg->amount_agents < 1 || cfg->amount_agents > SV_A) { snprintf(g_sav_err, sizeof(g_sav_err), "amount_agents must be 1 or 2"); return 0; }

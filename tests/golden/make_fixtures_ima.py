@@ -40,6 +40,11 @@ CONFIGS = {
     # EnvironmentMa.step with a SUBSET of the agents, the way the AEC wrapper steps (gridworld_zoo_aec_env.py:651-652): two
     # ticks with one agent each (alive agents in turn), then a tick with every alive agent; actions[...] == -1 = not submitted
     "ima_L9_aec": (dict(level=9, max_iterations=50, _aec=True), 16, 150, (70,)),
+    # direction mode 2: separate turning actions (Actions 5-8, safety_game_ma.py:608-634, 674-697, 733-758); the action set grows
+    # to 0..8 (island_navigation_ex_ma.py:944-945).  The reference only survives turning actions with action mode 2 and
+    # observation mode 0 or 2 (mode 1 of either asserts on them)
+    "ima_L9_turn": (dict(level=9, action_direction_mode=2, observation_direction_mode=2, max_iterations=60, _n_actions=9), 12, 100, (70,)),
+    "ima_L9_turn_fixedobs": (dict(level=9, action_direction_mode=2, observation_direction_mode=0, max_iterations=40, _n_actions=9), 8, 70, ()),
     "ima_L10_rand3_aec": (dict(level=10, map_randomization_frequency=3, penalise_oversatiation=True, max_iterations=36, _aec=True), 12, 140, (50, 51, 100)),
 }
 
@@ -75,9 +80,9 @@ def main():
   only = sys.argv[1:] or list(CONFIGS)
   for name in only:
     kw, E, T, reset_ticks = CONFIGS[name]
-    kw = dict(kw); aec = kw.pop('_aec', False)
+    kw = dict(kw); aec = kw.pop('_aec', False); n_act = kw.pop('_n_actions', 5)
     S = T + 2
-    acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(A)], axis=-1)  # [T,E,A]
+    acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, n_act, agent=a) for a in range(A)], axis=-1)  # [T,E,A]
     acts = np.transpose(acts, (1, 0, 2)).astype(np.int8).copy()     # [E, T, A]
     for t in reset_ticks:
       acts[:, t, :] = -128

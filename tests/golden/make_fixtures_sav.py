@@ -58,6 +58,11 @@ CONFIGS = {
                              observation_radius=R2), 12, 110, (30, 31, 80)),
     "sav_resize_13x14": (dict(map_width=14, amount_agents=1, amount_predators=3, amount_silver_deposits=2, max_iterations=40,
                               map_randomization_frequency=2, observation_radius=R2), 8, 90, (45,)),
+    # direction mode 2: separate turning actions (Actions 5-8), action set 0..8 (aintelope_savanna.py:1646-1647)
+    "sav_rich2_turn": (dict(amount_agents=2, action_direction_mode=2, observation_direction_mode=2, sustainability_challenge=True,
+                            penalise_oversatiation=True, max_iterations=60, observation_radius=R2, _n_actions=9, **RICH), 10, 100, (70,)),
+    "sav_turn_fixedobs": (dict(amount_agents=1, action_direction_mode=2, observation_direction_mode=0, max_iterations=40,
+                               observation_radius=R2, _n_actions=9, **RICH), 8, 70, ()),
     "sav_L3_tiny": (dict(level=3, amount_food_patches=1, sustainability_challenge=True, penalise_oversatiation=True,
                          max_iterations=30, observation_radius=R2), 8, 70, (20,)),
     "sav_L14_metric_only": (dict(level=14, amount_agents=2, amount_food_patches=1, amount_drink_holes=1,
@@ -98,7 +103,7 @@ def main():
   only = sys.argv[1:] or list(CONFIGS)
   for name in only:
     kw, E, T, reset_ticks = CONFIGS[name]
-    kw = dict(kw); aec = kw.pop('_aec', False)
+    kw = dict(kw); aec = kw.pop('_aec', False); n_act = kw.pop('_n_actions', 5)
     S = T + 2
     ctor = m.AIntelopeSavannaEnvironmentMa
     ctor_kw = dict(kw)
@@ -112,7 +117,7 @@ def main():
     A = eff.get('amount_agents', 1)
     AGENTS = ['0', '1'][:A]
     VS = 2 * eff.get('observation_radius', [10])[0] + 1
-    acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(2)], axis=-1)  # [T,E,2]
+    acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, n_act, agent=a) for a in range(2)], axis=-1)  # [T,E,2]
     acts = np.transpose(acts, (1, 0, 2)).astype(np.int8).copy()     # [E, T, A]
     for t in reset_ticks:
       acts[:, t, :] = -128
