@@ -288,6 +288,14 @@ int sgw_set_family_table(sgw_engine* e, const double* table_host, int64_t n) {
   return SGW_OK;
 }
 
+#ifdef SGW_FM_PROF      // diagnostic build only
+extern "C" int sgw_debug_fm_prof(unsigned long long* out, int clear) {      // out[4096 * 12]
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fm_prof), 4096 * 12 * 8) != hipSuccess) return -1;
+  if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fm_prof)) != hipSuccess || hipMemset(p, 0, 4096 * 12 * 8) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
+
 int sgw_pow_f64(const double* x_dev, double y, double* out_dev, int64_t n, int device, void* stream) {
   if (!x_dev || !out_dev || n < 0) return fail(SGW_ERR_ARG, "sgw_pow_f64: null / negative argument");
   if (n == 0) return SGW_OK;

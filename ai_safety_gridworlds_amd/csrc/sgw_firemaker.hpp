@@ -56,6 +56,10 @@ constexpr PcgJump make_pcg_jump() {
 }
 __device__ const PcgJump g_pcg_jump = make_pcg_jump();
 
+#ifdef SGW_FM_PROF
+__device__ unsigned long long g_fm_prof[4096 * 12];      // [wave][phase], each wave adds to its own row
+#endif
+
 struct Firemaker {
   static constexpr int NA = 3;
   static constexpr int NU = 9;          // [agent][3]
@@ -237,7 +241,14 @@ struct Firemaker {
   static constexpr int SCR_FIRE = 0, SCR_LIST = 64, SCR_NEW = 64 + 640, SCR_BYTES = 768;
   static constexpr int X_JUMP = 0, X_DRAWS = 2112, X_EXCH = X_DRAWS + WAVES * 128 * 8, X_TICKET = X_EXCH + 2 * 7 * 64 * 8,
                        X_SCR = X_TICKET + 16, LDS_EXTRA = X_SCR + WAVES * SCR_BYTES;
+#ifdef SGW_FM_PROF      // diagnostic build only (tools/diag/fm_prof.py): wave cycles per phase of a round, summed over all waves
+#define FM_T(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); cx.pf[k] += n_ - cx.t_last; cx.t_last = n_; } while (0)
+  struct Ctx { const uint64_t* jump; double* draws; uint64_t* exch; uint32_t* ticket; uint8_t* scr; int wave, lane, parity; uint32_t base;
+               unsigned long long pf[12], t_last; };
+#else
+#define FM_T(k) do { } while (0)
   struct Ctx { const uint64_t* jump; double* draws; uint64_t* exch; uint32_t* ticket; uint8_t* scr; int wave, lane, parity; uint32_t base; };
+#endif
   static __device__ void init_ctx(Ctx& cx, const Lds& l) {
     cx.lane = threadIdx.x & 63;
     cx.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -251,6 +262,10 @@ struct Firemaker {
     cx.scr = l.extra + X_SCR + cx.wave * SCR_BYTES;
     if (threadIdx.x == 0) *cx.ticket = 0u;
     cx.base = 0u;
+#ifdef SGW_FM_PROF
+    for (int k = 0; k < 12; ++k) cx.pf[k] = 0ull;
+    cx.t_last = __builtin_amdgcn_s_memtime();
+#endif
   }
 
   struct U128 { uint64_t hi, lo; };
@@ -308,6 +323,74 @@ struct Firemaker {
     }
     return m;
   }
+  // NH x 64 candidates from list position p0 on, ascending cells.  NH = 2: two independent probability chains per lane
+  // (candidates p0 + lane and p0 + 64 + lane) give the f64 pipeline something to overlap; the draws are ranked chunk by chunk.
+  template <int NH>
+  static __device__ void spread_chunks(int p0, int nc, const uint64_t* fw, const uint16_t* list, uint32_t* nfw, uint32_t v25, uint32_t valid,
+                                       uint32_t ws, const double (&q)[9], const Lds& l, Ring& g, Ctx& cx) {
+    const int lane = cx.lane;
+    bool act[NH]; int t[NH]; uint32_t nb[NH]; double cum[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      act[h] = p0 + 64 * h + lane < nc;
+      t[h] = act[h] ? (int)list[p0 + 64 * h + lane] : 0;
+      uint32_t b25 = 0;                                              // the 25 neighbourhood bits of the OLD fire mask
+#pragma unroll
+      for (int dr = -2; dr <= 2; ++dr) {
+        const int pos = t[h] + dr * W - 2 + 64;                      // + 64: fw[] carries one zero word in front
+        const int w = pos >> 6, sh = pos & 63;
+        const uint64_t lo = fw[w], hi = fw[w + 1];
+        const uint64_t bits = (lo >> sh) | ((hi << 1) << (63 - sh));
+        b25 |= ((uint32_t)bits & 31u) << (5 * (dr + 2));
+      }
+      nb[h] = act[h] ? (b25 & v25) : 0u;
+      cum[h] = 0.0;
+    }
+    // FM:601-609 `p = 1 - (1 - p)(1 - q)` over the burning sources in row-major order.  A source that does not burn takes the
+    // factor 1.0 instead of a select on p: every p here is 1.0 - y with y in (0, 1], i.e. a multiple of 2^-53 below 1, so
+    // 1.0 - p is exact and 1.0 - (1.0 - p) * 1.0 == p bit for bit -- and the selects leave the dependent chain
+#pragma unroll
+    for (int i = 0; i < 25; ++i) {
+      if (i == 12) continue;
+      const int dr = i / 5 - 2, dc = i % 5 - 2, k = (dr < 0 ? -dr : dr) * 3 + (dc < 0 ? -dc : dc);
+      const uint64_t qb = f2u(q[k]);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const uint32_t m = (uint32_t)(((int32_t)(nb[h] << (31 - i))) >> 31);            // all ones when source i burns
+        const uint32_t flo = (uint32_t)qb & m, fhi = ((uint32_t)(qb >> 32) & m) | (0x3ff00000u & ~m);
+        cum[h] = 1.0 - (1.0 - cum[h]) * u2f(((uint64_t)fhi << 32) | flo);
+      }
+    }
+    FM_T(5);                                                         // neighbourhoods + probability chains
+    if (ws & 3u) {                                                   // then the virtual workshop sources, agent order (FM:550-554)
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int tr = (t[h] * 241) >> 12, tc = t[h] - tr * W;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          if ((ws >> a) & 1u) {
+            const int wc = (int)((ws >> (8 + 9 * a)) & 0x1ffu), wr = (wc * 241) >> 12;
+            const int adr = abs(wr - tr), adc = abs(wc - wr * W - tc);
+            const bool near = act[h] && adr <= 2 && adc <= 2;
+            const int k = near ? adr * 3 + adc : 0;
+            if (near && ((valid >> k) & 1u)) cum[h] = 1.0 - (1.0 - cum[h]) * (1.0 - l.params[P_SPREAD0 + k]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const uint64_t need = __ballot(act[h] && cum[h] > 0.0);        // FM:612: one draw per target with p > 0, row-major
+      if (need) {
+        ring_ready(g, cx);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+        const double u = cx.draws[(g.consumed + rank) & 127];
+        if (act[h] && cum[h] > 0.0 && u < cum[h]) atomicOr(&nfw[t[h] >> 5], 1u << (t[h] & 31));
+        g.consumed += __builtin_popcountll(need);
+      }
+    }
+    FM_T(6);                                                         // workshop sources + draws
+  }
   static __device__ void spread_compact(const uint64_t (&o)[5], const uint64_t (&c)[5], uint64_t (&nf)[5], uint32_t v25, uint32_t valid,
                                         uint32_t ws, const double (&q)[9], const Lds& l, Ring& g, Ctx& cx) {
     const int lane = cx.lane;
@@ -327,52 +410,15 @@ struct Firemaker {
       nc += __builtin_popcountll(cw);
     }
     lds_wave_sync();
-    for (int p0 = 0; p0 < nc; p0 += 64) {                              // scalar loop: 64 candidates at a time, ascending cells
-      const bool act = p0 + lane < nc;
-      const int t = act ? (int)list[p0 + lane] : 0;
-      uint32_t nb = 0;                                                 // the 25 neighbourhood bits of the OLD fire mask
-#pragma unroll
-      for (int dr = -2; dr <= 2; ++dr) {
-        const int pos = t + dr * W - 2 + 64;                           // + 64: fw[] carries one zero word in front
-        const int w = pos >> 6, sh = pos & 63;
-        const uint64_t lo = fw[w], hi = fw[w + 1];
-        const uint64_t bits = (lo >> sh) | ((hi << 1) << (63 - sh));
-        nb |= ((uint32_t)bits & 31u) << (5 * (dr + 2));
-      }
-      nb = act ? (nb & v25) : 0u;
-      double cum = 0.0;
-#pragma unroll
-      for (int i = 0; i < 25; ++i) {
-        if (i == 12) continue;
-        const int dr = i / 5 - 2, dc = i % 5 - 2, k = (dr < 0 ? -dr : dr) * 3 + (dc < 0 ? -dc : dc);
-        const double nv = 1.0 - (1.0 - cum) * q[k];                    // FM:601-609
-        cum = ((nb >> i) & 1u) ? nv : cum;
-      }
-      if (ws & 3u) {                                                   // then the virtual workshop sources, agent order (FM:550-554)
-        const int tr = (t * 241) >> 12, tc = t - tr * W;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          if ((ws >> a) & 1u) {
-            const int wc = (int)((ws >> (8 + 9 * a)) & 0x1ffu), wr = (wc * 241) >> 12;
-            const int adr = abs(wr - tr), adc = abs(wc - wr * W - tc);
-            const bool near = act && adr <= 2 && adc <= 2;
-            const int k = near ? adr * 3 + adc : 0;
-            if (near && ((valid >> k) & 1u)) cum = 1.0 - (1.0 - cum) * (1.0 - l.params[P_SPREAD0 + k]);
-          }
-        }
-      }
-      const uint64_t need = __ballot(act && cum > 0.0);                // FM:612: one draw per target with p > 0, row-major
-      if (need) {
-        ring_ready(g, cx);
-        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-        const double u = cx.draws[(g.consumed + rank) & 127];
-        if (act && cum > 0.0 && u < cum) atomicOr(&nfw[t >> 5], 1u << (t & 31));
-        g.consumed += __builtin_popcountll(need);
-      }
+    FM_T(4);                                                           // scratch fill + candidate list
+    for (int p0 = 0; p0 < nc;) {                                       // scalar loop
+      if (nc - p0 > 64) { spread_chunks<2>(p0, nc, fw, list, nfw, v25, valid, ws, q, l, g, cx); p0 += 128; }
+      else { spread_chunks<1>(p0, nc, fw, list, nfw, v25, valid, ws, q, l, g, cx); p0 += 64; }
     }
     lds_wave_sync();
 #pragma unroll
     for (int j = 0; j < 5; ++j) nf[j] = uniform_u64(reinterpret_cast<const uint64_t*>(nfw)[j]);
+    FM_T(7);                                                           // new fire words back
   }
   template <int WI>
   static __device__ void continue_pass(const uint64_t (&o)[5], uint64_t (&nf)[5], double cont, Ring& g, Ctx& cx) {
@@ -385,10 +431,36 @@ struct Firemaker {
     g.consumed += __builtin_popcountll(ow);
   }
 
+  // FM:619-621 for all five words at once when the env's fire cells fit the ring's window (they do unless > 64 cells burn):
+  // one ring_ready, five independent LDS reads, instead of five dependent passes
+  static __device__ void continue_all(const uint64_t (&o)[5], uint64_t (&nf)[5], double cont, Ring& g, Ctx& cx) {
+    const int total = __builtin_popcountll(o[0]) + __builtin_popcountll(o[1]) + __builtin_popcountll(o[2]) +
+                      __builtin_popcountll(o[3]) + __builtin_popcountll(o[4]);
+    if (total == 0) return;
+    if (total > 64) {
+      continue_pass<0>(o, nf, cont, g, cx); continue_pass<1>(o, nf, cont, g, cx); continue_pass<2>(o, nf, cont, g, cx);
+      continue_pass<3>(o, nf, cont, g, cx); continue_pass<4>(o, nf, cont, g, cx);
+      return;
+    }
+    ring_ready(g, cx);                                                // draws [consumed, consumed + 64) are readable
+    int base = g.consumed;
+    double u[5];
+#pragma unroll
+    for (int wi = 0; wi < 5; ++wi) {
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(o[wi] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)o[wi], 0u));
+      u[wi] = cx.draws[(base + rank) & 127];                          // lanes that are no fire cell of this word read a neighbour's draw
+      base += __builtin_popcountll(o[wi]);
+    }
+#pragma unroll
+    for (int wi = 0; wi < 5; ++wi) nf[wi] &= ~(__ballot(!(u[wi] < cont)) & o[wi]);
+    g.consumed = base;
+  }
+
   // FireDrape.update (FM:536-629).  Runs with all 64 lanes of all 4 waves active (see k_engine).
   static __device__ void fire_update(State& s, const KSpec& sp, const Lds& l, double (&r)[NU], bool live, Ctx& cx) {
     const double* p = l.params;
     const int lane = cx.lane;
+    FM_T(0);                                                    // everything outside fire_update
 #pragma unroll
     for (int ag = 0; ag < 3; ++ag) set_bit(s.fire, s.row[ag] * W + s.col[ag], false);     // FM:540-542
     const M5 old = s.fire;
@@ -420,6 +492,7 @@ struct Firemaker {
     const int n_work = __builtin_popcountll(work);
     const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(work >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)work, 0u));
     bool mine_lane = false;                                                                  // this wave spread this lane's env
+    FM_T(1);                                                    // dilation, candidates, work mask
     if (n_work) {
       const uint32_t valid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p[P_VALID]);
       const double cont = uniform_f64(p[P_CONTINUE]);
@@ -431,10 +504,11 @@ struct Firemaker {
       const U128 aj = {jt[0], jt[1]}, gj = {jt[2], jt[3]};
       Ring g;
       g.a64.hi = uniform_u64(cx.jump[64 * 4]); g.a64.lo = uniform_u64(cx.jump[64 * 4 + 1]);
+      uint32_t tk = 0;
+      if (lane == 0) tk = atomicAdd(cx.ticket, 1u);
       for (;;) {
-        uint32_t tk = 0;
-        if (lane == 0) tk = atomicAdd(cx.ticket, 1u);
         const int k = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)tk) - cx.base);
+        FM_T(2);                                                // ticket
         if (k >= n_work) break;
         const int e = __builtin_ctzll(__ballot(has_work && my_rank == k));
         mine_lane = mine_lane || (lane == e);
@@ -450,9 +524,12 @@ struct Firemaker {
         g.blk = 0; g.consumed = 0;
         lds_wave_sync();
         cx.draws[lane] = pcg_double(g.xa); cx.draws[64 + lane] = pcg_double(g.xb);
+        FM_T(3);                                                // broadcast + generator jump-ahead + first 128 draws
         spread_compact(o, c, nf, v25, valid, wse, q, l, g, cx);
-        continue_pass<0>(o, nf, cont, g, cx); continue_pass<1>(o, nf, cont, g, cx); continue_pass<2>(o, nf, cont, g, cx);
-        continue_pass<3>(o, nf, cont, g, cx); continue_pass<4>(o, nf, cont, g, cx);
+        // the next ticket is drawn here: its LDS round trip (the loop's only serial wait) hides behind the continue passes
+        tk = 0;
+        if (lane == 0) tk = atomicAdd(cx.ticket, 1u);
+        continue_all(o, nf, cont, g, cx);
         U128 fin = st;
         if (g.consumed > 0) {                                             // the env's stream stops after its last draw
           const int t1 = g.consumed - 1, src_lane = t1 & 63;
@@ -462,6 +539,10 @@ struct Firemaker {
         const bool me = (lane == e);
         res.a = me ? nf[0] : res.a; res.b = me ? nf[1] : res.b; res.c = me ? nf[2] : res.c; res.d = me ? nf[3] : res.d;
         res.e = me ? nf[4] : res.e; res_hi = me ? fin.hi : res_hi; res_lo = me ? fin.lo : res_lo;
+        FM_T(8);                                                // continue passes + final generator state
+#ifdef SGW_FM_PROF
+        cx.pf[11] += 1ull << 32;                                // env-spreads served (upper half of the tail slot)
+#endif
       }
       cx.base += (uint32_t)(n_work + WAVES);                     // every wave drew exactly one ticket past the end
     }
@@ -470,7 +551,9 @@ struct Firemaker {
     if (mine_lane) {
       ex[0] = res.a; ex[64] = res.b; ex[128] = res.c; ex[192] = res.d; ex[256] = res.e; ex[320] = res_hi; ex[384] = res_lo;
     }
+    FM_T(9);                                                    // publish
     __syncthreads();
+    FM_T(10);                                                   // waiting for the slowest wave of the workgroup
     if (has_work) {
       s.fire.a = ex[0]; s.fire.b = ex[64]; s.fire.c = ex[128]; s.fire.d = ex[192]; s.fire.e = ex[256];
       s.rs_hi = ex[320]; s.rs_lo = ex[384];
@@ -486,6 +569,12 @@ struct Firemaker {
     const bool sup = !(sp.flags & F_NO_SUP);
     r[2 * 3 + 1] += sup ? ext : 0.0;
     r[0 * 3 + 2] += sup ? 0.0 : ext;
+#ifdef SGW_FM_PROF
+    FM_T(11);
+    if (lane == 0) { unsigned long long* row = g_fm_prof + ((blockIdx.x * WAVES + cx.wave) & 4095) * 12; for (int k = 0; k < 12; ++k) { row[k] += cx.pf[k]; } }
+    for (int k = 0; k < 12; ++k) cx.pf[k] = 0ull;
+    cx.t_last = __builtin_amdgcn_s_memtime();
+#endif
   }
 
   // one Engine.play({agent: {"step": action}})
