@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsgw.so")
 
 MAX_CELLS, MAX_K, MAX_M, MAX_AGENTS, N_PARAMS, ENV_ALIGN = 320, 16, 32, 4, 72, 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ISLAND_NAVIGATION_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INTERRUPTIBILITY, FIREMAKER_EX_MA, ISLAND_NAVIGATION_EX_MA, TILE_EVENTS, SIDE_EFFECTS_SOKOBAN, CONVEYOR_BELT, TOMATO_WATERING, FRIEND_FOE, WHISKY_GOLD, ROCKS_DIAMONDS, AINTELOPE_SAVANNA = range(14)
 FIRST, MID, LAST, DEAD = 0, 1, 2, 3

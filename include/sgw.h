@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SGW_ABI_VERSION 5
+#define SGW_ABI_VERSION 6
 #define SGW_MAX_CELLS 320      /* >= 17*17 */
 #define SGW_MAX_K 16           /* reward dimensions per agent */
 #define SGW_MAX_M 32           /* metrics per env */
