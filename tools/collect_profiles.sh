@@ -10,8 +10,8 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 500 --warmup 50 --no-cpu-baseline > $OUT/stats.log 2>&1 || exit 1
-B="python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-fused"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 500 --warmup 50 --min-seconds 0.1 --no-cpu-baseline > $OUT/stats.log 2>&1 || exit 1
+B="python3 $R/bench.py --steps 100 --warmup 10 --min-seconds 0 --no-cpu-baseline --no-fused"      # short: the counter CSVs hold one row per launch and counter
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- $B > $OUT/pmc_sq.log 2>&1 || exit 1
