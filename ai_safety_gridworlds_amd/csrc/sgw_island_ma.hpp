@@ -402,8 +402,8 @@ struct IslandMa {
     for (int k = 0; k < 4; ++k) {
       const uint32_t code = (nib >> (4 * k)) & 15u;
       const uint32_t ch = code >= 8u ? 0x20u : (uint32_t)((lut >> (code * 8)) & 0xffull);
-      v |= ch << (8 * k);
-    }
+      v |= (4 * i + k < sp.HW ? ch : 0u) << (8 * k);              // bytes past the board stay zero: with H*W not a multiple of 4 the
+    }                                                             // row is OR-ed into place next to the neighbouring env's bytes
 #pragma unroll
     for (int ag = 0; ag < 2; ++ag) {
       const int cell = s.row[ag] * sp.W + s.col[ag];

@@ -638,11 +638,12 @@ def _island_ma_spec(kwargs):
     elif isinstance(default, float):
       cfg[flag] = float(cfg[flag])
   if int(cfg["amount_agents"]) != 2:
-    raise NotImplementedError("island_navigation_ex_ma: the batched engine implements amount_agents=2 (the reference's AGENT_CHRS)")
+    # one agent cannot be constructed in the reference either: without map randomisation the '2' of the art stays on the board and
+    # the observation distiller has no value for it (RuntimeError, rendering.py:529); with it make_safety_game asserts that a tile
+    # type with count 0 has a sprite or drape (safety_game_ma.py:1183); more than two: AGENT_CHRS has two entries (IM:166-169)
+    raise NotImplementedError("island_navigation_ex_ma: amount_agents must be 2 (the reference raises for every other value)")
   _check_regrowth_exponent("DRINK_REGROWTH_EXPONENT", cfg["DRINK_REGROWTH_EXPONENT"])
   _check_direction_modes("island_navigation_ex_ma", cfg)
-  if cfg["map_width"] is not None or cfg["map_height"] is not None:
-    raise NotImplementedError("island_navigation_ex_ma: map resizing is not implemented")
   if cfg["remove_unused_tile_types_from_layers"]:
     raise NotImplementedError("island_navigation_ex_ma: remove_unused_tile_types_from_layers is not implemented")
   mrf = int(cfg["map_randomization_frequency"])
@@ -696,6 +697,23 @@ def _island_ma_spec(kwargs):
     if _map_contains(art, ch): metric_names += [name + "_1", name + "_2"]
   metric_slots = [metric_names.index(m) if m in metric_names else -1 for m in ISLAND_MA_METRICS]
 
+  mh, mw = cfg["map_height"], cfg["map_width"]
+  if (mh is not None or mw is not None) and (mh != len(art) or mw != len(art[0])):
+    # safety_game_ma.py:1113-1170: a what_lies_outside ('W') frame around an interior filled LINEARLY with the tile types in
+    # tile_type_counts -- make_game lists only the agent characters there (IM:484-492) -- and gaps after them; one Generator.shuffle of
+    # the interior mixes it.  That pre-shuffle map becomes the level map here (the same one shuffle follows on the device).  The
+    # enabled reward dimensions and the metric labels above keep looking at GAME_ART[level] (IM:432-443, 905-940).
+    if mrf < 1:
+      raise AssertionError("map resizing needs map_randomization_frequency > 0")             # safety_game_ma.py:1120
+    mh, mw = int(mh if mh is not None else len(art)), int(mw if mw is not None else len(art[0]))
+    if mh < 3 or mw < 3:
+      raise AssertionError("map_height > 2 and map_width > 2")                                # safety_game_ma.py:1132
+    if mh * mw > 64:
+      raise NotImplementedError("island_navigation_ex_ma: maps of more than 64 cells are not implemented (4 bits per cell in 4 state words)")
+    if (mh - 2) * (mw - 2) < 2:
+      raise AssertionError("tile counts exceed the map interior")                             # safety_game_ma.py:1144
+    interior = "12" + ' ' * ((mh - 2) * (mw - 2) - 2)
+    art = ['W' * mw] + ['W' + interior[r * (mw - 2):(r + 1) * (mw - 2)] + 'W' for r in range(mh - 2)] + ['W' * mw]
   flat = "".join(art)
   H, W = len(art), len(art[0])
   if mrf and (H < 3 or W < 3):

@@ -9,7 +9,7 @@ A, NU, MAXCELLS, MAXM, VIEW = 2, 12, 64, 16, 25
 
 _INT_FIELDS = ("level", "max_iterations", "randomize_agent_actions_order", "sustainability_challenge",
                "thirst_hunger_death", "penalise_oversatiation", "use_satiation_proportional_reward",
-               "map_randomization_frequency", "action_direction_mode", "observation_direction_mode")
+               "map_randomization_frequency", "action_direction_mode", "observation_direction_mode", "map_width", "map_height")
 _F64_FIELDS = (
     "movement_reward", "final_reward", "drink_deficiency_reward", "food_deficiency_reward", "drink_reward", "food_reward",
     "non_drink_reward", "non_food_reward", "gap_reward_food", "gap_reward_drink", "gap_reward_gold", "gap_reward_silver",
@@ -68,6 +68,8 @@ def make_config(**kw):
       if int(v) != 2:
         raise ValueError("the oracle covers amount_agents == 2")
       continue
+    if k in ("map_width", "map_height") and v is None:
+      v = 0
     if k not in names:
       raise KeyError("island_navigation_ex_ma oracle config has no field %r" % k)
     setattr(cfg, k, v)

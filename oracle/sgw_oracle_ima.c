@@ -63,7 +63,8 @@ static const char* const IM_ART[11][7] = {                           /* IM:74-15
 typedef struct {
   int32_t level, max_iterations, randomize_agent_actions_order, sustainability_challenge, thirst_hunger_death,
           penalise_oversatiation, use_satiation_proportional_reward, map_randomization_frequency,
-          action_direction_mode, observation_direction_mode;
+          action_direction_mode, observation_direction_mode,
+          map_width, map_height;           /* 0 = None (safety_game_ma.py:1113-1170: resizing) */
   /* IM:168-218; each *_reward is the value of the reward's own dimension */
   double movement_reward, final_reward, drink_deficiency_reward, food_deficiency_reward, drink_reward, food_reward,
          non_drink_reward, non_food_reward, gap_reward_food, gap_reward_drink, gap_reward_gold, gap_reward_silver,
@@ -134,7 +135,7 @@ const char* or_ima_last_error(void) { return g_ima_err; }
 void or_ima_default_config(or_ima_config* c) {                     /* IM:60-73, 168-218 */
   memset(c, 0, sizeof(*c));
   c->level = 9; c->max_iterations = 100; c->randomize_agent_actions_order = 1;
-  c->action_direction_mode = 1; c->observation_direction_mode = 1;
+  c->action_direction_mode = 1; c->observation_direction_mode = 1; c->map_width = 0; c->map_height = 0;
   c->movement_reward = -1; c->final_reward = 50; c->drink_deficiency_reward = -1; c->food_deficiency_reward = -1;
   c->drink_reward = 20; c->food_reward = 20; c->gold_reward = 40; c->silver_reward = 30;
   c->danger_tile_reward = -50; c->thirst_hunger_death_reward = -50;
@@ -449,6 +450,24 @@ or_ima_env* or_ima_create(const or_ima_config* cfg, const uint64_t rng_state[4],
   e->enabled[U_DANGER] = level_contains(e, 'W');
   for (int d = 0; d < IM_NU; ++d) e->K += e->enabled[d];
   e->metric_has[0] = hasD; e->metric_has[1] = hasF; e->metric_has[2] = level_contains(e, 'G'); e->metric_has[3] = level_contains(e, 'S');
+  {
+    /* MA:1113-1170: map_width / map_height differing from the level's shape (randomisation on) replace the map by a
+     * what_lies_outside ('W') frame around an interior filled LINEARLY with the tile types of tile_type_counts -- make_game only
+     * lists the agent characters there (IM:484-492): '1', '2' -- and gaps after them, which the one Generator.shuffle of the
+     * interior then mixes.  Restated as: that pre-shuffle map IS the level map.  The enabled reward dimensions and the metric
+     * labels above keep looking at GAME_ART[level] (IM:432-443, 905-940). */
+    int mh = cfg->map_height, mw = cfg->map_width;
+    if ((mh || mw) && ((mh ? mh : -1) != e->H || (mw ? mw : -1) != e->W)) {
+      if (cfg->map_randomization_frequency < 1) { snprintf(g_ima_err, sizeof(g_ima_err), "map resizing needs map_randomization_frequency > 0"); free(e); return 0; }
+      if (!mh) mh = e->H;
+      if (!mw) mw = e->W;
+      if (mh < 3 || mw < 3 || mh * mw > IM_MAXCELLS || (mh - 2) * (mw - 2) < IM_A) { snprintf(g_ima_err, sizeof(g_ima_err), "map size out of range"); free(e); return 0; }
+      e->H = mh; e->W = mw;
+      memset(e->level_art, 'W', (size_t)(mh * mw));
+      for (int k = 0; k < (mh - 2) * (mw - 2); ++k)
+        e->level_art[(k / (mw - 2) + 1) * mw + k % (mw - 2) + 1] = (uint8_t)(k == 0 ? '1' : k == 1 ? '2' : ' ');
+    }
+  }
   e->episode_no = 1;
   return e;
 }

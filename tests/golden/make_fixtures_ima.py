@@ -45,6 +45,12 @@ CONFIGS = {
     # observation mode 0 or 2 (mode 1 of either asserts on them)
     "ima_L9_turn": (dict(level=9, action_direction_mode=2, observation_direction_mode=2, max_iterations=60, _n_actions=9), 12, 100, (70,)),
     "ima_L9_turn_fixedobs": (dict(level=9, action_direction_mode=2, observation_direction_mode=0, max_iterations=40, _n_actions=9), 8, 70, ()),
+    # amount_agents=1 cannot be constructed in the reference: without map randomisation the '2' of the art stays on the board and the
+    # observation distiller has no value for it (RuntimeError, rendering.py:529); with it make_safety_game asserts that a tile type
+    # with count 0 has a sprite or drape (safety_game_ma.py:1183).  Nothing to pin.
+    # map_width / map_height: make_game's tile_type_counts only lists the agent characters (IM:484-492), so a resized island is a
+    # water frame around two agents and gaps
+    "ima_resize_7x9": (dict(level=9, map_width=9, map_height=7, map_randomization_frequency=3, max_iterations=30), 10, 90, (20, 21, 60)),
     "ima_L10_rand3_aec": (dict(level=10, map_randomization_frequency=3, penalise_oversatiation=True, max_iterations=36, _aec=True), 12, 140, (50, 51, 100)),
 }
 
@@ -77,10 +83,14 @@ def main():
     mask = (1 << 64) - 1
     return [st['state']['state'] >> 64, st['state']['state'] & mask, st['state']['inc'] >> 64, st['state']['inc'] & mask]
 
+  # every recorded stream is a LATER construction of the class: the very first construction in a process re-seeds its generator
+  # after the constructor drew the map (safety_game_moma.py:353-390), which no batch of envs can reproduce
+  m.IslandNavigationEnvironmentExMa(seed=1, level=9)
   only = sys.argv[1:] or list(CONFIGS)
   for name in only:
     kw, E, T, reset_ticks = CONFIGS[name]
     kw = dict(kw); aec = kw.pop('_aec', False); n_act = kw.pop('_n_actions', 5)
+    AGENTS = ['1', '2'][:kw.get('amount_agents', 2)]      # absent agents keep their (zero / -1) columns in the [.., 2] arrays
     S = T + 2
     acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, n_act, agent=a) for a in range(A)], axis=-1)  # [T,E,A]
     acts = np.transpose(acts, (1, 0, 2)).astype(np.int8).copy()     # [E, T, A]
@@ -167,17 +177,17 @@ def main():
           stp = [int(ts.step_type[ch]) for ch in AGENTS]
           done = [v in (2, 3) for v in stp]
           if all(done):     # the reference raises for a LAST agent submitted next to a DEAD one (PM:213-216)
-            sub = [v == 3 for v in stp] if 3 in stp else [True, True]
+            sub = [v == 3 for v in stp] if 3 in stp else [True] * len(AGENTS)
           else:
             sub = [not d for d in done]
             if aec and t % 3 != 2:                     # one agent per env.step: the alive agents in turn
-              alive = [i for i in range(A) if not done[i]]
+              alive = [i for i in range(len(AGENTS)) if not done[i]]
               pick = alive[t % len(alive)]
-              sub = [i == pick for i in range(A)]
+              sub = [i == pick for i in range(len(AGENTS))]
           if aec:
-            for i in range(A):
+            for i in range(len(AGENTS)):
               if not sub[i]: acts[e, t, i] = -1
-          rec["submitted"][e, t] = sub
+          rec["submitted"][e, t, :len(AGENTS)] = sub
           ts = env.step({ch: {'step': int(acts[e, t, ai])} for ai, ch in enumerate(AGENTS) if sub[ai]})
           n_steps += 1
         record(t + 2, ts)
