@@ -289,9 +289,9 @@ int sgw_set_family_table(sgw_engine* e, const double* table_host, int64_t n) {
 }
 
 #ifdef SGW_FM_PROF      // diagnostic build only
-extern "C" int sgw_debug_fm_prof(unsigned long long* out, int clear) {      // out[4096 * 12]
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fm_prof), 4096 * 12 * 8) != hipSuccess) return -1;
-  if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fm_prof)) != hipSuccess || hipMemset(p, 0, 4096 * 12 * 8) != hipSuccess) return -1; }
+extern "C" int sgw_debug_fm_prof(unsigned long long* out, int clear) {      // out[4096 * 16]
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fm_prof), 4096 * 16 * 8) != hipSuccess) return -1;
+  if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fm_prof)) != hipSuccess || hipMemset(p, 0, 4096 * 16 * 8) != hipSuccess) return -1; }
   return 0;
 }
 #endif

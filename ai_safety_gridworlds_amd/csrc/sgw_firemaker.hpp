@@ -57,7 +57,7 @@ constexpr PcgJump make_pcg_jump() {
 __device__ const PcgJump g_pcg_jump = make_pcg_jump();
 
 #ifdef SGW_FM_PROF
-__device__ unsigned long long g_fm_prof[4096 * 12];      // [wave][phase], each wave adds to its own row
+__device__ unsigned long long g_fm_prof[4096 * 16];      // [wave][phase], each wave adds to its own row
 #endif
 
 struct Firemaker {
@@ -244,7 +244,7 @@ struct Firemaker {
 #ifdef SGW_FM_PROF      // diagnostic build only (tools/diag/fm_prof.py): wave cycles per phase of a round, summed over all waves
 #define FM_T(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); cx.pf[k] += n_ - cx.t_last; cx.t_last = n_; } while (0)
   struct Ctx { const uint64_t* jump; double* draws; uint64_t* exch; uint32_t* ticket; uint8_t* scr; int wave, lane, parity; uint32_t base;
-               unsigned long long pf[12], t_last; };
+               unsigned long long pf[16], t_last; };
 #else
 #define FM_T(k) do { } while (0)
   struct Ctx { const uint64_t* jump; double* draws; uint64_t* exch; uint32_t* ticket; uint8_t* scr; int wave, lane, parity; uint32_t base; };
@@ -263,7 +263,7 @@ struct Firemaker {
     if (threadIdx.x == 0) *cx.ticket = 0u;
     cx.base = 0u;
 #ifdef SGW_FM_PROF
-    for (int k = 0; k < 12; ++k) cx.pf[k] = 0ull;
+    for (int k = 0; k < 16; ++k) cx.pf[k] = 0ull;
     cx.t_last = __builtin_amdgcn_s_memtime();
 #endif
   }
@@ -411,6 +411,12 @@ struct Firemaker {
     }
     lds_wave_sync();
     FM_T(4);                                                           // scratch fill + candidate list
+#ifdef SGW_FM_PROF
+    {
+      const int nfire = __builtin_popcountll(o[0]) + __builtin_popcountll(o[1]) + __builtin_popcountll(o[2]) + __builtin_popcountll(o[3]) + __builtin_popcountll(o[4]);
+      cx.pf[12] += (nc <= 32 && nfire <= 32) ? 1 : 0; cx.pf[13] += (nc > 32 && nc <= 64) ? 1 : 0; cx.pf[14] += nc > 64 ? 1 : 0; cx.pf[15] += (unsigned long long)nc;
+    }
+#endif
     for (int p0 = 0; p0 < nc;) {                                       // scalar loop
       if (nc - p0 > 64) { spread_chunks<2>(p0, nc, fw, list, nfw, v25, valid, ws, q, l, g, cx); p0 += 128; }
       else { spread_chunks<1>(p0, nc, fw, list, nfw, v25, valid, ws, q, l, g, cx); p0 += 64; }
@@ -571,8 +577,8 @@ struct Firemaker {
     r[0 * 3 + 2] += sup ? 0.0 : ext;
 #ifdef SGW_FM_PROF
     FM_T(11);
-    if (lane == 0) { unsigned long long* row = g_fm_prof + ((blockIdx.x * WAVES + cx.wave) & 4095) * 12; for (int k = 0; k < 12; ++k) { row[k] += cx.pf[k]; } }
-    for (int k = 0; k < 12; ++k) cx.pf[k] = 0ull;
+    if (lane == 0) { unsigned long long* row = g_fm_prof + ((blockIdx.x * WAVES + cx.wave) & 4095) * 16; for (int k = 0; k < 16; ++k) { row[k] += cx.pf[k]; } }
+    for (int k = 0; k < 16; ++k) cx.pf[k] = 0ull;
     cx.t_last = __builtin_amdgcn_s_memtime();
 #endif
   }

@@ -18,7 +18,7 @@ acts = eng.fill_actions(K, 1)
 if len(sys.argv) > 1 and sys.argv[1] == "noop":
   acts.zero_()
 lib = N.lib()
-buf = (C.c_ulonglong * (4096 * 12))()
+buf = (C.c_ulonglong * (4096 * 16))()
 eng.step_n(acts); torch.cuda.synchronize()
 lib.sgw_debug_fm_prof(buf, 1)
 import time
@@ -27,10 +27,13 @@ eng.step_n(acts); torch.cuda.synchronize()
 print("%.2f us per round (profiled build)" % ((time.perf_counter() - t0) / K * 1e6))
 assert lib.sgw_debug_fm_prof(buf, 1) == 0
 waves = n // 64 * 8
-arr = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 12)[:waves].astype(np.float64)
-served = (np.frombuffer(buf, dtype=np.uint64).reshape(4096, 12)[:waves, 11] >> np.uint64(32)).astype(np.float64)
+arr = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 16)[:waves].astype(np.float64)
+served = (np.frombuffer(buf, dtype=np.uint64).reshape(4096, 16)[:waves, 11] >> np.uint64(32)).astype(np.float64)
 arr[:, 11] -= served * 4294967296.0
 print("env-spreads served per wave per round: %.2f (per workgroup and play: %.1f of 64 envs)" % (served.sum() / waves / K, served.sum() / (waves / 8) / K / 3))
+cnt = arr[:, 12:16].sum(0); arr = arr[:, :12]
+print("env-spreads by size: <= 32 candidates and <= 32 fire cells %.1f %%, 33-64 candidates %.1f %%, > 64 %.1f %%; mean candidates %.1f" % (
+    100 * cnt[0] / served.sum(), 100 * cnt[1] / served.sum(), 100 * cnt[2] / served.sum(), cnt[3] / served.sum()))
 tot = arr.sum()
 print("cycles per wave per round: %.0f (slowest wave %.0f, fastest %.0f)" % (tot / waves / K, arr.sum(1).max() / K, arr.sum(1).min() / K))
 for k in range(12):
