@@ -51,6 +51,7 @@ struct IslandMa {
   static constexpr int WAVES = 1, LDS_EXTRA = 0;
   static constexpr bool COOPERATIVE = false;
   static constexpr bool ROLLOUT_PIPELINED = false;   // a round is ~10x the output copy: a draining partner wave has nothing to overlap
+  static constexpr bool STEP_REREADS_ARGS = false;   // measured: 39 instead of 88 SGPR spills but 296 instead of 240 registers = one wave per SIMD: 23.9 vs 24.2 us at 65 536 envs, 84.9 vs 70.6 us at 262 144
   static constexpr int ENV_WAVES_MAX = 2;    // env-waves per workgroup (LDS: every output staged must fit 160 KiB)
   static constexpr bool PER_AGENT = true;   // step_type / term_reason / safety are [N, A]
   struct Ctx {};

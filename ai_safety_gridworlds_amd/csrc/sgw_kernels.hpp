@@ -24,6 +24,10 @@ template <class F, class = void> struct has_init_issue : std::false_type {};
 template <class F> struct has_init_issue<F, std::void_t<decltype(&F::init_issue)>> : std::true_type {};
 // fused rollout: the COMPUTING wave re-reads the kernel arguments every step (see the loop) unless the family opts out
 // (`ROLLOUT_KEEPS_ARGS`: measured faster and inside the register budget)
+// one-step kernel: re-read the arguments AFTER the rules for the output phase, so that what only the outputs need (a dozen
+// pointers, the LDS plan) is not held in SGPRs across play() -- for the families whose step kernel spills SGPRs (`STEP_REREADS_ARGS`)
+template <class F, class = void> struct step_rereads : std::false_type {};
+template <class F> struct step_rereads<F, std::void_t<decltype(F::STEP_REREADS_ARGS)>> : std::integral_constant<bool, F::STEP_REREADS_ARGS> {};
 template <class F, class = void> struct rollout_rereads : std::true_type {};
 template <class F> struct rollout_rereads<F, std::void_t<decltype(F::ROLLOUT_KEEPS_ARGS)>> : std::integral_constant<bool, !F::ROLLOUT_KEEPS_ARGS> {};
 template <class F, class = void> struct has_init_args : std::false_type {};
@@ -495,22 +499,34 @@ __global__ __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* ho
     }
     SGW_STAMP(a, 2);
     // ---- this step's outputs and finished-episode returns go into the wave's staging buffer ...
-    const int C = a.sp.A * a.sp.K + 1;
+    KArgs a_out;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (KIND == K_STEP && step_rereads<F>::value) {
+      typedef const KArgs __attribute__((address_space(4))) * KArgsSeg;
+      KArgsSeg seg = (KArgsSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + SGW_KARGS_OFFSET);
+      asm volatile("" : "+s"(seg) : : "memory");
+      a_out = *seg;
+    }
+#endif
+    const KArgs& ae = (KIND == K_STEP && step_rereads<F>::value) ? a_out : a;
+    const Lds l_out = lds_carve(smem, ae.lp, F::LDS_EXTRA, wv * NB + (NB > 1 ? (t & 1) : 0));
+    const Lds& le = (KIND == K_STEP && step_rereads<F>::value) ? l_out : l;
+    const int C = ae.sp.A * ae.sp.K + 1;
     const bool last_t = (t == TT - 1);
-    const bool writes = a.write_every != 0 || last_t;
+    const bool writes = ae.write_every != 0 || last_t;
     bool acc_any = false;
     if (leader) {
       if constexpr (!PIPE) lds_wave_sync();                 // the previous step's cooperative reads are done (program order)
-      if (a.need & LN_RETURNS) {
+      if (ae.need & LN_RETURNS) {
         acc_any = __ballot(over_now && real) != 0ull;       // wave-uniform
         if (acc_any) {
 #pragma unroll
-          for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_a, l.trash, lane, C, F::slot(a.sp, u)) = over_now ? s.cum[u] : 0.0;
-          l.vec_a[lane * C + C - 1] = over_now ? 1.0 : 0.0;
+          for (int u = 0; u < F::NU; ++u) *stage_cell(le.vec_a, le.trash, lane, C, F::slot(ae.sp, u)) = over_now ? s.cum[u] : 0.0;
+          le.vec_a[lane * C + C - 1] = over_now ? 1.0 : 0.0;
         }
-        if constexpr (PIPE) { if (lane == 0) l.flag[0] = acc_any ? 1u : 0u; }
+        if constexpr (PIPE) { if (lane == 0) le.flag[0] = acc_any ? 1u : 0u; }
       }
-      if (writes) emit_stage<F, PIPE>(s, r, discount, a, l, lane);
+      if (writes) emit_stage<F, PIPE>(s, r, discount, ae, le, lane);
     }
     // ... and leave it: the pair's draining wave takes the buffer over at the barrier (pipelined rollout), or this wave
     // copies it out itself
@@ -519,12 +535,13 @@ __global__ __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* ho
     } else if (leader) {
       lds_wave_sync();
       if (writes) {
-        emit_drain<F, false>(a, l, env0, lane, a.write_every != 0 ? (long long)t * a.n_pad : 0, true, true);
-        emit_small_direct<F>(s, discount, a, env0, lane, a.write_every != 0 ? (long long)t * a.n_pad : 0, true);
+        emit_drain<F, false>(ae, le, env0, lane, ae.write_every != 0 ? (long long)t * ae.n_pad : 0, true, true);
+        emit_small_direct<F>(s, discount, ae, env0, lane, ae.write_every != 0 ? (long long)t * ae.n_pad : 0, true);
       }
-      SGW_STAMP(a, 3);
-      if (acc_any) accumulate_returns(a, l, wave_id, env0, lane);
+      SGW_STAMP(ae, 3);
+      if (acc_any) accumulate_returns(ae, le, wave_id, env0, lane);
     }
+    if constexpr (KIND == K_STEP && step_rereads<F>::value) { if (leader) F::store(s, ae, env); return; }
   }
   SGW_STAMP(a, 4);
   if (leader) F::store(s, a, env);

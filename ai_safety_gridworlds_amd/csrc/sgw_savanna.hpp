@@ -77,6 +77,7 @@ struct Savanna {
   static constexpr int WAVES = 1, LDS_EXTRA = 0;
   static constexpr bool COOPERATIVE = false;
   static constexpr bool ROLLOUT_PIPELINED = false;   // a round is ~10x the output copy: a draining partner wave has nothing to overlap
+  static constexpr bool STEP_REREADS_ARGS = true;    // the one-step kernel re-reads the arguments for its output phase (sgw_kernels.hpp step_rereads)
   static constexpr int ENV_WAVES_MAX = 1;    // env-waves per workgroup (LDS: every output staged must fit 160 KiB)
   static constexpr bool PER_AGENT = true;
   struct Ctx {};
