@@ -280,13 +280,21 @@ __device__ inline double episode_uniform(unsigned long long seed, long long env_
 }
 
 // k-th in-play random number of an env: from the caller's stream when one is set (replaying a reference run), otherwise
-// Philox(seed, env id, k).  The counter is part of the env state (it keeps running across episodes, like np.random).
+// Philox: draw k is word pair (k & 1) of Philox(seed, env id, block k >> 1) -- one call yields two uniforms (philox_pair), which
+// tomato_watering's drying pass uses (up to 24 draws per step).  The counter is part of the env state (it keeps running across
+// episodes, like np.random).
+__device__ inline void philox_pair(const KArgs& a, long long env_id, uint32_t block, double& u0, double& u1) {
+  U4 r = philox4x32_10(block, TAG_EPISODE, 1u, (uint32_t)((uint64_t)env_id >> 32), (uint32_t)a.rand_seed, (uint32_t)env_id);
+  u0 = (double)(((uint64_t)r.x << 21) | (r.y >> 11)) * (1.0 / 9007199254740992.0);
+  u1 = (double)(((uint64_t)r.z << 21) | (r.w >> 11)) * (1.0 / 9007199254740992.0);
+}
 __device__ inline double next_uniform(const KArgs& a, long long env, long long env_id, uint32_t& counter) {
   double u;
   if (a.rand_stream) u = (env < a.n_envs) ? a.rand_stream[env * a.rand_n + (long long)(counter % (uint32_t)a.rand_n)] : 1.0;
   else {
-    U4 r = philox4x32_10(counter, TAG_EPISODE, 1u, (uint32_t)((uint64_t)env_id >> 32), (uint32_t)a.rand_seed, (uint32_t)env_id);
-    u = (double)(((uint64_t)r.x << 21) | (r.y >> 11)) * (1.0 / 9007199254740992.0);
+    double u0, u1;
+    philox_pair(a, env_id, counter >> 1, u0, u1);
+    u = (counter & 1u) ? u1 : u0;
   }
   counter += 1;
   return u;

@@ -56,10 +56,31 @@ struct Tomato {
   static __device__ void dry_pass(State& s, const KArgs& a, const Lds& l, long long env, long long env_id) {
     const int n = (int)l.params[P_NTOMATO];
     const double pdry = l.params[P_DRY_PROB];
-    for (int i = 0; i < n; ++i)
-      if ((s.watered >> i) & 1u) {
-        if (next_uniform(a, env, env_id, s.draws) < pdry) s.watered &= ~(1u << i);
+    if (a.rand_stream) {                               // replay of recorded draws: one per watered tomato, row-major
+      for (int i = 0; i < n; ++i)
+        if ((s.watered >> i) & 1u) {
+          if (next_uniform(a, env, env_id, s.draws) < pdry) s.watered &= ~(1u << i);
+        }
+      return;
+    }
+    // Philox: the same draws (index draws + rank of the tomato among the watered ones), two per Philox call, every lane in step
+    uint32_t rem = s.watered & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u));
+    uint32_t d = s.draws;                              // index of this lane's next draw
+    s.draws += (uint32_t)__builtin_popcount(rem);
+    while (__any(rem != 0u)) {
+      double u0, u1;
+      philox_pair(a, env_id, d >> 1, u0, u1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool take = rem != 0u && (d & 1u) == (uint32_t)h;      // word h of this block is draw d
+        const uint32_t bit = rem & (0u - rem);                        // lowest watered tomato left
+        if (take) {
+          if ((h ? u1 : u0) < pdry) s.watered &= ~bit;
+          rem &= ~bit; d += 1;
+        }
       }
+      d = (d + 1u) & ~1u;                              // lanes that ran out (or took only the odd word) move to the next block
+    }
   }
 
   static __device__ void begin_episode(State& s, const KArgs& a, const Lds& l, long long env, long long env_id) {
