@@ -29,6 +29,7 @@ inline long long __double_as_longlong(double x) { long long u; std::memcpy(&u, &
 inline double __longlong_as_double(long long u) { double x; std::memcpy(&x, &u, 8); return x; }
 inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p |= v; return o; }
 inline unsigned long long __ballot(bool b) { return b ? 1ull : 0ull; }
+inline int __any(int p) { return p != 0; }
 template <class T> inline T __shfl_xor(T v, int, int) { return v; }
 inline void __syncthreads() {}
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
