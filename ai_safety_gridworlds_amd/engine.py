@@ -238,7 +238,9 @@ class BatchedEngine(object):
     agent_pos = self._bufs["agent_pos"] if agent_pos is None else agent_pos
     outside_chr = outside_chr or getattr(sp, "what_lies_outside", '#')
     L = len(sp.layer_chars)
-    chars, _ = self._layer_tables
+    if not hasattr(self, "_layer_chars_dev"):        # (observe_layers builds its own tables only for board-derived layers)
+      self._layer_chars_dev = torch.tensor([ord(c) for c in sp.layer_chars], dtype=torch.uint8, device=self.device)
+    chars = self._layer_chars_dev
     vb = int(self._lib.sgw_view_bytes(self._h))
     out = torch.empty((self.n_envs, vb * L), dtype=torch.uint8, device=self.device)
     N.check(self._lib.sgw_agent_layer_views(self._h, layers.data_ptr(), agent_pos.data_ptr(), self._view_flags(agent_flags), chars.data_ptr(), L,

@@ -29,12 +29,49 @@ from .gridworld_gym_env import DiscreteActionSpace, BoxObservationSpace
 OUTS = ("board", "obs_board", "reward", "cumulative", "step_type", "term_reason", "discount", "metrics", "frame",
         "agent_pos", "agent_flags", "hidden", "actual_action")
 
+# info keys of the reference wrapper (gridworld_zoo_parallel_env.py:53-64; pycolab_interface_ma.py:37-39)
+INFO_OBSERVED_REWARD = "observed_reward"
+INFO_DISCOUNT = "discount"
+INFO_OBSERVATION_DIRECTION = "observation_direction"
+INFO_ACTION_DIRECTION = "action_direction"
+INFO_OBSERVATION_COORDINATES = "info_observation_coordinates"
+INFO_OBSERVATION_LAYERS_DICT = "info_observation_layers_dict"
+INFO_OBSERVATION_LAYERS_ORDER = "info_observation_layers_order"
+INFO_OBSERVATION_LAYERS_CUBE = "info_observation_layers_cube"
+INFO_AGENT_OBSERVATIONS = "info_agent_observations"
+INFO_AGENT_OBSERVATION_COORDINATES = "info_agent_observation_coordinates"
+INFO_AGENT_OBSERVATION_LAYERS_DICT = "info_agent_observation_layers_dict"
+INFO_AGENT_OBSERVATION_LAYERS_ORDER = "info_agent_observation_layers_order"
+INFO_AGENT_OBSERVATION_LAYERS_CUBE = "info_agent_observation_layers_cube"
+
 
 class GridworldZooParallelEnv(_Base):
   metadata = {"render.modes": ["human", "ansi", "rgb_array"], "name": "ai_safety_gridworlds_amd"}
 
-  def __init__(self, env_name, use_transitions=False, flatten_observations=False, ascii_observation_format=True,
-               test_death=False, test_death_probability=0.33, np_random=None, seed=None, device="cuda:0", **kwargs):
+  def __init__(self, env_name, use_transitions=False, render_animation_delay=0.1, flatten_observations=False,
+               ascii_observation_format=True, object_coordinates_in_observation=True, layers_in_observation=True,
+               occlusion_in_layers=False, layers_order_in_cube=[], layers_order_in_cube_per_agent={},
+               ascii_attributes_format=False, attribute_coordinates_in_observation=True, layers_in_attribute_observation=False,
+               occlusion_in_atribute_layers=False, observable_attribute_categories=None, observable_attribute_value_mapping=None,
+               use_multi_discrete_action_space=False, np_random=None, seed=None, test_death=False, test_death_probability=0.33,
+               pre_reset_callback=None, post_reset_callback=None, pre_step_callback=None, post_step_callback=None,
+               render_mode=None, device="cuda:0", **kwargs):
+    """Same parameters as the reference wrapper (gridworld_zoo_parallel_env.py:100-135).  The observable-attribute parameters are
+    accepted and unused (no environment of the reference defines observable attributes); `use_multi_discrete_action_space` is
+    refused."""
+    if use_multi_discrete_action_space:
+      raise NotImplementedError("use_multi_discrete_action_space is not implemented")
+    if occlusion_in_layers:
+      raise NotImplementedError("occlusion_in_layers=True: the reference's branch (safety_game_moma.py:607-618) raises NameError "
+                                "at this snapshot")
+    self.render_mode = render_mode
+    self._object_coordinates_in_observation = object_coordinates_in_observation
+    self._layers_in_observation = layers_in_observation
+    self._occlusion_in_layers = occlusion_in_layers
+    self._layers_order_in_cube = layers_order_in_cube
+    self._layers_order_in_cube_per_agent = layers_order_in_cube_per_agent
+    self._pre_reset_callback, self._post_reset_callback = pre_reset_callback, post_reset_callback
+    self._pre_step_callback, self._post_step_callback = pre_step_callback, post_step_callback
     self._env_name = env_name
     self._env = BatchedSafetyEnvironment(env_name, num_envs=1, device=device, outputs=OUTS, **kwargs)
     sp = self.spec_ = self._env.spec
@@ -125,11 +162,51 @@ class GridworldZooParallelEnv(_Base):
       states[a] = st.flatten() if self._flatten_observations else st
     return o, states
 
-  def _infos(self, o):
+  def _layer_infos(self, o):
+    """The observation-derived entries of `_process_observation` (zoo.py:286-316): computed once per step, shared by the agents."""
+    sp = self.spec_
+    out = {}
+    need_layers = (self._layers_in_observation or self._object_coordinates_in_observation or self._layers_order_in_cube is not None
+                   or (self._ma and self._layers_order_in_cube_per_agent is not None))
+    if sp.scalar or not need_layers:
+      return out
+    lay = self._env.engine.observe_layers()
+    glob = lay[0].cpu().numpy().astype(bool)
+    layers = {c: glob[i] for i, c in enumerate(sp.layer_chars)}                 # observation['layers'] (unoccluded)
+    out["layers"] = layers
+    if self._object_coordinates_in_observation:                                  # safety_game_moma.py:583-603
+      out["coords"] = {c: [tuple(x) for x in np.argwhere(layers[c]).tolist()] for c in layers}
+    if self._layers_order_in_cube is not None:                                   # :621-672
+      order = list(self._layers_order_in_cube) or sorted(layers.keys())
+      zero = np.zeros_like(glob[0])
+      out["order"], out["cube"] = order, np.stack([layers.get(c, zero) for c in order], axis=0)
+    if self._ma:                                                                 # agent_perspectives_with_layers (:430-525)
+      cubes = [v[0].cpu().numpy().astype(bool) for v in self._env.engine.agent_layer_views(layers=lay)]
+      out["agent_layers"], out["agent_coords"], out["agent_order"], out["agent_cube"] = {}, {}, {}, {}
+      for i, a in enumerate(self.possible_agents):
+        ch = self.agent_name_mapping[a]
+        al = {c: cubes[self._slots[i]][j] for j, c in enumerate(sp.layer_chars)}
+        out["agent_layers"][a] = al
+        if self._object_coordinates_in_observation:                              # calculate_agents_observation_coordinates (:528-580)
+          me = np.argwhere(al[ch]) if ch in al else []
+          if len(me) > 0:
+            ay, ax = int(me[0][0]), int(me[0][1])
+            out["agent_coords"][a] = {c: [(int(x) - ax, int(y) - ay) for y, x in np.argwhere(al[c]).tolist()] for c in al}
+          else:
+            out["agent_coords"][a] = []                                          # the agent is not in its own layers
+        if self._layers_order_in_cube_per_agent is not None:
+          order = list(self._layers_order_in_cube_per_agent.get(a, [])) or sorted(al.keys())
+          zero = np.zeros_like(cubes[self._slots[i]][0])
+          out["agent_order"][a], out["agent_cube"][a] = order, np.stack([al.get(c, zero) for c in order], axis=0)
+    return out
+
+  def _infos(self, o, states=None):
     sp = self.spec_
     infos = {}
+    li = self._layer_infos(o)
+    flags = o["agent_flags"].reshape(-1)
     for i, a in enumerate(self.possible_agents):
-      info = {"board": self._vm[o["board"]], "ascii_codes": o["board"].copy(),
+      info = {"board": self._vm[o["board"]], "ascii_codes": o["board"].copy(), "ascii": np.vectorize(chr)(o["board"]),
               "metrics_dict": dict(zip(sp.metric_names, o["metrics"].reshape(-1)[:sp.M].tolist())),
               "extra_observations": {}}
       st_all = o["step_type"].reshape(-1)
@@ -142,22 +219,51 @@ class GridworldZooParallelEnv(_Base):
       if self._ma:
         names = sp.agent_dim_names[sp.agent_chars[i]]
         q = self._slots[i]
+        # zoo.py:325-335: directions as the env's observation carries them (Directions LEFT=0 RIGHT=1 UP=2 DOWN=3)
+        info[INFO_OBSERVATION_DIRECTION] = int((flags[q] >> 3) & 3)
+        info[INFO_ACTION_DIRECTION] = int((flags[q] >> 1) & 3)
         info["reward_dict"] = dict(zip(names, o["reward"].reshape(sp.A, sp.K)[q, :len(names)].tolist()))
         info["cumulative_reward_dict"] = dict(zip(names, o["cumulative"].reshape(sp.A, sp.K)[q, :len(names)].tolist()))
         info["info_agent_position"] = tuple(int(x) for x in o["agent_pos"].reshape(sp.A, 2)[q])
+      if "coords" in li:
+        info[INFO_OBSERVATION_COORDINATES] = li["coords"]                        # shared global observation, returned via every agent
+      if self._layers_in_observation and "layers" in li:
+        info[INFO_OBSERVATION_LAYERS_DICT] = li["layers"]
+      if "cube" in li:
+        info[INFO_OBSERVATION_LAYERS_ORDER], info[INFO_OBSERVATION_LAYERS_CUBE] = li["order"], li["cube"]
+      if self._ma and states is not None:                                         # zoo.py:348-359
+        view = states[a]
+        info[INFO_AGENT_OBSERVATIONS] = view[-1] if not self._flatten_observations else view
+        if "agent_layers" in li:
+          if self._layers_in_observation:
+            info[INFO_AGENT_OBSERVATION_LAYERS_DICT] = li["agent_layers"][a]
+          if self._object_coordinates_in_observation:
+            info[INFO_AGENT_OBSERVATION_COORDINATES] = li["agent_coords"][a]
+          if self._layers_order_in_cube_per_agent is not None:
+            info[INFO_AGENT_OBSERVATION_LAYERS_ORDER] = li["agent_order"][a]
+            info[INFO_AGENT_OBSERVATION_LAYERS_CUBE] = li["agent_cube"][a]
       infos[a] = info
     return infos
 
   def reset(self, seed=None, *args, **kwargs):
+    if self._pre_reset_callback is not None:                    # zoo.py:619-622
+      (allow_reset, seed, args, kwargs) = self._pre_reset_callback(seed, *args, **kwargs)
+      if not allow_reset:
+        return
     if seed is not None:
       self.seed(seed=seed)
     ts = self._env.reset()
     self._dones = {a: False for a in self.possible_agents}
     self._test_deads = {a: False for a in self.possible_agents}
     o, states = self._observe(ts, True)
-    return states, self._infos(o)
+    result = (states, self._infos(o, states))
+    if self._post_reset_callback is not None:
+      self._post_reset_callback(*result, seed, *args, **kwargs)
+    return result
 
   def step(self, actions, *args, **kwargs):
+    if self._pre_step_callback is not None:                     # zoo.py:445-446
+      actions = self._pre_step_callback(actions, *args, **kwargs)
     sp = self.spec_
     acts = [0] * sp.A                     # by column of the library's layout (absent agents / the unused second savanna column: 0)
     for i, a in enumerate(self.possible_agents):
@@ -179,7 +285,7 @@ class GridworldZooParallelEnv(_Base):
     ts = self._env.step(torch.tensor(acts, dtype=torch.int8))
     first = int(ts.step_type.reshape(-1)[0].item()) == N.FIRST
     o, states = self._observe(ts, first)
-    infos = self._infos(o)
+    infos = self._infos(o, states)
     st_all = o["step_type"].reshape(-1)
     per_agent = getattr(sp, "per_agent", False)
     if per_agent:
@@ -214,4 +320,7 @@ class GridworldZooParallelEnv(_Base):
         dones.pop(a, None); states.pop(a, None); rewards.pop(a, None)
     self._dones.update(dones)
     truncateds = {a: False for a in dones}
-    return states, rewards, dones, truncateds, infos
+    result = (states, rewards, dones, truncateds, infos)
+    if self._post_step_callback is not None:
+      self._post_step_callback(actions, *result, *args, **kwargs)
+    return result

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Golden values for the PettingZoo-parallel wrapper's per-agent info keys, produced by RUNNING the reference (build container only).
+
+    python tests/golden/make_fixtures_zoo.py
+
+The L5 wrapper itself needs pettingzoo (absent); what `_process_observation` / `_compute_infos` put into `infos[agent]`
+(gridworld_zoo_parallel_env.py:286-376) comes from methods of the L4 multi-agent environment, which run here:
+calculate_observation_coordinates, get_layers_order, calculate_observation_layers_cube, agent_perspectives_with_layers,
+calculate_agents_observation_coordinates (safety_game_moma.py:430-700) and the observation's direction / layer entries.
+One island_navigation_ex_ma level-9 env (default flags: rotating 5x5 views), both agents stepped every round with the Philox
+action stream; written as data to tests/golden/zoo_island_ma_L9.npz (+ JSON strings for the coordinate dicts).
+Same stand-ins and the one documented patch as make_fixtures_ima.py.
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+SEED = 0x5AFE
+
+
+def main():
+  import tempfile
+  os.chdir(tempfile.mkdtemp(prefix="sgw_fixtures_"))
+  sys.dont_write_bytecode = True
+  sys.path.insert(0, "/root/reference")
+  sys.path.insert(0, os.path.join(HERE, "standins"))
+  sys.path.insert(0, REPO)
+  import numpy as np
+  from ai_safety_gridworlds_amd import philox
+  from ai_safety_gridworlds.environments.shared.rl import pycolab_interface_ma
+  _orig = pycolab_interface_ma.EnvironmentMa._update_for_game_step
+  def _patched(self, observations, reward, discount):      # the documented patch (make_fixtures_ima.py)
+    if self._last_reward is None:
+      self._last_reward = self._default_reward
+    return _orig(self, observations, reward, discount)
+  pycolab_interface_ma.EnvironmentMa._update_for_game_step = _patched
+  from ai_safety_gridworlds.environments import island_navigation_ex_ma as m
+
+  T, seed = 24, 4242
+  AG = ['1', '2']
+  m.IslandNavigationEnvironmentExMa(seed=1, level=9)          # every recorded stream is a later construction of the class
+  # random walks end in the water quickly (an agent that steps into it terminates): take, among the first 200 Philox env ids, the
+  # stream that keeps both agents alive longest and record exactly that many rounds
+  best = (-1, 0)
+  for cand in range(200):
+    acts = np.stack([philox.actions(SEED, np.arange(cand, cand + 1), np.arange(T), 0, 5, agent=a)[:, 0] for a in range(2)], axis=-1).astype(np.int8)
+    probe = m.IslandNavigationEnvironmentExMa(seed=seed, level=9, max_iterations=100)
+    probe.reset()
+    alive = 0
+    for t in range(T):
+      ts = probe.step({ch: {'step': int(acts[t, i])} for i, ch in enumerate(AG)})
+      if not all(int(ts.step_type[ch]) == 1 for ch in AG):
+        break
+      alive = t + 1
+    if alive > best[0]:
+      best = (alive, cand)
+  T, env_id = best
+  acts = np.stack([philox.actions(SEED, np.arange(env_id, env_id + 1), np.arange(T), 0, 5, agent=a)[:, 0] for a in range(2)], axis=-1).astype(np.int8)
+  env = m.IslandNavigationEnvironmentExMa(seed=seed, level=9, max_iterations=100)
+  rows = dict(cube=[], obs_dir=[], act_dir=[], agent_ascii=[], agent_board=[], agent_cube=[], board=[])
+  coords, agent_coords, orders, agent_orders = [], [], [], []
+
+  def record(ts):
+    obs = ts.observation
+    rows["board"].append(np.array(obs["ascii_codes"], np.uint8, copy=True))       # the renderer reuses its buffer: copy
+    c = env.calculate_observation_coordinates(obs, occlusion_in_layers=False, ascii=True)
+    coords.append({k: [list(map(int, x)) for x in v] for k, v in c.items()})
+    order = env.get_layers_order(obs, occlusion_in_layers=False, layers_order=[])
+    orders.append("".join(order))
+    rows["cube"].append(env.calculate_observation_layers_cube(obs, occlusion_in_layers=False, layers_order=order).astype(np.uint8))
+    rows["obs_dir"].append([int(obs["observation_direction"][ch]) for ch in AG])
+    rows["act_dir"].append([int(obs["action_direction"][ch]) for ch in AG])
+    ao = env.agent_perspectives_with_layers(obs, include_layers=True, ascii=True)
+    rows["agent_ascii"].append(np.stack([np.vectorize(ord)(ao[ch]["ascii"]).astype(np.uint8) for ch in AG]))
+    rows["agent_board"].append(np.stack([np.array(ao[ch]["board"], np.float32, copy=True) for ch in AG]))
+    ac = env.calculate_agents_observation_coordinates(obs, ao, occlusion_in_layers=False, ascii=True)
+    agent_coords.append({ch: {k: [list(map(int, x)) for x in v] for k, v in ac[ch].items()} for ch in AG})
+    per_order, per_cube = [], []
+    for ch in AG:
+      o = env.get_layers_order(ao[ch], occlusion_in_layers=False, layers_order=[])
+      per_order.append("".join(o))
+      per_cube.append(env.calculate_observation_layers_cube(ao[ch], occlusion_in_layers=False, layers_order=o).astype(np.uint8))
+    agent_orders.append(per_order)
+    rows["agent_cube"].append(np.stack(per_cube))
+
+  ts = env.reset()
+  record(ts)
+  for t in range(T):
+    ts = env.step({ch: {'step': int(acts[t, i])} for i, ch in enumerate(AG)})
+    assert all(int(ts.step_type[ch]) == 1 for ch in AG), ("the stream must stay inside one episode", t, [int(ts.step_type[ch]) for ch in AG])
+    record(ts)
+  rec = {k: np.asarray(v) for k, v in rows.items()}
+  rec.update(actions=acts, seed=np.array(seed), philox_env_id=np.array(env_id), coords_json=np.array(json.dumps(coords)), agent_coords_json=np.array(json.dumps(agent_coords)),
+             orders=np.array("|".join(orders)), agent_orders=np.array("|".join(",".join(p) for p in agent_orders)))
+  np.savez_compressed(os.path.join(HERE, "zoo_island_ma_L9.npz"), **rec)
+  print("orders", orders[0], agent_orders[0], "cube", rec["cube"].shape, "agent cube", rec["agent_cube"].shape, "dirs", rows["obs_dir"][-1], rows["act_dir"][-1])
+  print("agent coords sample", json.dumps(agent_coords[3])[:300])
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,76 @@
+"""The PettingZoo-parallel facade's per-agent info keys == what the reference wrapper's `_process_observation` / `_compute_infos`
+(gridworld_zoo_parallel_env.py:286-376) put there, i.e. the results of the L4 environment's own methods, which
+tests/golden/make_fixtures_zoo.py recorded by running the reference: global layers / coordinates / order / cube, directions,
+agent-centric ascii and value boards, per-agent layer dicts, relative coordinates and cubes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ai_safety_gridworlds_amd.helpers import gridworld_zoo_parallel_env as Z
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def test_zoo_parallel_infos_match_reference_fixture():
+  fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoo_island_ma_L9.npz"))
+  coords, agent_coords = json.loads(str(fx["coords_json"])), json.loads(str(fx["agent_coords_json"]))
+  orders = str(fx["orders"]).split("|")
+  agent_orders = [p.split(",") for p in str(fx["agent_orders"]).split("|")]
+  acts = fx["actions"]
+  names = ["agent_1", "agent_2"]
+  env = Z.GridworldZooParallelEnv("island_navigation_ex_ma", level=9, max_iterations=100, seed=int(fx["seed"]))
+  envf = Z.GridworldZooParallelEnv("island_navigation_ex_ma", level=9, max_iterations=100, seed=int(fx["seed"]), ascii_observation_format=False)
+
+  def check(t, obs, infos, obs_f, infos_f):
+    for i, a in enumerate(names):
+      info = infos[a]
+      assert np.array_equal(info["ascii_codes"], fx["board"][t]), (t, a)
+      assert info[Z.INFO_OBSERVATION_DIRECTION] == fx["obs_dir"][t][i] and info[Z.INFO_ACTION_DIRECTION] == fx["act_dir"][t][i], (t, a)
+      assert info[Z.INFO_OBSERVATION_LAYERS_ORDER] == list(orders[t])
+      assert np.array_equal(info[Z.INFO_OBSERVATION_LAYERS_CUBE], fx["cube"][t].astype(bool)), (t, a)
+      assert {k: [list(x) for x in v] for k, v in info[Z.INFO_OBSERVATION_COORDINATES].items()} == coords[t], (t, a)
+      assert sorted(info[Z.INFO_OBSERVATION_LAYERS_DICT]) == sorted(orders[t])
+      want_view = np.vectorize(chr)(fx["agent_ascii"][t][i])
+      assert np.array_equal(info[Z.INFO_AGENT_OBSERVATIONS], want_view), (t, a)
+      assert np.array_equal(obs[a][0], want_view)
+      assert np.array_equal(infos_f[a][Z.INFO_AGENT_OBSERVATIONS], fx["agent_board"][t][i]), (t, a)      # value-mapped float board
+      assert info[Z.INFO_AGENT_OBSERVATION_LAYERS_ORDER] == list(agent_orders[t][i])
+      assert np.array_equal(info[Z.INFO_AGENT_OBSERVATION_LAYERS_CUBE], fx["agent_cube"][t][i].astype(bool)), (t, a)
+      got_c = info[Z.INFO_AGENT_OBSERVATION_COORDINATES]
+      assert {k: [list(x) for x in v] for k, v in got_c.items()} == agent_coords[t][a[-1]], (t, a)
+      lay = info[Z.INFO_AGENT_OBSERVATION_LAYERS_DICT]
+      for j, c in enumerate(agent_orders[t][i]):
+        assert np.array_equal(lay[c], fx["agent_cube"][t][i][j].astype(bool)), (t, a, c)
+
+  obs, infos = env.reset()
+  obs_f, infos_f = envf.reset()
+  check(0, obs, infos, obs_f, infos_f)
+  for t in range(acts.shape[0]):
+    a = {n: int(acts[t, i]) for i, n in enumerate(names)}
+    obs, rewards, terms, truncs, infos = env.step(a)
+    obs_f, _, _, _, infos_f = envf.step(a)
+    check(t + 1, obs, infos, obs_f, infos_f)
+    assert not any(terms.values())
+  env.close(); envf.close()
+
+
+def test_zoo_parallel_callbacks_and_custom_orders():
+  calls = []
+  env = Z.GridworldZooParallelEnv(
+      "island_navigation_ex_ma", level=9, seed=3, layers_order_in_cube=['1', 'W', 'Z'], layers_order_in_cube_per_agent={"agent_2": ['2', 'Z']},
+      pre_reset_callback=lambda seed, *a, **k: (calls.append("pre_reset") or True, seed, a, k),
+      post_reset_callback=lambda *a, **k: calls.append("post_reset"),
+      pre_step_callback=lambda actions, *a, **k: (calls.append("pre_step") or actions),
+      post_step_callback=lambda *a, **k: calls.append("post_step"))
+  obs, infos = env.reset()
+  obs, rewards, terms, truncs, infos = env.step({"agent_1": 0, "agent_2": 0})
+  assert calls == ["pre_reset", "post_reset", "pre_step", "post_step"]
+  i1, i2 = infos["agent_1"], infos["agent_2"]
+  assert i1[Z.INFO_OBSERVATION_LAYERS_ORDER] == ['1', 'W', 'Z'] and i1[Z.INFO_OBSERVATION_LAYERS_CUBE].shape[0] == 3
+  assert not i1[Z.INFO_OBSERVATION_LAYERS_CUBE][2].any()                          # 'Z' does not exist: an all-zero plane
+  assert i2[Z.INFO_AGENT_OBSERVATION_LAYERS_ORDER] == ['2', 'Z'] and i2[Z.INFO_AGENT_OBSERVATION_LAYERS_CUBE].shape == (2, 5, 5)
+  assert i1[Z.INFO_AGENT_OBSERVATION_LAYERS_ORDER] == sorted(i1[Z.INFO_AGENT_OBSERVATION_LAYERS_DICT])   # not listed: every layer
+  env.close()
