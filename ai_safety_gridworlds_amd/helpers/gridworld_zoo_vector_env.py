@@ -12,7 +12,11 @@ helpers/gridworld_zoo_parallel_env.py:429-615) returns for it:
   rewards[agent]     float64 [N, K_agent] in the agent's sorted reward-dimension order (0 at an auto-reset round)
   terminateds[agent] bool [N]: the agent's StepType is LAST or DEAD;  truncateds[agent]: all False
   infos[agent]       device tensors: "step_type" [N], "cumulative_reward" [N, K_agent], "agent_position" [N, 2],
-                     "discount" [N] (NaN = None), "metrics" [N, M], "board" uint8 [N, H, W] (the global board, shared)
+                     "discount" [N] (NaN = None), "metrics" [N, M], "board" uint8 [N, H, W] (the global board, shared),
+                     "observation_direction" / "action_direction" uint8 [N] (Directions LEFT=0 RIGHT=1 UP=2 DOWN=3);
+                     with layers_in_observation=True also the wrapper's layer cubes as tensors (zoo.py:296-316, 337-359):
+                     "info_observation_layers_cube" uint8 [N, L, H, W] (shared) and "info_agent_observation_layers_cube"
+                     uint8 [N, L, h_a, w_a], both in `layers_order` = the sorted layer characters
 A finished env auto-resets at its next round exactly like the reference adapter (the round's actions are discarded); agents of
 the per-agent families that are already LAST/DEAD can be given -1 ("not in the dict").  One round = ONE kernel launch for the
 step (shuffled sequential plays, fire spread, rewards, auto-reset) + one for the agent windows.
@@ -29,7 +33,8 @@ OUTS = ("board", "reward", "cumulative", "step_type", "term_reason", "discount",
 class GridworldZooVectorEnv(object):
   metadata = {"name": "ai_safety_gridworlds_amd_vector"}
 
-  def __init__(self, env_name, num_envs, ascii_observation_format=True, seed=None, device="cuda:0", env_id_base=0, **kwargs):
+  def __init__(self, env_name, num_envs, ascii_observation_format=True, layers_in_observation=False, seed=None, device="cuda:0",
+               env_id_base=0, **kwargs):
     self._env = BatchedSafetyEnvironment(env_name, num_envs=num_envs, device=device, env_id_base=env_id_base, outputs=OUTS, **kwargs)
     sp = self.spec_ = self._env.spec
     if sp.A < 2 and not getattr(sp, "per_agent", False):
@@ -42,6 +47,8 @@ class GridworldZooVectorEnv(object):
     self.agent_name_mapping = dict(zip(self.possible_agents, sp.agent_chars))
     self._k = {a: len(sp.agent_dim_names[c]) for a, c in self.agent_name_mapping.items()}
     self._ascii = bool(ascii_observation_format)
+    self._layers = bool(layers_in_observation)
+    self.layers_order = list(sp.layer_chars)                   # get_layers_order(...) of the reference: sorted layer keys
     self._vm = torch.tensor([sp.native.value_map[i] for i in range(128)], dtype=torch.float32, device=self.device)
     self._acts = torch.zeros((self.num_envs, sp.A), dtype=torch.int8, device=self.device)
     if sp.family == N.FIREMAKER_EX_MA or getattr(sp, "needs_rng", False):
@@ -69,6 +76,11 @@ class GridworldZooVectorEnv(object):
     rew = o["reward"].reshape(self.num_envs, sp.A, sp.K)
     cum = o["cumulative"].reshape(self.num_envs, sp.A, sp.K)
     pos = o["agent_pos"].reshape(self.num_envs, sp.A, 2)
+    flags = o["agent_flags"].reshape(self.num_envs, sp.A)
+    cube = agent_cubes = None
+    if self._layers:                                            # two more launches, tensors stay on the device
+      cube = self._env.engine.observe_layers()
+      agent_cubes = self._env.engine.agent_layer_views(layers=cube)
     obs, rewards, terms, truncs, infos = {}, {}, {}, {}, {}
     for i, a in enumerate(self.possible_agents):
       q, k = self._slots[i], self._k[a]
@@ -79,7 +91,13 @@ class GridworldZooVectorEnv(object):
       terms[a] = s_a >= N.LAST
       truncs[a] = torch.zeros_like(terms[a])
       infos[a] = {"step_type": s_a, "cumulative_reward": cum[:, q, :k], "agent_position": pos[:, q], "discount": o["discount"],
-                  "metrics": o["metrics"][:, :sp.M], "board": o["board"]}
+                  "metrics": o["metrics"][:, :sp.M], "board": o["board"],
+                  "observation_direction": (flags[:, q] >> 3) & 3, "action_direction": (flags[:, q] >> 1) & 3}
+      if self._layers:
+        infos[a]["info_observation_layers_order"] = self.layers_order
+        infos[a]["info_observation_layers_cube"] = cube
+        infos[a]["info_agent_observation_layers_order"] = self.layers_order
+        infos[a]["info_agent_observation_layers_cube"] = agent_cubes[q]
     return obs, rewards, terms, truncs, infos
 
   def reset(self, mask=None):

@@ -74,3 +74,33 @@ def test_zoo_parallel_callbacks_and_custom_orders():
   assert i2[Z.INFO_AGENT_OBSERVATION_LAYERS_ORDER] == ['2', 'Z'] and i2[Z.INFO_AGENT_OBSERVATION_LAYERS_CUBE].shape == (2, 5, 5)
   assert i1[Z.INFO_AGENT_OBSERVATION_LAYERS_ORDER] == sorted(i1[Z.INFO_AGENT_OBSERVATION_LAYERS_DICT])   # not listed: every layer
   env.close()
+
+
+def test_zoo_vector_layer_cubes_equal_the_single_env_facade():
+  """The batched facade's cubes (device tensors) == the one-env facade's, env by env, over a few rounds."""
+  import torch
+  from ai_safety_gridworlds_amd.helpers.gridworld_zoo_vector_env import GridworldZooVectorEnv
+  n = 3
+  vec = GridworldZooVectorEnv("island_navigation_ex_ma", num_envs=n, level=9, seed=11, layers_in_observation=True)
+  singles = [Z.GridworldZooParallelEnv("island_navigation_ex_ma", level=9, seed=11 + i) for i in range(n)]
+  vobs, vinfos = vec.reset()
+  sres = [e.reset() for e in singles]
+  rng = np.random.default_rng(0)
+  for t in range(6):
+    for i in range(n):
+      for a in ("agent_1", "agent_2"):
+        info = sres[i][-1][a]
+        assert info[Z.INFO_OBSERVATION_LAYERS_ORDER] == vinfos[a]["info_observation_layers_order"]
+        assert np.array_equal(info[Z.INFO_OBSERVATION_LAYERS_CUBE], vinfos[a]["info_observation_layers_cube"][i].cpu().numpy().astype(bool))
+        assert np.array_equal(info[Z.INFO_AGENT_OBSERVATION_LAYERS_CUBE], vinfos[a]["info_agent_observation_layers_cube"][i].cpu().numpy().astype(bool))
+        assert info[Z.INFO_OBSERVATION_DIRECTION] == int(vinfos[a]["observation_direction"][i])
+        assert info[Z.INFO_ACTION_DIRECTION] == int(vinfos[a]["action_direction"][i])
+    acts = rng.integers(0, 5, size=(n, 2))
+    if any(any(r[2].values()) for r in sres if len(r) == 5):
+      break                                                    # an agent finished: the single-env facade drops it from its dicts
+    vobs, _, _, _, vinfos = vec.step({"agent_1": torch.tensor(acts[:, 0], dtype=torch.int8, device=vec.device),
+                                      "agent_2": torch.tensor(acts[:, 1], dtype=torch.int8, device=vec.device)})
+    sres = [e.step({"agent_1": int(acts[i, 0]), "agent_2": int(acts[i, 1])}) for i, e in enumerate(singles)]
+  vec.close()
+  for e in singles:
+    e.close()
