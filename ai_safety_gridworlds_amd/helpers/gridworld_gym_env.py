@@ -249,6 +249,29 @@ class GridworldGymEnv(_Base):
           info["info_observation_layers_cube"] = np.stack([layers.get(c, zero) for c in order], axis=0)
         else:
           info["info_observation_layers_cube"] = np.stack([ascii_board == c for c in order], axis=0)
+      if self._ma:                                                # gym_env.py:373-384, 428-439: the controlled agent's own window
+        ch = sp.agent_chars[self._agent_index]
+        flags = int(o["agent_flags"].reshape(-1)[ai])
+        info["observation_direction"], info["action_direction"] = (flags >> 3) & 3, (flags >> 1) & 3
+        view = self._env.engine.agent_views()[ai][0].cpu().numpy()
+        info["info_agent_observations"] = np.vectorize(chr)(view) if self._ma_ascii else self._vm[view]
+        if lay is not None:
+          cube = self._env.engine.agent_layer_views()[ai][0].cpu().numpy().astype(bool)
+          al = {c: cube[j] for j, c in enumerate(sp.layer_chars)}
+          if self._layers_in_observation:
+            info["info_agent_observation_layers_dict"] = al
+          if self._object_coordinates_in_observation:             # calculate_agents_observation_coordinates (safety_game_moma.py:528-580)
+            me = np.argwhere(al[ch]) if ch in al else []
+            if len(me) > 0:
+              ay, ax = int(me[0][0]), int(me[0][1])
+              info["info_agent_observation_coordinates"] = {c: [(int(x) - ax, int(y) - ay) for y, x in np.argwhere(al[c]).tolist()] for c in al}
+            else:
+              info["info_agent_observation_coordinates"] = []
+          if self._layers_order_in_cube is not None:              # the SAME order parameter as the global cube (gym_env.py:382-384)
+            order = list(self._layers_order_in_cube) or sorted(al.keys())
+            zero = np.zeros_like(cube[0])
+            info["info_agent_observation_layers_order"] = order
+            info["info_agent_observation_layers_cube"] = np.stack([al.get(c, zero) for c in order], axis=0)
     if sp.name == "island_navigation_ex":
       info["safety"] = int(o["safety"])
     return info

@@ -104,3 +104,23 @@ def test_zoo_vector_layer_cubes_equal_the_single_env_facade():
   vec.close()
   for e in singles:
     e.close()
+
+
+@pytest.mark.parametrize("agent", ["1", "2"])
+def test_gym_facade_agent_observation_infos_at_reset(agent):
+  """GridworldGymEnv over a multi-agent env controls ONE agent (gym_env.py:373-384, 428-439): its agent-centric info keys at
+  reset == the reference fixture's slot 0 for that agent."""
+  from ai_safety_gridworlds_amd.helpers.gridworld_gym_env import GridworldGymEnv
+  fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoo_island_ma_L9.npz"))
+  agent_coords = json.loads(str(fx["agent_coords_json"]))
+  i = int(agent) - 1
+  env = GridworldGymEnv("island_navigation_ex_ma", level=9, max_iterations=100, seed=int(fx["seed"]), agent_character=agent,
+                        layers_order_in_cube=[])
+  state, info = env.reset()
+  assert np.array_equal(info["info_agent_observations"], np.vectorize(chr)(fx["agent_ascii"][0][i]))
+  assert info["observation_direction"] == fx["obs_dir"][0][i] and info["action_direction"] == fx["act_dir"][0][i]
+  assert info["info_agent_observation_layers_order"] == list(str(fx["agent_orders"]).split("|")[0].split(",")[i])
+  assert np.array_equal(info["info_agent_observation_layers_cube"], fx["agent_cube"][0][i].astype(bool))
+  assert {k: [list(x) for x in v] for k, v in info["info_agent_observation_coordinates"].items()} == agent_coords[0][agent]
+  assert np.array_equal(info["info_observation_layers_cube"], fx["cube"][0].astype(bool))
+  env.close()
