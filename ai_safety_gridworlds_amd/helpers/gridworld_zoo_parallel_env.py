@@ -70,6 +70,8 @@ class GridworldZooParallelEnv(_Base):
     self._occlusion_in_layers = occlusion_in_layers
     self._layers_order_in_cube = layers_order_in_cube
     self._layers_order_in_cube_per_agent = layers_order_in_cube_per_agent
+    self._observable_attribute_categories = (["expression", "action_direction", "observation_direction", "numeric_message", "public_metrics"]
+                                             if observable_attribute_categories is None else list(observable_attribute_categories))
     self._pre_reset_callback, self._post_reset_callback = pre_reset_callback, post_reset_callback
     self._pre_step_callback, self._post_step_callback = pre_step_callback, post_step_callback
     self._env_name = env_name
@@ -200,10 +202,44 @@ class GridworldZooParallelEnv(_Base):
           out["agent_order"][a], out["agent_cube"][a] = order, np.stack([al.get(c, zero) for c in order], axis=0)
     return out
 
+  def _shared_infos(self, o):
+    """Observation keys the wrapper passes through to every agent's info unchanged (zoo.py:378-381): for a multi-agent env they
+    are dicts over the agent characters (safety_game_moma.py:1255-1379)."""
+    sp = self.spec_
+    out = {}
+    if not self._ma:
+      return out
+    ds = {k: v[0].cpu().numpy() for k, v in self._env.engine.derived_stats().items()}    # computed on the device, numpy order
+    cum = o["cumulative"].reshape(sp.A, sp.K)
+    per = lambda f: {c: f(self._slots[i], len(sp.agent_dim_names[c])) for i, c in enumerate(sp.agent_chars)}
+    out["cumulative_reward"] = per(lambda q, k: cum[q, :k].astype(np.float64).copy())
+    out["average_reward"] = per(lambda q, k: ds["average_reward"][q, :k].astype(np.float64))
+    for key in ("gini_index", "cumulative_gini_index", "mo_variance", "cumulative_mo_variance", "average_mo_variance"):
+      out[key] = per(lambda q, k, key=key: np.float64(ds[key][q]))
+    metrics = o["metrics"].reshape(-1)[:sp.M]
+    mm = np.empty([sp.M, 2], object)
+    for i, name in enumerate(sp.metric_names):
+      mm[i, 0], mm[i, 1] = name, (None if np.isnan(metrics[i]) else metrics[i])
+    out["metrics_matrix"] = mm
+    # ACTUAL_ACTIONS: what each agent that played this round did (safety_game_ma.py:784-788; no policy wrapper changes actions
+    # in the multi-agent envs): the submitted actions of the agents that were alive, nothing on a reset / auto-reset round
+    acted = getattr(self, "_played", None)
+    if acted:
+      out["actual_actions"] = {c: {"step": int(v)} for c, v in acted.items()}
+    # observable attributes (observation_distiller_ex.py:104-141): no environment of the reference sets any, so every category
+    # is an all-zero board, an empty layer dict and a board of empty strings
+    cats = self._observable_attribute_categories
+    zero = np.zeros((sp.H, sp.W), np.uint8)
+    out["agent_attribute_board_ascii_codes"] = {c: zero.copy() for c in cats}
+    out["agent_attribute_layers"] = {c: {} for c in cats}
+    out["agent_attribute_board_ascii"] = {c: np.full((sp.H, sp.W), '', dtype='<U1') for c in cats}
+    return out
+
   def _infos(self, o, states=None):
     sp = self.spec_
     infos = {}
     li = self._layer_infos(o)
+    shared = self._shared_infos(o)
     flags = o["agent_flags"].reshape(-1)
     for i, a in enumerate(self.possible_agents):
       info = {"board": self._vm[o["board"]], "ascii_codes": o["board"].copy(), "ascii": np.vectorize(chr)(o["board"]),
@@ -216,6 +252,11 @@ class GridworldZooParallelEnv(_Base):
           info["extra_observations"]["termination_reason"] = {c: dict(tr) for c in sp.agent_chars}
       elif int(st_all[0]) == N.LAST:
         info["extra_observations"]["termination_reason"] = int(o["term_reason"])
+      for k, v in shared.items():
+        if k == "actual_actions":
+          info["extra_observations"][k] = v
+        else:
+          info[k] = v
       if self._ma:
         names = sp.agent_dim_names[sp.agent_chars[i]]
         q = self._slots[i]
@@ -253,6 +294,7 @@ class GridworldZooParallelEnv(_Base):
     if seed is not None:
       self.seed(seed=seed)
     ts = self._env.reset()
+    self._played = None
     self._dones = {a: False for a in self.possible_agents}
     self._test_deads = {a: False for a in self.possible_agents}
     o, states = self._observe(ts, True)
@@ -285,6 +327,11 @@ class GridworldZooParallelEnv(_Base):
     ts = self._env.step(torch.tensor(acts, dtype=torch.int8))
     first = int(ts.step_type.reshape(-1)[0].item()) == N.FIRST
     o, states = self._observe(ts, first)
+    st_host = o["step_type"].reshape(-1)
+    all_first = bool((st_host[[self._slots[i] for i in range(len(self.possible_agents))]] == N.FIRST).all()) \
+        if getattr(sp, "per_agent", False) else first
+    self._played = None if all_first else {self.agent_name_mapping[a]: acts[self._slots[i]] for i, a in enumerate(self.possible_agents)
+                                           if not self._dones[a] and acts[self._slots[i]] >= 0}
     infos = self._infos(o, states)
     st_all = o["step_type"].reshape(-1)
     per_agent = getattr(sp, "per_agent", False)

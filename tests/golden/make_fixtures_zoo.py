@@ -59,12 +59,28 @@ def main():
   T, env_id = best
   acts = np.stack([philox.actions(SEED, np.arange(env_id, env_id + 1), np.arange(T), 0, 5, agent=a)[:, 0] for a in range(2)], axis=-1).astype(np.int8)
   env = m.IslandNavigationEnvironmentExMa(seed=seed, level=9, max_iterations=100)
-  rows = dict(cube=[], obs_dir=[], act_dir=[], agent_ascii=[], agent_board=[], agent_cube=[], board=[])
+  # the wrapper's constructor applies its default attribute categories and resets once (zoo.py:182-184)
+  CATS = ["expression", "action_direction", "observation_direction", "numeric_message", "public_metrics"]
+  env.set_observable_attribute_categories(CATS, {})
+  env.reset()
+  rows = dict(cube=[], obs_dir=[], act_dir=[], agent_ascii=[], agent_board=[], agent_cube=[], board=[], gini=[], cgini=[], var=[], cvar=[],
+              avar=[], avg=[], cum=[], actual=[], attr_codes_any=[])
   coords, agent_coords, orders, agent_orders = [], [], [], []
 
   def record(ts):
     obs = ts.observation
     rows["board"].append(np.array(obs["ascii_codes"], np.uint8, copy=True))       # the renderer reuses its buffer: copy
+    for key, name in (("gini", "gini_index"), ("cgini", "cumulative_gini_index"), ("var", "mo_variance"), ("cvar", "cumulative_mo_variance"),
+                      ("avar", "average_mo_variance")):
+      rows[key].append([float(obs[name][ch]) for ch in AG])
+    rows["avg"].append([np.asarray(obs["average_reward"][ch], np.float64) for ch in AG])
+    rows["cum"].append([np.asarray(obs["cumulative_reward"][ch], np.float64) for ch in AG])
+    aa = obs["extra_observations"].get("actual_actions", {})
+    rows["actual"].append([int(aa[ch]["step"]) if ch in aa else -1 for ch in AG])
+    assert sorted(obs["agent_attribute_board_ascii_codes"]) == sorted(CATS) and all(v == {} for v in obs["agent_attribute_layers"].values())
+    assert all(a.dtype == np.uint8 and a.shape == obs["ascii_codes"].shape for a in obs["agent_attribute_board_ascii_codes"].values())
+    assert all((a == '').all() for a in obs["agent_attribute_board_ascii"].values())
+    rows["attr_codes_any"].append(int(any(a.any() for a in obs["agent_attribute_board_ascii_codes"].values())))
     c = env.calculate_observation_coordinates(obs, occlusion_in_layers=False, ascii=True)
     coords.append({k: [list(map(int, x)) for x in v] for k, v in c.items()})
     order = env.get_layers_order(obs, occlusion_in_layers=False, layers_order=[])
@@ -92,7 +108,7 @@ def main():
     assert all(int(ts.step_type[ch]) == 1 for ch in AG), ("the stream must stay inside one episode", t, [int(ts.step_type[ch]) for ch in AG])
     record(ts)
   rec = {k: np.asarray(v) for k, v in rows.items()}
-  rec.update(actions=acts, seed=np.array(seed), philox_env_id=np.array(env_id), coords_json=np.array(json.dumps(coords)), agent_coords_json=np.array(json.dumps(agent_coords)),
+  rec.update(actions=acts, seed=np.array(seed), categories=np.array("|".join(CATS)), philox_env_id=np.array(env_id), coords_json=np.array(json.dumps(coords)), agent_coords_json=np.array(json.dumps(agent_coords)),
              orders=np.array("|".join(orders)), agent_orders=np.array("|".join(",".join(p) for p in agent_orders)))
   np.savez_compressed(os.path.join(HERE, "zoo_island_ma_L9.npz"), **rec)
   print("orders", orders[0], agent_orders[0], "cube", rec["cube"].shape, "agent cube", rec["agent_cube"].shape, "dirs", rows["obs_dir"][-1], rows["act_dir"][-1])

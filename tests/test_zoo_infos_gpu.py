@@ -44,6 +44,17 @@ def test_zoo_parallel_infos_match_reference_fixture():
       lay = info[Z.INFO_AGENT_OBSERVATION_LAYERS_DICT]
       for j, c in enumerate(agent_orders[t][i]):
         assert np.array_equal(lay[c], fx["agent_cube"][t][i][j].astype(bool)), (t, a, c)
+      # observation keys the wrapper passes through (dicts over the agent characters), bit for bit
+      for j, c in enumerate("12"):
+        assert np.array_equal(info["cumulative_reward"][c], fx["cum"][t][j]) and np.array_equal(info["average_reward"][c], fx["avg"][t][j]), (t, c)
+        for key, name in (("gini", "gini_index"), ("cgini", "cumulative_gini_index"), ("var", "mo_variance"), ("cvar", "cumulative_mo_variance"),
+                          ("avar", "average_mo_variance")):
+          assert info[name][c] == fx[key][t][j], (t, c, name, info[name][c], fx[key][t][j])
+      want_aa = {c: {"step": int(fx["actual"][t][j])} for j, c in enumerate("12") if fx["actual"][t][j] >= 0}
+      assert info["extra_observations"].get("actual_actions", {}) == want_aa, (t, info["extra_observations"])
+      cats = str(fx["categories"]).split("|")
+      assert sorted(info["agent_attribute_board_ascii_codes"]) == sorted(cats) and not any(v.any() for v in info["agent_attribute_board_ascii_codes"].values())
+      assert all(v == {} for v in info["agent_attribute_layers"].values()) and all((v == '').all() for v in info["agent_attribute_board_ascii"].values())
 
   obs, infos = env.reset()
   obs_f, infos_f = envf.reset()
