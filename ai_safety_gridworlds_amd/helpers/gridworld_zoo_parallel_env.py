@@ -286,6 +286,12 @@ class GridworldZooParallelEnv(_Base):
       infos[a] = info
     return infos
 
+  def observe_infos_from_location(self, agents_coordinates, agents_observation_directions=None):
+    """zoo.py:395-412.  The reference cannot execute this at this snapshot: get_agent_perspective builds the overridden position
+    with `Sprite.Position`, and safety_game_moma.py never imports `Sprite` (NameError at safety_game_moma.py:2000, checked by
+    running it).  Kept with the reference's behaviour so that callers see the same failure."""
+    raise NameError("name 'Sprite' is not defined")
+
   def reset(self, seed=None, *args, **kwargs):
     if self._pre_reset_callback is not None:                    # zoo.py:619-622
       (allow_reset, seed, args, kwargs) = self._pre_reset_callback(seed, *args, **kwargs)
