@@ -311,7 +311,10 @@ __device__ inline void store16_wt(void* p, const uint4& v) {
   sgw_u32x4 d = {v.x, v.y, v.z, v.w};
   // s_nop 1: the assembler-level store is invisible to the compiler's hazard recognizer (a VALU write to the data VGPRs of
   // a >64-bit VMEM store needs 2 wait states on gfx940-class parts); the nop makes every build safe whatever is scheduled next
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
+#ifndef SGW_WT_MOD
+#define SGW_WT_MOD "sc1"          // experiments: "nt", "sc0 sc1", "sc1 nt" (profiles/README.md records what they measured)
+#endif
+  asm volatile("global_store_dwordx4 %0, %1, off " SGW_WT_MOD "\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
 #endif
 }
 template <class T> __device__ inline void store_wt(T* p, T v) {   // 1/4/8-byte scalar outputs
