@@ -66,6 +66,15 @@ __device__ inline int b3_kth(const B3& m, int k) {
   return 128 + kth64(m.c, k - ca - cb);
 }
 
+#ifdef SGW_SAV_PROF      // diagnostic build only (tools/diag/sav_prof.py): wave cycles per phase of a round, per wave
+__device__ unsigned long long g_sav_prof[4096 * 8];
+__device__ unsigned long long g_sav_last[4096];
+#define SAV_T(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); const int w_ = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 4095; \
+                      if ((threadIdx.x & 63) == 0) { g_sav_prof[w_ * 8 + (k)] += n_ - g_sav_last[w_]; g_sav_last[w_] = n_; } } while (0)
+#else
+#define SAV_T(k) do { } while (0)
+#endif
+
 struct Savanna {
   static constexpr int NA = 2;
   static constexpr int NUA = 13;
@@ -466,6 +475,7 @@ struct Savanna {
     const bool oversat = (sp.flags & F_OVERSAT) != 0, prop = (sp.flags & F_PROP) != 0, two = (sp.flags & F_TWO) != 0;
     const bool adir_rel = (sp.flags & F_ADIR) != 0, odir_rel = (sp.flags & F_ODIR) != 0;
     const bool a1 = (ag == 1);
+    SAV_T(0);                                                   // everything outside play_one (prologue, outputs, state store)
     s.frame += 1;
     // ---- AgentSprite.update
     const int cur_od = a1 ? s.odir[1] : s.odir[0], cur_ad = a1 ? s.adir[1] : s.adir[0];
@@ -541,6 +551,7 @@ struct Savanna {
     s.vis[V_GOLD][0] += on_G ? i0 : 0u; s.vis[V_GOLD][1] += on_G ? i1 : 0u;
     s.vis[V_SILVER][0] += on_S ? i0 : 0u; s.vis[V_SILVER][1] += on_S ? i1 : 0u;
     s.vis[V_GAP][0] += on_gap ? i0 : 0u; s.vis[V_GAP][1] += on_gap ? i1 : 0u;
+    SAV_T(1);                                                   // agent move + update_reward
     // ---- WaterDrape SV:1065-1079, PredatorDrape SV:1098-1193 (rewards only reach the acting agent)
     double injury = b3_get(s.water, pos) ? p[P_DANGER] : 0.0;
     {
@@ -569,13 +580,15 @@ struct Savanna {
       }
     }
     ra[INJURY] += injury;
+    SAV_T(2);                                                   // water + predators
     // the plot sums per agent and dimension in call order; every dimension receives its terms from one source here
 #pragma unroll
     for (int u = 0; u < NUA; ++u) { r[u] += a1 ? 0.0 : ra[u]; r[NUA + u] += a1 ? ra[u] : 0.0; }
     r[COOP] += a1 ? other_coop : 0.0; r[NUA + COOP] += a1 ? 0.0 : other_coop;
     // ---- resource drapes, update order D F d f
-    resource_update<0>(s, sp, l, false); resource_update<1>(s, sp, l, false);
-    resource_update<2>(s, sp, l, false); resource_update<3>(s, sp, l, false);
+    SAV_T(3);                                                   // reward bookkeeping
+    resource_update<0>(s, sp, l, false); SAV_T(4); resource_update<1>(s, sp, l, false); SAV_T(5);
+    resource_update<2>(s, sp, l, false); SAV_T(6); resource_update<3>(s, sp, l, false); SAV_T(7);
   }
 
   // one ROUND
