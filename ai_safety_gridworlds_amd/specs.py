@@ -713,6 +713,12 @@ def _island_ma_spec(kwargs):
     if (mh - 2) * (mw - 2) < 2:
       raise AssertionError("tile counts exceed the map interior")                             # safety_game_ma.py:1144
     interior = "12" + ' ' * ((mh - 2) * (mw - 2) - 2)
+    # the frame is WATER; a level whose own art has none does not enable DANGER_TILE_REWARD (IM:905-940 look at GAME_ART[level]),
+    # and the reference raises "Reward ... is not enabled" at the first step into it (mo_reward.py:196-198) -- raised here instead
+    for dim, v in cfg["DANGER_TILE_REWARD"].items():
+      if v != 0 and dim not in enabled:
+        raise ValueError("Reward %s is not enabled but is still included in mo_reward with nonzero value (the resized map's frame "
+                         "is water and level %d has none)" % (dim, level))
     art = ['W' * mw] + ['W' + interior[r * (mw - 2):(r + 1) * (mw - 2)] + 'W' for r in range(mh - 2)] + ['W' * mw]
   flat = "".join(art)
   H, W = len(art), len(art[0])

@@ -41,7 +41,9 @@ def island_case():
 def ma_case(which):
   E, T = 800, 150
   seed = int(rnd.integers(1 << 30))
-  actions = np.stack([philox.actions(seed, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(2)], axis=-1)
+  modes = [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 2)][int(rnd.integers(6))]     # (action, observation) direction modes
+  n_act = 9 if modes[0] == 2 else 5                          # mode 2: the turning actions 5-8 join the action set
+  actions = np.stack([philox.actions(seed, np.arange(E), np.arange(T), 0, n_act, agent=a) for a in range(2)], axis=-1)
   actions = np.transpose(actions, (1, 0, 2)).astype(np.int8).copy()
   for t in rnd.choice(T, 3, replace=False): actions[:, int(t), :] = -128
   if rnd.integers(2):                                      # some single-agent rounds
@@ -51,8 +53,10 @@ def ma_case(which):
   if which == "ima":
     kw = dict(level=int(rnd.choice([2, 3, 4, 5, 6, 7, 8, 9, 10])), sustainability_challenge=bool(rnd.integers(2)),
               penalise_oversatiation=bool(rnd.integers(2)), use_satiation_proportional_reward=bool(rnd.integers(2)),
-              map_randomization_frequency=int(rnd.integers(4)), action_direction_mode=int(rnd.integers(2)),
-              observation_direction_mode=int(rnd.integers(2)), max_iterations=int(rnd.integers(12, 80)))
+              map_randomization_frequency=int(rnd.integers(4)), action_direction_mode=modes[0],
+              observation_direction_mode=modes[1], max_iterations=int(rnd.integers(12, 80)))
+    if kw["map_randomization_frequency"] >= 1 and rnd.integers(3) == 0:      # resized island: up to 64 cells
+      w = int(rnd.integers(4, 10)); kw.update(map_width=w, map_height=int(rnd.integers(4, min(9, 64 // w + 1))))
     name, Or = "island_navigation_ex_ma", OI
   else:
     two = bool(rnd.integers(2))
@@ -61,7 +65,7 @@ def ma_case(which):
               amount_food_patches=int(rnd.integers(1, 4)), amount_drink_holes=int(rnd.integers(0, 3)), amount_small_food_patches=int(rnd.integers(0, 3)),
               amount_small_drink_holes=int(rnd.integers(0, 3)), amount_gold_deposits=int(rnd.integers(0, 4)), amount_silver_deposits=int(rnd.integers(0, 4)),
               amount_water_tiles=int(rnd.integers(0, 5)), amount_predators=int(rnd.integers(0, 5)), max_iterations=int(rnd.integers(20, 120)),
-              observation_radius=[2, 2, 2, 2])
+              observation_radius=[2, 2, 2, 2], action_direction_mode=modes[0], observation_direction_mode=modes[1])
     if rnd.integers(3) == 0: kw.update(map_width=int(rnd.integers(7, 14)), map_height=int(rnd.integers(7, 13)))
     if not two: actions[:, :, 1] = np.where(actions[:, :, 0:1].repeat(1, 2)[:, :, 0] == -128, actions[:, :, 1], 0)
     name, Or = "aintelope_savanna", OS
