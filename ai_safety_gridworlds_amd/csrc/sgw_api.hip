@@ -628,6 +628,13 @@ static ViewSpec make_viewspec(const sgw_engine* e) {
 
 int sgw_view_bytes(const sgw_engine* e) { return e ? make_viewspec(e).total : 0; }
 
+// LDS stage of one wave of the window kernels: the largest window + one 16-byte phase, rounded to 16
+static int view_stage_bytes(const ViewSpec& v) {
+  int mx = 0;
+  for (int a = 0; a < v.A; ++a) mx = v.vh[a] * v.vw[a] > mx ? v.vh[a] * v.vw[a] : mx;
+  return (mx + 16 + 15) / 16 * 16;
+}
+
 static int check_rotation(const sgw_engine* e, const ViewSpec& v, const uint8_t* flags) {
   if (!flags) return SGW_OK;
   for (int a = 0; a < v.A; ++a)
@@ -643,10 +650,11 @@ int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agen
   if (v.total <= 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_agent_views: the spec defines no agent views");
   if (check_rotation(e, v, agent_flags_dev)) return SGW_ERR_UNSUPPORTED;
   HIP_TRY(hipSetDevice(e->device));
-  long long total = e->n_envs * v.total;
-  int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  hipLaunchKernelGGL(k_agent_views, dim3(blocks), dim3(256), 0, (hipStream_t)stream, board_dev, agent_pos_dev,
-                     agent_flags_dev, e->n_envs, v, outside_chr, views_dev);
+  long long total = e->n_envs * (long long)v.A * WAVE;                   // one wave per (env, agent) window
+  int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  const int lds_per_wave = view_stage_bytes(v);
+  hipLaunchKernelGGL(k_agent_views, dim3(blocks), dim3(256), 4 * lds_per_wave, (hipStream_t)stream, board_dev, agent_pos_dev,
+                     agent_flags_dev, e->n_envs, v, outside_chr, views_dev, lds_per_wave);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }
@@ -659,10 +667,11 @@ int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_
   if (v.total <= 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_agent_layer_views: the spec defines no agent views");
   if (check_rotation(e, v, agent_flags_dev)) return SGW_ERR_UNSUPPORTED;
   HIP_TRY(hipSetDevice(e->device));
-  long long total = e->n_envs * (long long)v.total * n_layers;
-  int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
-  hipLaunchKernelGGL(k_agent_layer_views, dim3(blocks), dim3(256), 0, (hipStream_t)stream, layers_dev, agent_pos_dev,
-                     agent_flags_dev, e->n_envs, v, layer_chars_dev, n_layers, outside_chr, out_dev);
+  long long total = e->n_envs * (long long)v.A * n_layers * WAVE;        // one wave per (env, agent, layer) window
+  int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  const int lds_per_wave = view_stage_bytes(v);
+  hipLaunchKernelGGL(k_agent_layer_views, dim3(blocks), dim3(256), 4 * lds_per_wave, (hipStream_t)stream, layers_dev, agent_pos_dev,
+                     agent_flags_dev, e->n_envs, v, layer_chars_dev, n_layers, outside_chr, out_dev, lds_per_wave);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }

@@ -716,41 +716,119 @@ __device__ inline void view_unrotate(int dir, int n, int& vr, int& vc) {
   else if (dir == 0) { vr = n - 1 - c; vc = r; }             // LEFT: rot90 k=-1 (clockwise)
   else if (dir == 1) { vr = c; vc = n - 1 - r; }             // RIGHT: rot90 k=1 (counter-clockwise)
 }
-__global__ void k_agent_views(const uint8_t* board, const uint8_t* pos, const uint8_t* flags, long long n, ViewSpec v,
-                              uint8_t outside, uint8_t* views) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = n * v.total;
-  for (; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long e = i / v.total;
-    int b = (int)(i % v.total), ag = 0;
+// One WAVE produces one agent's window of one env.  The lanes cover whole window rows (64 / vw rows per pass, one byte per lane) and
+// read contiguous board cells (a board row, or a column when the window is rotated); the window is assembled in LDS at the same
+// 16-byte phase as its place in the output and leaves as 16-byte stores (head and tail bytes singly): window bytes are not
+// aligned to anything (1 139 bytes per firemaker env), and byte-masked partial-line writes were what the earlier versions
+// were waiting for.  History (16 384 firemaker envs x 1 139 window bytes): one thread per output byte with its own divisions,
+// 46 us; one thread per window row, 49 us; one wave per window with byte stores, 42-44 us.
+__device__ inline void view_wave(const uint8_t* src, uint8_t* dst, uint8_t* lds, int H, int W, int vh, int vw, int pr, int pc, int dir,
+                                 bool rotate, uint8_t pad, int lane) {
+  const int len = vh * vw;
+  const int phase = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
+  uint8_t* stage = lds + phase;                                   // stage[j] and dst[j] share their 16-byte alignment
+  if (len > H * W && vw <= 255) {
+    // a window LARGER than the board (firemaker's supervisor: 33 x 33 around a 17 x 17 board) is mostly padding: fill the stage
+    // with the pad byte (16-byte LDS stores), then walk the BOARD cells once and drop each where it lands in the window
+    const uint32_t p4 = 0x01010101u * pad;
+    const uint4 fill = make_uint4(p4, p4, p4, p4);
+    for (int k = lane; k < (phase + len + 15) >> 4; k += WAVE) reinterpret_cast<uint4*>(lds)[k] = fill;
+    lds_wave_sync();
+    const int cells = H * W;
+    for (int k0 = 0; k0 < cells; k0 += 4 * WAVE) {                 // four loads in flight
+      uint8_t val[4]; int at[4];
 #pragma unroll
-    for (int k = 1; k < SGW_MAX_AGENTS; ++k) if (k < v.A && b >= v.off[k]) ag = k;
-    b -= v.off[ag];
-    int vr = b / v.vw[ag], vc = b % v.vw[ag];
-    if (flags) view_unrotate((flags[e * v.A + ag] >> 3) & 3, v.vw[ag], vr, vc);
-    const int r = (int)pos[(e * v.A + ag) * 2] - v.up[ag] + vr, c = (int)pos[(e * v.A + ag) * 2 + 1] - v.left[ag] + vc;
-    views[i] = (r < 0 || r >= v.H || c < 0 || c >= v.W) ? outside : board[e * (v.H * v.W) + r * v.W + c];
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + q * WAVE + lane;
+        const bool in_board = k < cells;
+        val[q] = src[in_board ? k : 0];
+        const int r = k / W, c = k - r * W;
+        const int cr = r - pr, cc = c - pc;                       // crop coordinates
+        int vr = cr, vc = cc;                                     // inverse of view_unrotate
+        if (rotate) {
+          if (dir == 3) { vr = vw - 1 - cr; vc = vw - 1 - cc; }
+          else if (dir == 0) { vr = cc; vc = vw - 1 - cr; }
+          else if (dir == 1) { vr = vw - 1 - cc; vc = cr; }
+        }
+        at[q] = (in_board && cr >= 0 && cr < vh && cc >= 0 && cc < vw) ? vr * vw + vc : -1;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (at[q] >= 0) stage[at[q]] = val[q];
+    }
+  } else if (vw > WAVE) {                                         // wider than a wave: plain column chunks (no reference env is)
+    for (int vr = 0; vr < vh; ++vr)
+      for (int vc = lane; vc < vw; vc += WAVE) {
+        int r = vr, c = vc;
+        if (rotate) view_unrotate(dir, vw, r, c);
+        r += pr; c += pc;
+        stage[vr * vw + vc] = (r < 0 || r >= H || c < 0 || c >= W) ? pad : src[r * W + c];
+      }
+  } else {
+    const int rpg = WAVE / vw;                                    // window rows per pass
+    const int lr = lane / vw, lc = lane - lr * vw;
+    const bool lane_on = lr < rpg;
+    for (int vr0 = 0; vr0 < vh; vr0 += 4 * rpg) {                 // four passes in flight: loads first, LDS writes after
+      uint8_t val[4]; bool on[4]; int at[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int vr = vr0 + k * rpg + lr;
+        on[k] = lane_on && vr < vh;
+        int r = on[k] ? vr : 0, c = lc;
+        if (rotate) view_unrotate(dir, vw, r, c);
+        r += pr; c += pc;
+        const bool inside = !(r < 0 || r >= H || c < 0 || c >= W);
+        const uint8_t got = src[inside ? r * W + c : 0];           // unconditional load (index clamped), selected afterwards
+        val[k] = inside ? got : pad;
+        at[k] = vr * vw + lc;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (on[k]) stage[at[k]] = val[k];
+    }
+  }
+  lds_wave_sync();
+  const int head = (16 - phase) & 15;                             // bytes up to the first 16-byte boundary of the output
+  const int nh = head < len ? head : len;
+  if (lane < nh) dst[lane] = stage[lane];
+  const int body = (len - nh) >> 4;                               // whole 16-byte chunks
+  for (int k = lane; k < body; k += WAVE)
+    *reinterpret_cast<uint4*>(dst + nh + 16 * k) = *reinterpret_cast<const uint4*>(stage + nh + 16 * k);
+  const int done = nh + 16 * body;
+  if (lane < len - done) dst[done + lane] = stage[done + lane];
+  lds_wave_sync();                                                // the next window of this wave reuses the stage
+}
+__global__ void k_agent_views(const uint8_t* board, const uint8_t* pos, const uint8_t* flags, long long n, ViewSpec v,
+                              uint8_t outside, uint8_t* views, int lds_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t view_lds[];
+  const int lane = threadIdx.x & (WAVE - 1);
+  uint8_t* lds = view_lds + (threadIdx.x >> 6) * lds_per_wave;
+  const long long stride = ((long long)gridDim.x * blockDim.x) >> 6, windows = n * v.A;
+  for (long long wv = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wv < windows; wv += stride) {
+    const long long e = wv / v.A;
+    const int ag = (int)(wv - e * v.A);
+    const int pr = (int)pos[wv * 2] - v.up[ag], pc = (int)pos[wv * 2 + 1] - v.left[ag];
+    const int dir = flags ? (flags[wv] >> 3) & 3 : 2;
+    view_wave(board + e * (long long)(v.H * v.W), views + e * v.total + v.off[ag], lds, v.H, v.W, v.vh[ag], v.vw[ag], pr, pc, dir,
+              flags != nullptr, outside, lane);
   }
 }
 
-// per-layer agent windows: out[e][agent][layer][vr][vc]
+// per-layer agent windows: out[e][agent][layer][vr][vc]; one wave per (env, agent, layer)
 __global__ void k_agent_layer_views(const uint8_t* layers, const uint8_t* pos, const uint8_t* flags, long long n, ViewSpec v,
-                                    const uint8_t* chars, int L, uint8_t outside, uint8_t* out) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long per_env = (long long)v.total * L, total = n * per_env;
-  for (; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long e = i / per_env;
-    int b = (int)(i % per_env), ag = 0;
-#pragma unroll
-    for (int k = 1; k < SGW_MAX_AGENTS; ++k) if (k < v.A && b >= v.off[k] * L) ag = k;
-    b -= v.off[ag] * L;
+                                    const uint8_t* chars, int L, uint8_t outside, uint8_t* out, int lds_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t view_lds[];
+  const int lane = threadIdx.x & (WAVE - 1);
+  uint8_t* lds = view_lds + (threadIdx.x >> 6) * lds_per_wave;
+  const long long stride = ((long long)gridDim.x * blockDim.x) >> 6, windows = n * v.A * L;
+  for (long long wv = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wv < windows; wv += stride) {
+    const long long ea = wv / L;                                 // env * A + agent
+    const int li = (int)(wv - ea * L);
+    const long long e = ea / v.A;
+    const int ag = (int)(ea - e * v.A);
+    const int pr = (int)pos[ea * 2] - v.up[ag], pc = (int)pos[ea * 2 + 1] - v.left[ag];
+    const int dir = flags ? (flags[ea] >> 3) & 3 : 2;
     const int cells = v.vh[ag] * v.vw[ag];
-    const int li = b / cells, c2 = b % cells;
-    int vr = c2 / v.vw[ag], vc = c2 % v.vw[ag];
-    if (flags) view_unrotate((flags[e * v.A + ag] >> 3) & 3, v.vw[ag], vr, vc);
-    const int r = (int)pos[(e * v.A + ag) * 2] - v.up[ag] + vr, c = (int)pos[(e * v.A + ag) * 2 + 1] - v.left[ag] + vc;
-    out[i] = (r < 0 || r >= v.H || c < 0 || c >= v.W) ? (uint8_t)(chars[li] == outside)
-                                                     : layers[(e * L + li) * (v.H * v.W) + r * v.W + c];
+    view_wave(layers + (e * L + li) * (long long)(v.H * v.W), out + e * ((long long)v.total * L) + (long long)v.off[ag] * L + (long long)li * cells,
+              lds, v.H, v.W, v.vh[ag], v.vw[ag], pr, pc, dir, flags != nullptr, (uint8_t)(chars[li] == outside), lane);
   }
 }
 

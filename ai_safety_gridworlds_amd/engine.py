@@ -68,6 +68,7 @@ class BatchedEngine(object):
   # -- buffers ----------------------------------------------------------------------------------
   def _alloc_outputs(self, T):
     self._T = T
+    self._views_cache = None
     for name in self.outputs:
       dt, shp = _dtype_shape(self.spec, name)
       lead = (T, self.n_pad) if T > 1 else (self.n_pad,)
@@ -76,6 +77,10 @@ class BatchedEngine(object):
       setattr(self._out, name, self._bufs[name].data_ptr() if name in self._bufs else None)
 
   def _views(self):
+    """{name: view of the persistent output buffer}: the views only change with a reallocation, so they are built once (a step
+    from Python is host-bound: every microsecond here is throughput)."""
+    if getattr(self, "_views_cache", None) is not None:
+      return dict(self._views_cache)
     out = {}
     for name, t in self._bufs.items():
       v = t[:, :self.n_envs] if self._T > 1 else t[:self.n_envs]
@@ -86,7 +91,8 @@ class BatchedEngine(object):
       elif name == "agent_pos":
         v = v.reshape(v.shape[:-1] + (self.spec.A, 2))
       out[name] = v
-    return out
+    self._views_cache = out
+    return dict(out)
 
   def _stream(self):
     return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -213,14 +219,15 @@ class BatchedEngine(object):
     t = self._bufs["agent_flags"] if agent_flags is None else agent_flags
     return t.data_ptr()
 
-  def agent_views(self, board=None, agent_pos=None, outside_chr=None, agent_flags=None):
+  def agent_views(self, board=None, agent_pos=None, outside_chr=None, agent_flags=None, out=None):
     """Agent-centric windows (safety_game_moma.py:1996-2101): list of uint8 [N, h_a, w_a] tensors, one per agent
-    (rotated by the agent's observation direction when the env's observation_direction_mode is not 0)."""
+    (rotated by the agent's observation direction when the env's observation_direction_mode is not 0).  `out`: a uint8
+    [N, sgw_view_bytes] buffer to write into (a caller that steps in a loop reuses one buffer and its views)."""
     board = self._bufs["board"] if board is None else board
     agent_pos = self._bufs["agent_pos"] if agent_pos is None else agent_pos
     outside_chr = outside_chr or getattr(self.spec, "what_lies_outside", '#')
     vb = int(self._lib.sgw_view_bytes(self._h))
-    views = torch.empty((self.n_envs, vb), dtype=torch.uint8, device=self.device)
+    views = torch.empty((self.n_envs, vb), dtype=torch.uint8, device=self.device) if out is None else out
     N.check(self._lib.sgw_agent_views(self._h, board.data_ptr(), agent_pos.data_ptr(), self._view_flags(agent_flags),
                                       ord(outside_chr), views.data_ptr(), self._stream()), "sgw_agent_views")
     out, off = [], 0

@@ -40,8 +40,9 @@ class TimeStep(collections.namedtuple("TimeStep", ["step_type", "reward", "disco
 
 class BatchedSafetyEnvironment(object):
 
-  def __init__(self, env_name, num_envs=1, device="cuda:0", env_id_base=0, outputs=None, **kwargs):
+  def __init__(self, env_name, num_envs=1, device="cuda:0", env_id_base=0, outputs=None, track_performance=True, **kwargs):
     self.env_name = env_name
+    self._track_performance = bool(track_performance)     # get_last_performance bookkeeping: two more device ops per step
     self.spec = make_spec(env_name, **kwargs)
     self.num_envs = int(num_envs)
     if outputs is None:        # everything the family produces ('safety2_<agent>' exists in aintelope_savanna only)
@@ -71,7 +72,7 @@ class BatchedSafetyEnvironment(object):
                                                                                torch.full_like(st[:, 0], N.MID)))
     else:
       st = st[:, 0]                                           # all agents of an env share the step type
-    if "cumulative" in o or "hidden" in o:      # _calculate_episode_performance (safety_game.py:253-263)
+    if self._track_performance and ("cumulative" in o or "hidden" in o):      # _calculate_episode_performance (safety_game.py:253-263)
       use_hidden = self.spec.scalar and getattr(self.spec, "performance", "hidden") == "hidden"   # distributional_shift keeps the default: episode return
       perf = o["hidden"].reshape(self.num_envs, 1) if use_hidden and "hidden" in o else o.get("cumulative")
       if perf is not None:

@@ -380,9 +380,10 @@ class GridworldVectorEnv(object):
                outputs=("board", "obs_board", "reward", "cumulative", "step_type", "term_reason", "hidden"),
                **kwargs):
     self._env = BatchedSafetyEnvironment(env_name, num_envs=num_envs, device=device, env_id_base=env_id_base,
-                                         outputs=outputs, **kwargs)
+                                         outputs=outputs, track_performance=False, **kwargs)
     self.spec_ = self._env.spec
     self.num_envs = num_envs
+    self._never = torch.zeros(num_envs, dtype=torch.bool, device=self._env.device)      # truncated: always False (gym_env.py:563-578)
 
   def _pack(self, ts):
     o = ts.observation
@@ -395,11 +396,11 @@ class GridworldVectorEnv(object):
     return self._pack(self._env.reset(mask))
 
   def step(self, actions):
-    ts = self._env.step(actions.to(torch.int8))
+    ts = self._env.step(actions if actions.dtype == torch.int8 else actions.to(torch.int8))
     obs, info = self._pack(ts)
     reward = ts.reward if not self.spec_.scalar else ts.reward.reshape(-1)
     terminated = ts.step_type == N.LAST
-    return obs, reward, terminated, torch.zeros_like(terminated), info
+    return obs, reward, terminated, self._never, info
 
   def close(self):
     self._env.close()

@@ -35,7 +35,8 @@ class GridworldZooVectorEnv(object):
 
   def __init__(self, env_name, num_envs, ascii_observation_format=True, layers_in_observation=False, seed=None, device="cuda:0",
                env_id_base=0, **kwargs):
-    self._env = BatchedSafetyEnvironment(env_name, num_envs=num_envs, device=device, env_id_base=env_id_base, outputs=OUTS, **kwargs)
+    self._env = BatchedSafetyEnvironment(env_name, num_envs=num_envs, device=device, env_id_base=env_id_base, outputs=OUTS,
+                                         track_performance=False, **kwargs)
     sp = self.spec_ = self._env.spec
     if sp.A < 2 and not getattr(sp, "per_agent", False):
       raise NotImplementedError("%s is a single-agent env: use GridworldVectorEnv" % env_name)
@@ -51,6 +52,10 @@ class GridworldZooVectorEnv(object):
     self.layers_order = list(sp.layer_chars)                   # get_layers_order(...) of the reference: sorted layer keys
     self._vm = torch.tensor([sp.native.value_map[i] for i in range(128)], dtype=torch.float32, device=self.device)
     self._acts = torch.zeros((self.num_envs, sp.A), dtype=torch.int8, device=self.device)
+    self._never = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)            # truncated: always False
+    cfg = getattr(sp, "config", None) or {}
+    self._turning = bool(cfg.get("action_direction_mode", 0) or cfg.get("observation_direction_mode", 0))
+    self._up = torch.full((self.num_envs,), 2, dtype=torch.uint8, device=self.device)         # Directions.UP: the fixed-direction envs
     if sp.family == N.FIREMAKER_EX_MA or getattr(sp, "needs_rng", False):
       # env i draws from Generator(PCG64(SeedSequence(seed + global id))): what seeding.np_random gives N separately seeded envs
       base = 0 if seed is None else int(seed)
@@ -70,35 +75,59 @@ class GridworldZooVectorEnv(object):
     self._env.close()
 
   def _pack(self, o):
+    """A step from Python is host-bound (every torch op is a launch, every view a microsecond).  The step's outputs live in
+    persistent buffers, so the per-agent dicts of views are built ONCE; a step then only refreshes what is computed from them:
+    the agent windows (one launch into a reused buffer) and the done flags (one comparison; two shifts more when the env has
+    moving directions).  The returned tensors are valid until the next step / reset, like the engine's outputs."""
     sp = self.spec_
-    views = self._env.engine.agent_views()                      # per column: uint8 [N, h, w]
-    st = o["step_type"].reshape(self.num_envs, -1)
-    rew = o["reward"].reshape(self.num_envs, sp.A, sp.K)
-    cum = o["cumulative"].reshape(self.num_envs, sp.A, sp.K)
-    pos = o["agent_pos"].reshape(self.num_envs, sp.A, 2)
-    flags = o["agent_flags"].reshape(self.num_envs, sp.A)
-    cube = agent_cubes = None
+    n = self.num_envs
+    eng = self._env.engine
+    if getattr(self, "_packed_for", None) is not o.get("reward"):       # first call, or the engine reallocated its outputs
+      self._packed_for = o.get("reward")
+      vb = int(eng._lib.sgw_view_bytes(eng._h))
+      self._view_buf = torch.empty((n, vb), dtype=torch.uint8, device=self.device)
+      views = eng.agent_views(out=self._view_buf)
+      st = o["step_type"].reshape(n, -1)
+      self._st = st
+      self._done = torch.empty_like(st, dtype=torch.bool)
+      rew = o["reward"].reshape(n, sp.A, sp.K)
+      cum = o["cumulative"].reshape(n, sp.A, sp.K)
+      pos = o["agent_pos"].reshape(n, sp.A, 2)
+      self._flags = o["agent_flags"].reshape(n, sp.A)
+      self._odir = torch.empty_like(self._flags); self._adir = torch.empty_like(self._flags)
+      metrics = o["metrics"][:, :sp.M]
+      obs, rewards, terms, truncs, infos = {}, {}, {}, {}, {}
+      for i, a in enumerate(self.possible_agents):
+        q, k = self._slots[i], self._k[a]
+        c = q if self._per_agent else 0
+        obs[a] = views[q]
+        rewards[a] = rew[:, q, :k]
+        terms[a] = self._done[:, c]
+        truncs[a] = self._never
+        infos[a] = {"step_type": st[:, c], "cumulative_reward": cum[:, q, :k], "agent_position": pos[:, q], "discount": o["discount"],
+                    "metrics": metrics, "board": o["board"],
+                    "observation_direction": self._odir[:, q] if self._turning else self._up,
+                    "action_direction": self._adir[:, q] if self._turning else self._up}
+      self._cached = (obs, rewards, terms, truncs, infos)
+    else:
+      eng.agent_views(out=self._view_buf)
+    torch.ge(self._st, N.LAST, out=self._done)
+    if self._turning:
+      torch.bitwise_right_shift(self._flags, 3, out=self._odir).bitwise_and_(3)
+      torch.bitwise_right_shift(self._flags, 1, out=self._adir).bitwise_and_(3)
+    obs, rewards, terms, truncs, infos = self._cached
+    obs, infos = dict(obs), {a: dict(d) for a, d in infos.items()}
+    if not self._ascii:
+      obs = {a: self._vm[v.long()] for a, v in obs.items()}
     if self._layers:                                            # two more launches, tensors stay on the device
-      cube = self._env.engine.observe_layers()
-      agent_cubes = self._env.engine.agent_layer_views(layers=cube)
-    obs, rewards, terms, truncs, infos = {}, {}, {}, {}, {}
-    for i, a in enumerate(self.possible_agents):
-      q, k = self._slots[i], self._k[a]
-      v = views[q]
-      obs[a] = v if self._ascii else self._vm[v.long()]
-      s_a = st[:, q] if self._per_agent else st[:, 0]
-      rewards[a] = rew[:, q, :k]
-      terms[a] = s_a >= N.LAST
-      truncs[a] = torch.zeros_like(terms[a])
-      infos[a] = {"step_type": s_a, "cumulative_reward": cum[:, q, :k], "agent_position": pos[:, q], "discount": o["discount"],
-                  "metrics": o["metrics"][:, :sp.M], "board": o["board"],
-                  "observation_direction": (flags[:, q] >> 3) & 3, "action_direction": (flags[:, q] >> 1) & 3}
-      if self._layers:
+      cube = eng.observe_layers()
+      agent_cubes = eng.agent_layer_views(layers=cube)
+      for i, a in enumerate(self.possible_agents):
         infos[a]["info_observation_layers_order"] = self.layers_order
         infos[a]["info_observation_layers_cube"] = cube
         infos[a]["info_agent_observation_layers_order"] = self.layers_order
-        infos[a]["info_agent_observation_layers_cube"] = agent_cubes[q]
-    return obs, rewards, terms, truncs, infos
+        infos[a]["info_agent_observation_layers_cube"] = agent_cubes[self._slots[i]]
+    return obs, dict(rewards), dict(terms), dict(truncs), infos
 
   def reset(self, mask=None):
     ts = self._env.reset(mask)
@@ -107,16 +136,21 @@ class GridworldZooVectorEnv(object):
 
   def step(self, actions):
     """actions: {agent: int8 / int64 tensor [N] on the device (or a python int for every env)}; a missing agent plays NOOP
-    (per-agent families: does not play this round)."""
+    (per-agent families: does not play this round).  Or ONE int8 tensor [N, A] already in the library's column order
+    (`agent_slots`): no per-agent copy."""
     sp = self.spec_
-    for i, a in enumerate(self.possible_agents):
-      col = self._acts[:, self._slots[i]]
-      v = actions.get(a)
-      if v is None:
-        col.fill_(-1 if self._per_agent else 0)
-      elif torch.is_tensor(v):
-        col.copy_(v.reshape(-1))
-      else:
-        col.fill_(int(v))
-    ts = self._env.step(self._acts.reshape(-1) if sp.A == 1 else self._acts)
+    if torch.is_tensor(actions):                                 # already the library's layout: int8 [N, A] by column (no copy)
+      acts = actions
+    else:
+      for i, a in enumerate(self.possible_agents):
+        col = self._acts[:, self._slots[i]]
+        v = actions.get(a)
+        if v is None:
+          col.fill_(-1 if self._per_agent else 0)
+        elif torch.is_tensor(v):
+          col.copy_(v.reshape(-1))
+        else:
+          col.fill_(int(v))
+      acts = self._acts
+    ts = self._env.step(acts.reshape(-1) if sp.A == 1 else acts)
     return self._pack(ts.observation)
