@@ -9,11 +9,12 @@ os.makedirs("profiles", exist_ok=True)
 KERNEL = "Island"
 
 def counters(d):
-  f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+  # gpurun_out/ is scratch that survives rounds: a tag reused from an earlier round still holds that round's CSVs -> newest file
+  f = sorted(glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
   acc = {}
   if not f:
     return acc
-  for r in csv.DictReader(open(f[0])):
+  for r in csv.DictReader(open(f[-1])):
     if KERNEL in r["Kernel_Name"] and "Li0E" in r["Kernel_Name"] or (KERNEL in r["Kernel_Name"] and "K_STEP" in r["Kernel_Name"]) or (KERNEL in r["Kernel_Name"] and ", 0>" in r["Kernel_Name"]):
       acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
   return {k: statistics.median(v[len(v) // 5:]) for k, v in acc.items()}
@@ -21,9 +22,9 @@ def counters(d):
 pm = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
   pm.update(counters(d))
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 if stats:
-  shutil.copy(stats[0], os.path.join("profiles", "%s_%s_kernel_stats.csv" % (rnd, tag)))
+  shutil.copy(stats[-1], os.path.join("profiles", "%s_%s_kernel_stats.csv" % (rnd, tag)))
 bench_dst = os.path.join("profiles", "%s_%s_bench.json" % (rnd, tag))
 shutil.copy(os.path.join(src, "bench.json"), bench_dst)
 out = {"tag": tag, "kernel": "sgw::k_engine<sgw::Island, K_STEP> (65536 envs, 1024 waves)", "pmc_median_per_launch": pm}
@@ -45,8 +46,7 @@ if os.path.exists(os.path.join(src, "phase_stamps.txt")):
   shutil.copy(os.path.join(src, "phase_stamps.txt"), os.path.join("profiles", "%s_%s_phase_stamps.txt" % (rnd, tag)))
 for wl, kname in (("firemaker_ex_ma", "Firemaker"), ("aintelope_savanna", "Savanna")):
   fm = {}
-  for f in glob.glob(os.path.join(src, "pmc_" + wl, "*", "*_counter_collection.csv")) + \
-           (glob.glob(os.path.join(src, "pmc_fm", "*", "*_counter_collection.csv")) if wl == "firemaker_ex_ma" else []):
+  for f in sorted(glob.glob(os.path.join(src, "pmc_" + wl, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
     acc = {}
     for r in csv.DictReader(open(f)):
       if kname in r["Kernel_Name"] and (", 0>(" in r["Kernel_Name"] or "Li0E" in r["Kernel_Name"]):
