@@ -318,6 +318,29 @@ def main():
                      "all listed outputs written every step"}
     eng2.close()
 
+  # multi-agent families: the same round loop with the agent-centric windows produced every round (what the Zoo
+  # wrapper hands to the agents): one step launch + one window launch per round, issued from Python (host cost ~15 us per round,
+  # below the device time), after the main measurement so that it cannot disturb it
+  with_views = None
+  if (a.workload != "mixed" and world == 1 and getattr(engines[0]["spec"], "view_shapes", None) and engines[0]["spec"].A > 1
+      and "agent_pos" in engines[0]["wl"]["outputs"] and not getattr(engines[0]["spec"], "rotating_views", False)):
+    e = engines[0]
+    eng = e["eng"]
+    vb = int(eng._lib.sgw_view_bytes(eng._h))
+    vbuf = torch.empty((e["n"], vb), dtype=torch.uint8, device=device)
+    acts = e["acts"]
+    nv = int(min(acts.shape[0], 400))
+    for t in range(min(nv, 50)):
+      eng.step(acts[t]); eng.agent_views(out=vbuf)
+    torch.cuda.synchronize(device)
+    v0 = time.perf_counter()
+    for t in range(nv):
+      eng.step(acts[t]); eng.agent_views(out=vbuf)
+    torch.cuda.synchronize(device)
+    vdt = (time.perf_counter() - v0) / nv
+    with_views = {"value": e["n"] / vdt, "unit": "env-steps/s", "us_per_round": vdt * 1e6, "view_bytes_per_env": vb, "rounds": nv,
+                  "note": "sgw_step + sgw_agent_views per round, both launches issued from Python"}
+
   if rank == 0:
     n_rank = sum(e["n"] for e in engines)
     alg_bytes = sum(e["n"] * e["wl"]["b_step"] for e in engines)      # algorithmic bytes of one bench step on this rank
@@ -382,6 +405,8 @@ def main():
           rl["frac"] = rl["achieved"] / VALU_PEAK_GINST
           rl["valu_insts_per_launch"] = valu
           rl["valu_source"] = "profiles/%s (separate rocprofv3 --pmc pass of this command; a constant in this run)" % VALU_BOUND[a.workload]
+    if with_views is not None:
+      line["with_agent_views"] = with_views
     if fused is not None:
       line["fused_rollout"] = fused
     if world == 1 and not a.no_cpu_baseline and a.workload == "island_navigation_ex":
