@@ -54,7 +54,7 @@ struct sgw_engine {
   int device;
   long long n_envs, n_pad, env_id_base;
   uint8_t* tables_dev;     // static_board | art | aux | value_map
-  uint64_t* state_dev;     // [words][n_pad]
+  uint64_t* state_dev;     // pair layout [env-wave][word pair][lane][2] (sgw_common.hpp state_index); canonical [words][n_pad] only through sgw_get/set_state
   const uint8_t* ep_bits;
   int ep_bits_n;
   unsigned long long ep_seed;

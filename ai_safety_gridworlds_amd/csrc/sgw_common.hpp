@@ -37,7 +37,7 @@ struct KArgs {
   LdsPlan lp;
   int need;                  // LN_* bits of the requested outputs (host-computed: one scalar instead of 14 pointer tests)
   const uint8_t* tables;     // device copy: static_board | art | aux (3 x SGW_MAX_CELLS) | value_map f32[128] | params f64[48]
-  uint64_t* state;           // [words][n_pad]
+  uint64_t* state;           // pair layout [env-wave][word pair][lane][2] (state_index below)
   long long n_pad, n_envs, env_id_base;
   const int8_t* actions;     // [n, A] or nullptr (synthetic)
   const uint8_t* mask;       // reset mask or nullptr
