@@ -188,7 +188,11 @@ int sgw_step(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, void*
 /* T consecutive sgw_step launches (one kernel launch per step, host loop in C): actions_dev int8
  * [T, N, A].  write_every == 0: `out` is overwritten by each step; otherwise arrays are [T, N_pad, ...].
  * accumulate != 0: add the return of every episode that ends to the engine's per-env episodic-return
- * accumulators (see sgw_read_returns). */
+ * accumulators (see sgw_read_returns).
+ * T >= 8: the second call with the same (actions_dev, T, write_every, out pointers, accumulate) captures its T launches into
+ * a hipGraph on an engine-owned stream and replays it on `stream` from then on -- refill the action buffer in place to get the
+ * benefit (one host launch costs ~5 us, a replayed one 0.2 us); SGW_STEP_GRAPHS=0 in the environment turns this off.  The
+ * contents of the buffers are read when the launches run, so replays see the refilled actions. */
 int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out,
                int accumulate, void* stream);
 
