@@ -418,8 +418,13 @@ struct Firemaker {
     }
 #endif
     for (int p0 = 0; p0 < nc;) {                                       // scalar loop
+      // (two chunks per iteration -- spread_chunks<2>, two independent chains per lane -- measured 1 % faster, at the price of 4 VGPRs
+      // spilled to scratch in the fused-rollout instantiation: off)
+#ifdef SGW_FM_TWO_CHUNKS
       if (nc - p0 > 64) { spread_chunks<2>(p0, nc, fw, list, nfw, v25, valid, ws, q, l, g, cx); p0 += 128; }
-      else { spread_chunks<1>(p0, nc, fw, list, nfw, v25, valid, ws, q, l, g, cx); p0 += 64; }
+      else
+#endif
+      { spread_chunks<1>(p0, nc, fw, list, nfw, v25, valid, ws, q, l, g, cx); p0 += 64; }
     }
     lds_wave_sync();
 #pragma unroll
