@@ -469,7 +469,9 @@ int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every,
     if (g.actions == actions_dev && g.T == T && g.write_every == (write_every != 0) && g.accumulate == (accumulate != 0) &&
         g.has_out == (out != nullptr) && memcmp(&g.out, &key_out, sizeof(key_out)) == 0) { hit = &g; break; }
   if (!hit) {                                   // first sighting: remember the arguments, launch directly
-    if (e->graphs.size() >= 256) {              // bounded: drop the least recently used capture
+    // bounded (256 captures, 64 Ki kernel nodes in all): drop the least recently used captures
+    auto nodes = [&]() { long long n = T; for (auto& g : e->graphs) n += g.T; return n; };
+    while (!e->graphs.empty() && (e->graphs.size() >= 256 || nodes() > 65536)) {
       size_t worst = 0;
       for (size_t i = 1; i < e->graphs.size(); ++i) if (e->graphs[i].last_use < e->graphs[worst].last_use) worst = i;
       if (e->graphs[worst].exec) (void)hipGraphExecDestroy(e->graphs[worst].exec);
