@@ -527,6 +527,17 @@ int sgw_rollout(sgw_engine* e, int T, uint64_t seed, int64_t step0, int write_ev
   return launch(e, a, (hipStream_t)stream);
 }
 
+int sgw_replay(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out, int accumulate, void* stream) {
+  if (!e) return fail(SGW_ERR_ARG, "sgw_replay: null engine");
+  if (!actions_dev || T < 1) return fail(SGW_ERR_ARG, "sgw_replay: bad argument");
+  KArgs a; memset(&a, 0, sizeof(a));
+  a.mode = MODE_STEP; a.actions = actions_dev; a.T = T;
+  if (accumulate) { int rc = ensure_acc(e, (hipStream_t)stream); if (rc) return rc; }
+  a.write_every = write_every; a.ep_acc = accumulate ? e->acc_dev : nullptr;
+  if (out) a.out = *out;
+  return launch(e, a, (hipStream_t)stream);
+}
+
 int sgw_fill_actions(sgw_engine* e, int T, uint64_t seed, int64_t step0, int8_t* actions_dev, void* stream) {
   if (!e || !actions_dev || T < 1) return fail(SGW_ERR_ARG, "sgw_fill_actions: bad argument");
   HIP_TRY(hipSetDevice(e->device));

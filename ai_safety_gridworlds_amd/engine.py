@@ -157,6 +157,19 @@ class BatchedEngine(object):
                                   C.byref(self._out), 1 if accumulate else 0, self._stream()), "sgw_rollout")
     return self._views()
 
+  def replay(self, actions, write_every=False, accumulate=False):
+    """actions int8 [T, N(, A)] resident on the device: the T steps in ONE fused launch (state in registers), output for
+    output what step_n gives for the same buffer."""
+    T = int(actions.shape[0])
+    assert actions.dtype == torch.int8 and actions.is_contiguous() and actions.device == self.device
+    assert actions.numel() == T * self.n_envs * self.spec.A
+    want_T = T if write_every else 1
+    if self._T != want_T:
+      self._alloc_outputs(want_T)
+    N.check(self._lib.sgw_replay(self._h, actions.data_ptr(), T, 1 if write_every else 0, C.byref(self._out),
+                                 1 if accumulate else 0, self._stream()), "sgw_replay")
+    return self._views()
+
   def fill_actions(self, T, seed, step0=0):
     """int8 [T, N] (or [T, N, A]) synthetic actions, same stream the fused rollout draws."""
     shape = (T, self.n_envs) + ((self.spec.A,) if self.spec.A > 1 else ())

@@ -204,6 +204,12 @@ int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every,
 int sgw_rollout(sgw_engine* e, int T, uint64_t seed, int64_t step0, int write_every,
                 const sgw_out* out, int accumulate, void* stream);
 
+/* The same fused launch over the CALLER's actions: actions_dev int8 [T, N, A] (an action tape: the reference's
+ * demonstrations replay, demonstrations.py:65-80, an open-loop plan, a logged episode).  Identical, output for output, to
+ * sgw_step_n over the same buffer; the state stays in registers between the steps. */
+int sgw_replay(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out, int accumulate,
+               void* stream);
+
 /* End-of-batch episodic returns: out_dev double [A*K + 1] = (sum over finished episodes of the
  * episode return vector, number of finished episodes), summed over this engine's envs in a fixed
  * order (deterministic, no atomics: per-wave accumulator rows summed in lane order + a tree reduction).  This is the

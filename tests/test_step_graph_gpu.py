@@ -65,3 +65,31 @@ def test_step_n_graph_write_every():
     for k in OUTS:
       assert torch.equal(got[k][t], want[k]), (k, t)
   a.close(); b.close()
+
+
+@pytest.mark.parametrize("name,kw", [("island_navigation_ex", {}), ("boat_race_ex", dict(level=3)), ("safe_interruptibility", dict(level=1)),
+                                     ("island_navigation_ex_ma", {}), ("firemaker_ex_ma", dict(amount_agents=3))])
+def test_replay_of_an_action_tape_equals_step_n(name, kw):
+  """sgw_replay (one fused launch over the caller's [T, N, A] actions) == sgw_step_n over the same buffer: every output of every
+  step, the final state and the episodic returns."""
+  n, T = 2000, 40
+  spec = make_spec(name, **kw)
+  outs = OUTS if spec.A == 1 else ("board", "reward", "step_type", "term_reason", "cumulative")
+  def mk():
+    e = BatchedEngine(spec, n, device=DEV, outputs=outs)
+    if name == "safe_interruptibility":
+      e.set_episode_bits(None, seed=5)
+    if getattr(spec, "needs_rng", False) or name == "firemaker_ex_ma":
+      e.set_rng_seeds(np.arange(n) + 9)
+    e.reset()
+    return e
+  a, b = mk(), mk()
+  acts = a.fill_actions(T, 21)
+  got = {k: v.clone() for k, v in a.replay(acts, write_every=True, accumulate=True).items()}
+  want = {k: v.clone() for k, v in b.step_n(acts, write_every=True, accumulate=True).items()}
+  torch.cuda.synchronize()
+  for k in outs:
+    assert torch.equal(got[k], want[k]), k
+  assert torch.equal(a.get_state(), b.get_state())
+  assert torch.equal(a.read_returns(), b.read_returns())
+  a.close(); b.close()
