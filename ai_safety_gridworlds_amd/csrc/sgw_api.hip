@@ -648,6 +648,11 @@ static int view_stage_bytes(const ViewSpec& v) {
   return (mx + 16 + 15) / 16 * 16;
 }
 
+static bool views_all_small(const ViewSpec& v) {
+  for (int a = 0; a < v.A; ++a) if (v.vh[a] * v.vw[a] > WAVE) return false;
+  return true;
+}
+
 static int check_rotation(const sgw_engine* e, const ViewSpec& v, const uint8_t* flags) {
   if (!flags) return SGW_OK;
   for (int a = 0; a < v.A; ++a)
@@ -663,6 +668,14 @@ int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agen
   if (v.total <= 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_agent_views: the spec defines no agent views");
   if (check_rotation(e, v, agent_flags_dev)) return SGW_ERR_UNSUPPORTED;
   HIP_TRY(hipSetDevice(e->device));
+  if (views_all_small(v)) {                                              // every window <= 64 cells: one thread per byte
+    long long total = e->n_envs * (long long)v.total;
+    int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(k_agent_views_small, dim3(blocks), dim3(256), 0, (hipStream_t)stream, board_dev, agent_pos_dev,
+                       agent_flags_dev, e->n_envs, v, outside_chr, views_dev);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
+  }
   long long total = e->n_envs * (long long)v.A * WAVE;                   // one wave per (env, agent) window
   int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   const int lds_per_wave = view_stage_bytes(v);
@@ -680,6 +693,14 @@ int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_
   if (v.total <= 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_agent_layer_views: the spec defines no agent views");
   if (check_rotation(e, v, agent_flags_dev)) return SGW_ERR_UNSUPPORTED;
   HIP_TRY(hipSetDevice(e->device));
+  if (views_all_small(v)) {
+    long long total = e->n_envs * (long long)v.total * n_layers;
+    int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(k_agent_layer_views_small, dim3(blocks), dim3(256), 0, (hipStream_t)stream, layers_dev, agent_pos_dev,
+                       agent_flags_dev, e->n_envs, v, layer_chars_dev, n_layers, outside_chr, out_dev);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
+  }
   long long total = e->n_envs * (long long)v.A * n_layers * WAVE;        // one wave per (env, agent, layer) window
   int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   const int lds_per_wave = view_stage_bytes(v);

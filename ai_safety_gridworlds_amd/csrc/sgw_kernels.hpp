@@ -812,6 +812,45 @@ __global__ void k_agent_views(const uint8_t* board, const uint8_t* pos, const ui
   }
 }
 
+// Small windows (every window <= 64 cells, e.g. the 5 x 5 windows of island_navigation_ex_ma): a wave per window would leave most
+// lanes idle (131 072 waves for 65 536 two-agent envs); one thread per output byte keeps the stores contiguous across lanes
+// and costs ~60 instructions per 64 bytes.  `per_env` = bytes per env (window bytes x layers for the layer variant).
+__device__ inline uint8_t small_view_byte(const uint8_t* src_env, const uint8_t* pos, const uint8_t* flags, const ViewSpec& v,
+                                          uint8_t pad, long long e, int ag, int cellidx) {
+  const int vw = v.vw[ag];
+  int vr = cellidx / vw, vc = cellidx - vr * vw;
+  const long long ea = e * v.A + ag;
+  if (flags) view_unrotate((flags[ea] >> 3) & 3, vw, vr, vc);
+  const int r = (int)pos[ea * 2] - v.up[ag] + vr, c = (int)pos[ea * 2 + 1] - v.left[ag] + vc;
+  return (r < 0 || r >= v.H || c < 0 || c >= v.W) ? pad : src_env[r * v.W + c];
+}
+__global__ void k_agent_views_small(const uint8_t* board, const uint8_t* pos, const uint8_t* flags, long long n, ViewSpec v,
+                                    uint8_t outside, uint8_t* views) {
+  const long long total = n * v.total;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i / v.total;
+    int b = (int)(i - e * v.total), ag = 0;
+#pragma unroll
+    for (int k = 1; k < SGW_MAX_AGENTS; ++k) if (k < v.A && b >= v.off[k]) ag = k;
+    views[i] = small_view_byte(board + e * (long long)(v.H * v.W), pos, flags, v, outside, e, ag, b - v.off[ag]);
+  }
+}
+__global__ void k_agent_layer_views_small(const uint8_t* layers, const uint8_t* pos, const uint8_t* flags, long long n, ViewSpec v,
+                                          const uint8_t* chars, int L, uint8_t outside, uint8_t* out) {
+  const long long per_env = (long long)v.total * L, total = n * per_env;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i / per_env;
+    int b = (int)(i - e * per_env), ag = 0;
+#pragma unroll
+    for (int k = 1; k < SGW_MAX_AGENTS; ++k) if (k < v.A && b >= v.off[k] * L) ag = k;
+    b -= v.off[ag] * L;
+    const int cells = v.vh[ag] * v.vw[ag];
+    const int li = b / cells;
+    out[i] = small_view_byte(layers + (e * L + li) * (long long)(v.H * v.W), pos, flags, v, (uint8_t)(chars[li] == outside), e, ag,
+                             b - li * cells);
+  }
+}
+
 // per-layer agent windows: out[e][agent][layer][vr][vc]; one wave per (env, agent, layer)
 __global__ void k_agent_layer_views(const uint8_t* layers, const uint8_t* pos, const uint8_t* flags, long long n, ViewSpec v,
                                     const uint8_t* chars, int L, uint8_t outside, uint8_t* out, int lds_per_wave) {

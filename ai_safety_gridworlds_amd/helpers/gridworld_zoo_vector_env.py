@@ -130,8 +130,9 @@ class GridworldZooVectorEnv(object):
     return obs, dict(rewards), dict(terms), dict(truncs), infos
 
   def reset(self, mask=None):
-    ts = self._env.reset(mask)
-    obs, _, _, _, infos = self._pack(ts.observation)
+    o = self._env.engine.reset(mask)             # straight to the engine: the L4 TimeStep bookkeeping is a dozen torch launches
+    self._env._last = o
+    obs, _, _, _, infos = self._pack(o)
     return obs, infos
 
   def step(self, actions):
@@ -152,5 +153,6 @@ class GridworldZooVectorEnv(object):
         else:
           col.fill_(int(v))
       acts = self._acts
-    ts = self._env.step(acts.reshape(-1) if sp.A == 1 else acts)
-    return self._pack(ts.observation)
+    o = self._env.engine.step(acts.reshape(-1) if sp.A == 1 else acts)
+    self._env._last = o
+    return self._pack(o)
