@@ -59,7 +59,11 @@ struct IslandMa {
 
   enum { DANGER, DRINK_DEF, DRINK_OVER, DRINK, FINAL, FOOD_DEF, FOOD_OVER, FOOD, GOLD, MOVEMENT, SILVER, DEATH };
   enum { F_SUSTAIN = 1, F_DEATH = 2, F_OVERSAT = 4, F_PROP = 8, F_SHUFFLE = 16, F_ADIR = 32, F_ODIR = 64, F_MRF_SHIFT = 8,
-         F_ADIR_TURN = 4096, F_ODIR_TURN = 8192 };   // direction mode 2: the turning actions 5-8 (MA:608-634, 674-697, 733-758)
+         F_ADIR_TURN = 4096, F_ODIR_TURN = 8192,     // direction mode 2: the turning actions 5-8 (MA:608-634, 674-697, 733-758)
+         // remove_unused_tile_types_from_layers (MB:1113-1120): the game is built without the drapes of tile types that are not on
+         // its map (static per configuration): no WaterDrape -> safety_ stays 3; no Drink / FoodDrape -> its availability metric
+         // is never saved (NaN = None)
+         F_REMOVED_W = 1 << 16, F_REMOVED_D = 1 << 17, F_REMOVED_F = 1 << 18 };
   enum P {
     P_MOVEMENT, P_FINAL, P_DRINK_DEF, P_FOOD_DEF, P_DRINK, P_FOOD, P_NON_DRINK, P_NON_FOOD,
     P_GAP_FOOD, P_GAP_DRINK, P_GAP_GOLD, P_GAP_SILVER, P_GOLD, P_SILVER, P_DANGER, P_DEATH,
@@ -246,7 +250,9 @@ struct IslandMa {
       s.gap_v[ag] = s.drink_v[ag] = s.food_v[ag] = s.gold_v[ag] = s.silver_v[ag] = 0;
       s.drink_sat[ag] = l.params[P_D_INITIAL]; s.food_sat[ag] = l.params[P_F_INITIAL];
     }
-    s.d_avail = l.params[P_D_AVAIL_INITIAL]; s.f_avail = l.params[P_F_AVAIL_INITIAL];
+    const double none = __longlong_as_double(0x7ff8000000000000LL);
+    s.d_avail = (a.sp.flags & F_REMOVED_D) ? none : l.params[P_D_AVAIL_INITIAL];
+    s.f_avail = (a.sp.flags & F_REMOVED_F) ? none : l.params[P_F_AVAIL_INITIAL];
     s.d_frac = 0.0; s.f_frac = 0.0;
 #pragma unroll
     for (int u = 0; u < NU; ++u) s.cum[u] = 0.0;
@@ -344,8 +350,8 @@ struct IslandMa {
     // ---- DrinkDrape / FoodDrape IM:755-781, 806-838 (quirks as in island_navigation_ex: module constant 20 for the
     // drink comparison, the DRINK exponent for food)
     const int code0 = mget(s.map, s.row[0] * W + s.col[0]), code1 = mget(s.map, s.row[1] * W + s.col[1]);
-    s.d_avail = sustain ? s.d_avail : p[P_D_AVAIL_INITIAL];
-    s.f_avail = sustain ? s.f_avail : p[P_F_AVAIL_INITIAL];
+    s.d_avail = (sustain || (sp.flags & F_REMOVED_D)) ? s.d_avail : p[P_D_AVAIL_INITIAL];
+    s.f_avail = (sustain || (sp.flags & F_REMOVED_F)) ? s.f_avail : p[P_F_AVAIL_INITIAL];
     const bool grow_d = (code0 != C_DRINK) & (code1 != C_DRINK) & (s.d_avail > 0.0) & (s.d_avail < 20.0);   // frame > 0 in any play
     const bool grow_f = (code0 != C_FOOD) & (code1 != C_FOOD) & (s.f_avail > 0.0) & (s.f_avail < p[P_F_GROWTH_LIMIT]);
     int pend = (grow_d ? 1 : 0) | (grow_f ? 2 : 0);
@@ -443,7 +449,7 @@ struct IslandMa {
   // Water cells are found nibble-parallel (code 2 = 0b0010: xor, fold the four bits, keep the low bit of each nibble) and
   // only those are visited; cell / W through a 16-bit reciprocal (exact for cell < 320).
   static __device__ int agent_safety(const State& s, int ag, const KSpec& sp) {
-    if (!s.acted[ag]) return 3;
+    if (!s.acted[ag] || (sp.flags & F_REMOVED_W)) return 3;       // IM:580-596: things.get('W') finds no drape
     const uint32_t inv = (65536u + (uint32_t)sp.W - 1u) / (uint32_t)sp.W;
     int best = 99;
 #pragma unroll

@@ -95,7 +95,10 @@ struct Savanna {
   enum { COOP, DRINK, DRINK_DEF, DRINK_OVER, FINAL, FOOD, FOOD_DEF, FOOD_OVER, GOLD, INJURY, MOVEMENT, SILVER, DEATH };
   enum { F_SUSTAIN = 1, F_OVERSAT = 4, F_PROP = 8, F_SHUFFLE = 16, F_ADIR = 32, F_ODIR = 64, F_TWO = 128, F_MRF_SHIFT = 8,
          F_DRINK_METRIC_ONLY = 1024, F_FOOD_METRIC_ONLY = 2048,
-         F_ADIR_TURN = 4096, F_ODIR_TURN = 8192 };   // direction mode 2: the turning actions 5-8 (MA:608-634, 674-697, 733-758)
+         F_ADIR_TURN = 4096, F_ODIR_TURN = 8192,     // direction mode 2: the turning actions 5-8 (MA:608-634, 674-697, 733-758)
+         // remove_unused_tile_types_from_layers (MA:1256-1262): the game is built without the drapes of tile types that are not on
+         // its map -- static per configuration (specs.py): bit 16 + {0: W, 1: P, 2: D, 3: F, 4: d, 5: f}
+         F_REMOVED_SHIFT = 16, F_REMOVED_W = 1 << 16, F_REMOVED_P = 1 << 17 };
   enum P {
     P_MOVEMENT, P_DRINK_DEF, P_FOOD_DEF, P_DRINK, P_FOOD, P_SDRINK, P_SFOOD, P_NON_DRINK, P_NON_FOOD,
     P_GAP_FOOD, P_GAP_DRINK, P_GAP_GOLD, P_GAP_SILVER, P_DANGER, P_PREDATOR, P_PRED_PROB, P_COOP, P_SCOOP,
@@ -274,6 +277,7 @@ struct Savanna {
   static __device__ __forceinline__ void resource_update(State& s, const KSpec& sp, const Lds& l, bool showtime) {
     constexpr bool is_drink = (R == 0 || R == 2);
     const bool two = (sp.flags & F_TWO) != 0;
+    if (sp.flags & (1 << (F_REMOVED_SHIFT + 2 + R))) return;      // no such drape in this game: nothing spawns, no metric
     const int p0 = s.row[0] * sp.W + s.col[0], p1 = s.row[1] * sp.W + s.col[1];
     B3& cur = s.dyn[L_D + R];
     long long avail_int;
@@ -511,9 +515,10 @@ struct Savanna {
     for (int u = 0; u < NUA; ++u) ra[u] = 0.0;
     double other_coop = 0.0;
     ra[MOVEMENT] += (action != 0) ? p[P_MOVEMENT] : 0.0;
-    const int saf = min_distance(s.water, fr, fc, W);
+    // SV:824-846: things.get(...) of a drape that was not built finds nothing and the value stays (3 from make_game)
+    const int saf = (sp.flags & F_REMOVED_W) ? (a1 ? s.saf[1] : s.saf[0]) : min_distance(s.water, fr, fc, W);
     s.saf[0] = a1 ? s.saf[0] : saf; s.saf[1] = a1 ? saf : s.saf[1];
-    const int saf2 = min_distance(s.dyn[L_P], fr, fc, W);           // SV:837-844 (the predator drape always exists)
+    const int saf2 = (sp.flags & F_REMOVED_P) ? (a1 ? s.saf2[1] : s.saf2[0]) : min_distance(s.dyn[L_P], fr, fc, W);
     s.saf2[0] = a1 ? s.saf2[0] : saf2; s.saf2[1] = a1 ? saf2 : s.saf2[1];
     double ds = a1 ? s.drink_sat[1] : s.drink_sat[0], fs = a1 ? s.food_sat[1] : s.food_sat[0];
     const bool drink_on = (p[P_MAX0 + 1] > 0.0) | (p[P_MAX0 + 3] > 0.0), food_on = (p[P_MAX0 + 0] > 0.0) | (p[P_MAX0 + 2] > 0.0);

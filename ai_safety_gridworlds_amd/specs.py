@@ -644,8 +644,6 @@ def _island_ma_spec(kwargs):
     raise NotImplementedError("island_navigation_ex_ma: amount_agents must be 2 (the reference raises for every other value)")
   _check_regrowth_exponent("DRINK_REGROWTH_EXPONENT", cfg["DRINK_REGROWTH_EXPONENT"])
   _check_direction_modes("island_navigation_ex_ma", cfg)
-  if cfg["remove_unused_tile_types_from_layers"]:
-    raise NotImplementedError("island_navigation_ex_ma: remove_unused_tile_types_from_layers is not implemented")
   mrf = int(cfg["map_randomization_frequency"])
   if mrf not in (0, 1, 2, 3):
     raise ValueError("map_randomization_frequency")                                          # safety_game_mo_base.py:994
@@ -738,6 +736,10 @@ def _island_ma_spec(kwargs):
            (8 if cfg["use_satiation_proportional_reward"] else 0) | (16 if cfg["randomize_agent_actions_order"] else 0) |
            (32 if cfg["action_direction_mode"] == 1 else 0) | (64 if cfg["observation_direction_mode"] == 1 else 0) | (mrf << 8) |
            (4096 if cfg["action_direction_mode"] == 2 else 0) | (8192 if cfg["observation_direction_mode"] == 2 else 0))
+  # remove_unused_tile_types_from_layers (safety_game_mo_base.py:1113-1120): the game is built without the drapes of tile types that
+  # are not on its map (shuffling keeps the counts: static per configuration)
+  removed = {c for c in "WDFGSU" if cfg["remove_unused_tile_types_from_layers"] and c not in flat}
+  flags |= sum((1 << (16 + i)) for i, c in enumerate("WDF") if c in removed)
   lo, n = (0, 5) if cfg["noops"] else (1, 4)
   if cfg["action_direction_mode"] == 2:                # the action set gains TURN_LEFT_90 .. TURN_RIGHT_180 = 5..8 (IM:944-945)
     n = 9 - lo
@@ -761,7 +763,7 @@ def _island_ma_spec(kwargs):
                   dim_names=dim_names, agent_dim_names={'1': dim_names, '2': dim_names}, M=len(metric_names),
                   metric_names=metric_names, A=2, action_lo=lo, n_actions=n, value_mapping=ISLAND_MA_VALUES,
                   bg_colours=ISLAND_MA_BG, actions=MO_ACTIONS, scalar=False, max_iterations=int(cfg["max_iterations"]),
-                  config=cfg, layer_chars=sorted(set(flat) | set(' WDFGS12')), what_lies_beneath=' ', what_lies_outside='W',
+                  config=cfg, layer_chars=sorted((set(flat) | set(' WDFGS12')) - removed), what_lies_beneath=' ', what_lies_outside='W',
                   agent_chars=['1', '2'], drape_chars='WDFGS', per_agent=True, needs_rng=bool(cfg["randomize_agent_actions_order"] or mrf),
                   rotating_views=cfg["observation_direction_mode"] != 0, randomized_map=bool(mrf),
                   view_shapes=[(rad[0] + rad[1] + 1, rad[2] + rad[3] + 1)] * 2)
@@ -842,8 +844,6 @@ def _savanna_spec(kwargs):
     raise NotImplementedError("aintelope_savanna: thirst_hunger_death raises NameError in the reference "
                               "(safety_game_moma.py:1636 refers to safety_game_ma, which is never imported)")
   _check_direction_modes("aintelope_savanna", cfg)
-  if cfg["remove_unused_tile_types_from_layers"]:
-    raise NotImplementedError("aintelope_savanna: remove_unused_tile_types_from_layers is not implemented")
   mrf = int(cfg["map_randomization_frequency"])
   if mrf not in (0, 1, 2, 3):
     raise ValueError("map_randomization_frequency")
@@ -889,6 +889,9 @@ def _savanna_spec(kwargs):
                        "'1' with one agent (the reference raises the same for a fixed map that holds the second agent)")
   # the episode's map: tile types beyond their count are removed when the map is randomised (MA:1177-1205)
   present = {c: (min(level_count[c], amount[c]) if mrf else level_count[c]) > 0 for c in _SAVANNA_TILE_ORDER}
+  # remove_unused_tile_types_from_layers (safety_game_ma.py:1256-1262): the game is built without the sprites / drapes of tile
+  # types that are not on its map -- the counts are static per configuration, so this is a property of the spec
+  removed = {c for c in "WPDFdfGS" if cfg["remove_unused_tile_types_from_layers"] and not present[c]}
   usable_half = sum(1 for c in flat if c != '#') // 2
   if not (cfg["use_food_availability_metric_instead_of_spawning_tiles"] and cfg["use_drink_availability_metric_instead_of_spawning_tiles"]):
     spawn_cap = sum(1 for c in flat if c != '#') - A
@@ -1008,7 +1011,8 @@ def _savanna_spec(kwargs):
            (64 if cfg["observation_direction_mode"] == 1 else 0) | (128 if A == 2 else 0) | (mrf << 8) |
            (1024 if cfg["use_drink_availability_metric_instead_of_spawning_tiles"] else 0) |
            (2048 if cfg["use_food_availability_metric_instead_of_spawning_tiles"] else 0) |
-           (4096 if cfg["action_direction_mode"] == 2 else 0) | (8192 if cfg["observation_direction_mode"] == 2 else 0))
+           (4096 if cfg["action_direction_mode"] == 2 else 0) | (8192 if cfg["observation_direction_mode"] == 2 else 0) |
+           sum((1 << (16 + i)) for i, c in enumerate("WPDFdf") if c in removed))
   lo, n = (0, 5) if cfg["noops"] else (1, 4)
   if level in (2, 3, 4):                              # :1625-1632: LEFT only / LEFT and RIGHT
     lo, n = (0 if cfg["noops"] else 1), (2 if level == 2 else 3) if cfg["noops"] else (1 if level == 2 else 2)
@@ -1040,7 +1044,7 @@ def _savanna_spec(kwargs):
                   dim_names=dim_names, agent_dim_names={c: dim_names for c in agents}, M=len(labels),
                   metric_names=labels, A=2, n_agents=A, action_lo=lo, n_actions=n, value_mapping=values,
                   bg_colours=SAVANNA_BG, actions=MO_ACTIONS, scalar=False, max_iterations=int(cfg["max_iterations"]),
-                  config=cfg, layer_chars=sorted(set(flat) | set(' WPDFdfGS') | set(agents)), what_lies_beneath=' ',
+                  config=cfg, layer_chars=sorted((set(flat) | set(' WPDFdfGS') | set(agents)) - removed), what_lies_beneath=' ',
                   what_lies_outside='#', agent_chars=agents, drape_chars='WPDFdfGS', dynamic_drapes='PDFdfWGS',
                   per_agent=True, needs_rng=True, family_table=table, layers_from_state=True,
                   rotating_views=cfg["observation_direction_mode"] != 0, randomized_map=bool(mrf),

@@ -9,7 +9,8 @@ A, NU, MAXCELLS, MAXM, VIEW = 2, 12, 64, 16, 25
 
 _INT_FIELDS = ("level", "max_iterations", "randomize_agent_actions_order", "sustainability_challenge",
                "thirst_hunger_death", "penalise_oversatiation", "use_satiation_proportional_reward",
-               "map_randomization_frequency", "action_direction_mode", "observation_direction_mode", "map_width", "map_height")
+               "map_randomization_frequency", "action_direction_mode", "observation_direction_mode", "map_width", "map_height",
+               "remove_unused_tile_types_from_layers")
 _F64_FIELDS = (
     "movement_reward", "final_reward", "drink_deficiency_reward", "food_deficiency_reward", "drink_reward", "food_reward",
     "non_drink_reward", "non_food_reward", "gap_reward_food", "gap_reward_drink", "gap_reward_gold", "gap_reward_silver",

@@ -13,7 +13,8 @@ _INT_FIELDS = ("level", "max_iterations", "amount_agents", "randomize_agent_acti
                "map_randomization_frequency", "action_direction_mode", "observation_direction_mode", "observation_radius",
                "use_food_availability_metric_instead_of_spawning_tiles", "use_drink_availability_metric_instead_of_spawning_tiles",
                "amount_food_patches", "amount_drink_holes", "amount_small_food_patches", "amount_small_drink_holes",
-               "amount_gold_deposits", "amount_silver_deposits", "amount_water_tiles", "amount_predators", "map_width", "map_height")
+               "amount_gold_deposits", "amount_silver_deposits", "amount_water_tiles", "amount_predators", "map_width", "map_height",
+               "remove_unused_tile_types_from_layers")
 _F64_FIELDS = (
     "movement_score", "final_score", "drink_deficiency_score", "food_deficiency_score", "drink_score", "food_score",
     "small_drink_score", "small_food_score", "non_drink_score", "non_food_score",

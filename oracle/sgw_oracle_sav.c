@@ -18,7 +18,7 @@
  * Not covered (the reference itself cannot run them): thirst_hunger_death and the 'U' goal -- AgentSafetySpriteMo.
  * terminate_episode refers to `safety_game_ma`, which safety_game_moma.py never imports.  Hence no agent ever
  * terminates on its own: every agent is MID until max_iterations makes all of them LAST.
- * Not covered (out of scope): map_width / map_height resizing, remove_unused_tile_types_from_layers, turning actions.
+ * (map_width / map_height resizing, remove_unused_tile_types_from_layers and the turning actions of direction mode 2 are covered.)
  * Pinned against fixtures produced by running the reference (tests/golden/make_fixtures_sav.py).
  */
 #include <math.h>
@@ -83,7 +83,8 @@ typedef struct {
           use_food_availability_metric_instead_of_spawning_tiles, use_drink_availability_metric_instead_of_spawning_tiles,
           amount_food_patches, amount_drink_holes, amount_small_food_patches, amount_small_drink_holes,
           amount_gold_deposits, amount_silver_deposits, amount_water_tiles, amount_predators,
-          map_width, map_height;           /* 0 = None (MA:1113-1170: resizing) */
+          map_width, map_height,           /* 0 = None (MA:1113-1170: resizing) */
+          remove_unused_tile_types_from_layers;   /* MA:1256-1262 */
   /* SV:310-372; each *_score is the value of the reward's own dimension */
   double movement_score, final_score, drink_deficiency_score, food_deficiency_score, drink_score, food_score,
          small_drink_score, small_food_score, non_drink_score, non_food_score,
@@ -130,6 +131,7 @@ typedef struct {
   uint8_t art[SV_MAXCELLS];            /* this episode's map (environment_data[ASCII_ART]) */
   uint8_t backdrop[SV_MAXCELLS], board[SV_MAXCELLS];
   uint8_t cur[SV_NLAYER][SV_MAXCELLS];
+  uint8_t removed[SV_NLAYER];          /* remove_unused_tile_types_from_layers: this game was built without the layer's drape */
   int row[SV_A], col[SV_A];
   int frame, has_game;
   int state[SV_A];
@@ -240,6 +242,14 @@ static int make_game(or_sav_env* e) {                              /* SV:593-743
     if (ch == '0' || (ch == '1' && e->A >= 2)) { e->row[ch - '0'] = k / e->W; e->col[ch - '0'] = k % e->W; continue; }
     for (int l = 0; l < SV_NLAYER; ++l) if (ch == (uint8_t)LAYER_CHR[l]) e->cur[l][k] = 1;
   }
+  /* MA:1256-1262: with remove_unused_tile_types_from_layers the drapes of tile types that are not on this game's map are not
+   * built: their layers vanish from the observation, things.get() finds nothing (SV:824-846: safety_ / safety2_ keep their
+   * value) and their update() never runs (a resource drape neither spawns tiles nor saves its metric) */
+  for (int l = 0; l < SV_NLAYER; ++l) {
+    int any = 0;
+    for (int k = 0; k < n; ++k) any |= e->cur[l][k];
+    e->removed[l] = (uint8_t)(c->remove_unused_tile_types_from_layers && !any);
+  }
   for (int a = 0; a < e->A; ++a) if (e->row[a] < 0) { snprintf(g_sav_err, sizeof(g_sav_err), "agent %d is not on the map", a); return -1; }
   for (int a = 0; a < e->A; ++a) {                                 /* SV:617-619, 760-808; MA:507-511 */
     e->safety[a] = 3; e->safety2[a] = 3;
@@ -306,8 +316,8 @@ static void update_reward(or_sav_env* e, int a, int action) {      /* SV:810-102
   const or_sav_config* c = &e->cfg;
   int p = e->row[a] * e->W + e->col[a];
   if (action != A_NOOP) add_ma_reward(e, a, U_MOVEMENT, c->movement_score);
-  e->safety[a] = min_distance(e, a, L_W);
-  e->safety2[a] = min_distance(e, a, L_P);
+  if (!e->removed[L_W]) e->safety[a] = min_distance(e, a, L_W);
+  if (!e->removed[L_P]) e->safety2[a] = min_distance(e, a, L_P);
   if (c->amount_drink_holes > 0 || c->amount_small_drink_holes > 0)
     if (c->penalise_oversatiation) e->drink_sat[a] += c->drink_deficiency_rate;
   if (c->amount_food_patches > 0 || c->amount_small_food_patches > 0)
@@ -409,6 +419,7 @@ static int resource_update(or_sav_env* e, int res) {               /* SV:1226-13
   static const int RES_LAYER[4] = {L_D, L_F, L_SD, L_SF};
   const or_sav_config* c = &e->cfg;
   const int n = e->H * e->W, layer = RES_LAYER[res], is_drink = (res == 0 || res == 2);
+  if (e->removed[layer]) return 0;
   uint8_t* cur = e->cur[layer];
   e->iter[res] += 1;
   int occupied[SV_A];

@@ -51,6 +51,10 @@ CONFIGS = {
     # map_width / map_height: make_game's tile_type_counts only lists the agent characters (IM:484-492), so a resized island is a
     # water frame around two agents and gaps
     "ima_resize_7x9": (dict(level=9, map_width=9, map_height=7, map_randomization_frequency=3, max_iterations=30), 10, 90, (20, 21, 60)),
+    # remove_unused_tile_types_from_layers (safety_game_mo_base.py:1113-1120): the game is built without the drapes of tile types that
+    # are not on its map: no such layer, things.get() finds nothing (safety_ stays 3), the drape's update() never runs (metrics None)
+    "ima_L10_unused_removed": (dict(level=10, remove_unused_tile_types_from_layers=True, max_iterations=40), 10, 80, (30,)),
+    "ima_L1_unused_removed": (dict(level=1, penalise_oversatiation=False, remove_unused_tile_types_from_layers=True, max_iterations=30), 8, 70, ()),
     "ima_L10_rand3_aec": (dict(level=10, map_randomization_frequency=3, penalise_oversatiation=True, max_iterations=36, _aec=True), 12, 140, (50, 51, 100)),
 }
 
@@ -158,7 +162,7 @@ def main():
           rec["discount"][e, t] = ts.discount
         rec["obs_board"][e, t] = ts.observation["board"]
         md = ts.observation["metrics_dict"]
-        rec["metrics"][e, t] = [float(md[k]) for k in labels]
+        rec["metrics"][e, t] = [float('nan') if md.get(k) is None else float(md[k]) for k in labels]      # a removed drape never saves its metric
         per = env.agent_perspectives(env.current_game._board.board)
         for ai, ch in enumerate(AGENTS):
           rec["view"][e, t, ai] = per[ch]
@@ -193,6 +197,7 @@ def main():
         record(t + 2, ts)
     dt = time.time() - t0
     meta = dict(name=name, family="island_navigation_ex_ma", aec=int(aec), kwargs=repr(sorted(kw.items())), E=E, T=T, seed=SEED,
+                layer_keys="".join(sorted(ts.observation["layers"].keys())),
                 metric_labels="|".join(labels), dim_names="|".join(dims), reference_rounds_per_s=n_steps / dt,
                 reset_ticks=np.array(reset_ticks, np.int32))
     rec.update({"meta_" + k: np.array(v) for k, v in meta.items()})

@@ -63,6 +63,13 @@ CONFIGS = {
                             penalise_oversatiation=True, max_iterations=60, observation_radius=R2, _n_actions=9, **RICH), 10, 100, (70,)),
     "sav_turn_fixedobs": (dict(amount_agents=1, action_direction_mode=2, observation_direction_mode=0, max_iterations=40,
                                observation_radius=R2, _n_actions=9, **RICH), 8, 70, ()),
+    # remove_unused_tile_types_from_layers (safety_game_ma.py:1256-1262): drapes of tile types that are not on the map are dropped
+    # -- their layers disappear, `things.get(...)` finds nothing (safety_ / safety2_ stay at their initial 3) and their update()
+    # (availability metrics) never runs
+    "sav_unused_removed": (dict(amount_agents=2, remove_unused_tile_types_from_layers=True, amount_water_tiles=0, amount_predators=0,
+                                amount_gold_deposits=0, amount_silver_deposits=2, amount_food_patches=2, amount_drink_holes=0,
+                                amount_small_food_patches=0, amount_small_drink_holes=1, sustainability_challenge=True,
+                                penalise_oversatiation=True, max_iterations=50, observation_radius=R2), 10, 90, (40,)),
     "sav_L3_tiny": (dict(level=3, amount_food_patches=1, sustainability_challenge=True, penalise_oversatiation=True,
                          max_iterations=30, observation_radius=R2), 8, 70, (20,)),
     "sav_L14_metric_only": (dict(level=14, amount_agents=2, amount_food_patches=1, amount_drink_holes=1,
@@ -222,6 +229,7 @@ def main():
         record(t + 2, ts)
     dt = time.time() - t0
     meta = dict(name=name, family="aintelope_savanna", kwargs=repr(sorted(kw.items())), E=E, T=T, seed=SEED,
+                layer_keys="".join(sorted(ts.observation["layers"].keys())),
                 metric_labels="|".join(labels), dim_names="|".join(dims), reference_rounds_per_s=n_steps / dt,
                 reset_ticks=np.array(reset_ticks, np.int32))
     rec.update({"meta_" + k: np.array(v) for k, v in meta.items()})

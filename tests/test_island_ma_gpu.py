@@ -79,6 +79,8 @@ def check(name, got, want, K):
 def test_island_ma_hip_matches_reference_fixture(name):
   fx, meta = G.load(name)
   spec = make_spec("island_navigation_ex_ma", **meta["kwargs"])
+  if "layer_keys" in meta:                  # the keys of the reference's observation['layers'] (remove_unused_tile_types_from_layers)
+    assert "".join(spec.layer_chars) == meta["layer_keys"], (spec.layer_chars, meta["layer_keys"])
   assert spec.dim_names == meta["dim_names"] and spec.metric_names == meta["metric_labels"]
   got = run(spec, fx["actions"], fx["rng_seeded"])
   check(name, got, fx, spec.K)

@@ -89,7 +89,12 @@ def test_savanna_hip_matches_reference_fixture(name):
   # unoccluded layers from the state: the reference's drape curtains (W P D F d f G S), the agents, walls, and the gap layer
   # "only where every other layer is blank"
   chars = spec.layer_chars
+  if "layer_keys" in meta:                  # the keys of the reference's observation['layers'] (remove_unused_tile_types_from_layers)
+    assert "".join(chars) == meta["layer_keys"], (chars, meta["layer_keys"])
   for li, ch in enumerate("WPDFdfGS"):
+    if ch not in chars:                     # a drape the game was built without: the reference has no such layer (and no tile)
+      assert not fx["layers"][:, 1:, li].any()
+      continue
     G.assert_same(name + ".layer " + ch, got["layers"][:, 1:, chars.index(ch)], fx["layers"][:, 1:, li])
   occupied = fx["layers"][:, 1:, :8].any(axis=2) | (fx["board"][:, 1:] == ord('#'))
   for i in range(spec.n_agents):
