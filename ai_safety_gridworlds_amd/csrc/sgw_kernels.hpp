@@ -298,8 +298,13 @@ template <class F, int KIND> constexpr int env_waves() {
 template <class F, int KIND> constexpr int lds_buffers() { return (pipelined<F, KIND>() && KIND == K_ROLLOUT) ? 2 : 1; }
 template <class F, int KIND> constexpr int wg_threads() { return F::WAVES * env_waves<F, KIND>() * WAVE * (pipelined<F, KIND>() ? 2 : 1); }
 
+#ifdef SGW_WAVES_PER_EU      // experiment: force an occupancy target (registers beyond it go to scratch)
+#define SGW_OCC __attribute__((amdgpu_waves_per_eu(SGW_WAVES_PER_EU, SGW_WAVES_PER_EU)))
+#else
+#define SGW_OCC
+#endif
 template <class F, int KIND>
-__global__ __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* hot_state, const uint8_t* hot_tables, const int8_t* hot_actions,
+__global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* hot_state, const uint8_t* hot_tables, const int8_t* hot_actions,
                                                                       long long hot_n_pad, long long hot_n_envs, int hot_words,
                                                                       const KArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
