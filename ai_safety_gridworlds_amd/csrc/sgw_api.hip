@@ -289,9 +289,9 @@ int sgw_set_family_table(sgw_engine* e, const double* table_host, int64_t n) {
 }
 
 #ifdef SGW_SAV_PROF     // diagnostic build only
-extern "C" int sgw_debug_sav_prof(unsigned long long* out, int clear) {      // out[4096 * 8]
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sav_prof), 4096 * 8 * 8) != hipSuccess) return -1;
-  if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sav_prof)) != hipSuccess || hipMemset(p, 0, 4096 * 8 * 8) != hipSuccess) return -1; }
+extern "C" int sgw_debug_sav_prof(unsigned long long* out, int clear) {      // out[4096 * 16]
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sav_prof), 4096 * 16 * 8) != hipSuccess) return -1;
+  if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sav_prof)) != hipSuccess || hipMemset(p, 0, 4096 * 16 * 8) != hipSuccess) return -1; }
   return 0;
 }
 #endif

@@ -49,28 +49,47 @@ __device__ inline void b3_clr(B3& m, int i) {
   m.a &= ~(wi == 0 ? bit : 0ull); m.b &= ~(wi == 1 ? bit : 0ull); m.c &= ~(wi == 2 ? bit : 0ull);
 }
 __device__ inline int b3_count(const B3& m) { return __popcll(m.a) + __popcll(m.b) + __popcll(m.c); }
-__device__ inline int kth64(uint64_t w, int k) {          // position of the k-th (0-based) set bit, k < popcount(w)
+__device__ inline void b3_toggle(B3& m, int i) {
+  const uint64_t bit = 1ull << (i & 63); const int wi = i >> 6;
+  m.a ^= wi == 0 ? bit : 0ull; m.b ^= wi == 1 ? bit : 0ull; m.c ^= wi == 2 ? bit : 0ull;
+}
+__device__ inline bool b3_any(const B3& m) { return (m.a | m.b | m.c) != 0ull; }
+// index of the lowest set bit (m not empty), which is taken out of m.  Loops over the set bits of a bitmap go through
+// this one body: their trip count is the largest population in the wave, not the sum over the three words.
+__device__ inline int b3_pop_lowest(B3& m) {
+  const bool ua = m.a != 0ull, ub = !ua && m.b != 0ull;
+  const uint64_t w = ua ? m.a : (ub ? m.b : m.c);
+  const int i = (ua ? 0 : (ub ? 64 : 128)) + __builtin_ctzll(w);
+  const uint64_t nw = w & (w - 1ull);
+  m.a = ua ? nw : m.a; m.b = ub ? nw : m.b; m.c = (ua || ub) ? m.c : nw;
+  return i;
+}
+__device__ inline int kth32(uint32_t w, int k) {          // position of the k-th (0-based) set bit, k < popcount(w)
   int base = 0;
 #pragma unroll
-  for (int sh = 32; sh >= 1; sh >>= 1) {
-    const int c = __popcll((w >> base) & ((1ull << sh) - 1ull));
+  for (int sh = 16; sh >= 1; sh >>= 1) {
+    const int c = __popc((w >> base) & ((1u << sh) - 1u));
     const bool up = k >= c;
     k -= up ? c : 0; base += up ? sh : 0;
   }
   return base;
 }
-__device__ inline int b3_kth(const B3& m, int k) {
+__device__ inline int b3_kth(const B3& m, int k) {        // branch-free: one word, then one half of it, is searched
   const int ca = __popcll(m.a), cb = __popcll(m.b);
-  if (k < ca) return kth64(m.a, k);
-  if (k < ca + cb) return 64 + kth64(m.b, k - ca);
-  return 128 + kth64(m.c, k - ca - cb);
+  const bool in_a = k < ca, in_b = !in_a && k < ca + cb;
+  const uint64_t w = in_a ? m.a : (in_b ? m.b : m.c);
+  k -= in_a ? 0 : (in_b ? ca : ca + cb);
+  const uint32_t lo = (uint32_t)w;
+  const int cl = __popc(lo);
+  const bool upper = k >= cl;
+  return (in_a ? 0 : (in_b ? 64 : 128)) + (upper ? 32 : 0) + kth32(upper ? (uint32_t)(w >> 32) : lo, k - (upper ? cl : 0));
 }
 
 #ifdef SGW_SAV_PROF      // diagnostic build only (tools/diag/sav_prof.py): wave cycles per phase of a round, per wave
-__device__ unsigned long long g_sav_prof[4096 * 8];
+__device__ unsigned long long g_sav_prof[4096 * 16];
 __device__ unsigned long long g_sav_last[4096];
 #define SAV_T(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); const int w_ = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 4095; \
-                      if ((threadIdx.x & 63) == 0) { g_sav_prof[w_ * 8 + (k)] += n_ - g_sav_last[w_]; g_sav_last[w_] = n_; } } while (0)
+                      if ((threadIdx.x & 63) == 0) { g_sav_prof[w_ * 16 + (k)] += n_ - g_sav_last[w_]; g_sav_last[w_] = n_; } } while (0)
 #else
 #define SAV_T(k) do { } while (0)
 #endif
@@ -297,44 +316,35 @@ struct Savanna {
       }
       avail_int = (long long)ceil(av);
     }
+    SAV_T(8);
     if (sp.flags & (is_drink ? F_DRINK_METRIC_ONLY : F_FOOD_METRIC_ONLY)) return;
+    // SV:1262-1323 / 1412-1473: tiles are taken away while more are visible than available (first among the cells no agent
+    // stands on, then among all), or put on free cells while fewer are.  Either way a Generator.choice over the ranks of
+    // an `allowed` bitmap whose picks flip their cell: ONE sampling body serves both, so a wave whose lanes want different
+    // things runs it once.
     int visible = b3_count(cur);
-    if (avail_int < visible) {
-      for (int loop = 0; loop < 2; ++loop) {
-        B3 allowed = cur;
-        if (loop == 0) { b3_clr(allowed, p0); if (two) b3_clr(allowed, p1); }
-        const int len = b3_count(allowed);
-        const int want = (int)(visible - avail_int);
-        const int cnt = want < len ? want : len;
-        if (cnt == 0) {
-          cur = B3{0ull, 0ull, 0ull};                                  // `curtain[()] = False`
-        } else {
-          const B3 ch = choose(s.g, len, cnt);
-#pragma unroll
-          for (int wi = 0; wi < 3; ++wi) {
-            uint64_t z = b3_word(ch, wi);
-            while (z) { const int rank = wi * 64 + __builtin_ctzll(z); z &= z - 1; b3_clr(cur, b3_kth(allowed, rank)); }
-          }
-        }
-        if (visible - cnt > avail_int) visible -= cnt; else break;
+    int mode = avail_int < visible ? 1 : (avail_int > visible ? 2 : 0);           // 1 take away, 2 put
+    for (int pass = 0; pass < 2 && mode != 0; ++pass) {
+      B3 allowed;
+      if (mode == 1) {
+        allowed = cur;
+      } else {
+        const B3 vm = valid_mask(sp.HW);
+        allowed = B3{~cur.a & ~s.wall.a & vm.a, ~cur.b & ~s.wall.b & vm.b, ~cur.c & ~s.wall.c & vm.c};
       }
-    }
-    if (avail_int > visible) {
-      const B3 vm = valid_mask(sp.HW);
-      B3 allowed{~cur.a & ~s.wall.a & vm.a, ~cur.b & ~s.wall.b & vm.b, ~cur.c & ~s.wall.c & vm.c};
-      b3_clr(allowed, p0); if (two) b3_clr(allowed, p1);
+      if (mode == 2 || pass == 0) { b3_clr(allowed, p0); if (two) b3_clr(allowed, p1); }
       const int len = b3_count(allowed);
-      if (len > 0) {
-        int cnt = (int)(avail_int - visible);
-        cnt = cnt < len ? cnt : len;                 // the reference raises ValueError beyond len (specs.py rejects such configs)
-        const B3 ch = choose(s.g, len, cnt);
-#pragma unroll
-        for (int wi = 0; wi < 3; ++wi) {
-          uint64_t z = b3_word(ch, wi);
-          while (z) { const int rank = wi * 64 + __builtin_ctzll(z); z &= z - 1; b3_set(cur, b3_kth(allowed, rank)); }
-        }
+      const long long want = mode == 1 ? visible - avail_int : avail_int - visible;
+      const int cnt = (int)(want < len ? want : len);     // putting: the reference raises ValueError beyond len (specs.py rejects such configs)
+      if (cnt == 0) {
+        if (mode == 1) cur = B3{0ull, 0ull, 0ull};                                // `curtain[()] = False`
+      } else {
+        B3 ch = choose(s.g, len, cnt);
+        while (b3_any(ch)) b3_toggle(cur, b3_kth(allowed, b3_pop_lowest(ch)));
       }
+      if (mode == 1 && visible - cnt > avail_int) visible -= cnt; else mode = 0;
     }
+    SAV_T(9);
   }
 
   // make_safety_game's map generation into the lane's private LDS row (the board staging row, free outside emit), then
@@ -445,17 +455,17 @@ struct Savanna {
     return action == 3 ? cur : (action == 4 ? back : (action == 1 ? left : (action == 2 ? right : cur)));
   }
 
-  static __device__ __forceinline__ int min_distance(const B3& m, int row, int col, int W) {
+  // cell / W for cell < 192 by a multiplication: inv = 65536 / W + 1 (exact for every W: tests/test_host_families.py::test_reciprocal_row)
+  static __device__ __forceinline__ uint32_t inv_width(int W) { return 65536u / (uint32_t)W + 1u; }
+  static __device__ __forceinline__ int row_of(int cell, uint32_t inv) { return (int)(((uint32_t)cell * inv) >> 16); }
+  static __device__ __forceinline__ int min_distance(const B3& m, int row, int col, int W, uint32_t inv) {
     int best = 99;
-#pragma unroll
-    for (int wi = 0; wi < 3; ++wi) {
-      uint64_t z = b3_word(m, wi);
-      while (z) {
-        const int cell = wi * 64 + __builtin_ctzll(z); z &= z - 1;
-        const int r = cell / W, c = cell - r * W;
-        const int d = abs(row - r) + abs(col - c);
-        best = d < best ? d : best;
-      }
+    B3 z = m;
+    while (b3_any(z)) {
+      const int cell = b3_pop_lowest(z);
+      const int r = row_of(cell, inv), c = cell - r * W;
+      const int d = abs(row - r) + abs(col - c);
+      best = d < best ? d : best;
     }
     return best;
   }
@@ -480,6 +490,13 @@ struct Savanna {
     const bool adir_rel = (sp.flags & F_ADIR) != 0, odir_rel = (sp.flags & F_ODIR) != 0;
     const bool a1 = (ag == 1);
     SAV_T(0);                                                   // everything outside play_one (prologue, outputs, state store)
+    const uint32_t inv = inv_width(W);
+    // gold / silver visit rewards: fetched now, used (if the agent ends on such a tile) after the move: the wave does not
+    // sit out a global load in the middle of the play
+    const int TL = sp.max_iterations + 2;
+    const uint32_t gv = a1 ? s.vis[V_GOLD][1] : s.vis[V_GOLD][0], sv = a1 ? s.vis[V_SILVER][1] : s.vis[V_SILVER][0];
+    const double gold_reward = a.ftable[gv < (uint32_t)TL ? gv : (uint32_t)TL - 1u];
+    const double silver_reward = a.ftable[TL + (sv < (uint32_t)TL ? sv : (uint32_t)TL - 1u)];
     s.frame += 1;
     // ---- AgentSprite.update
     const int cur_od = a1 ? s.odir[1] : s.odir[0], cur_ad = a1 ? s.adir[1] : s.adir[0];
@@ -516,9 +533,9 @@ struct Savanna {
     double other_coop = 0.0;
     ra[MOVEMENT] += (action != 0) ? p[P_MOVEMENT] : 0.0;
     // SV:824-846: things.get(...) of a drape that was not built finds nothing and the value stays (3 from make_game)
-    const int saf = (sp.flags & F_REMOVED_W) ? (a1 ? s.saf[1] : s.saf[0]) : min_distance(s.water, fr, fc, W);
+    const int saf = (sp.flags & F_REMOVED_W) ? (a1 ? s.saf[1] : s.saf[0]) : min_distance(s.water, fr, fc, W, inv);
     s.saf[0] = a1 ? s.saf[0] : saf; s.saf[1] = a1 ? saf : s.saf[1];
-    const int saf2 = (sp.flags & F_REMOVED_P) ? (a1 ? s.saf2[1] : s.saf2[0]) : min_distance(s.dyn[L_P], fr, fc, W);
+    const int saf2 = (sp.flags & F_REMOVED_P) ? (a1 ? s.saf2[1] : s.saf2[0]) : min_distance(s.dyn[L_P], fr, fc, W, inv);
     s.saf2[0] = a1 ? s.saf2[0] : saf2; s.saf2[1] = a1 ? saf2 : s.saf2[1];
     double ds = a1 ? s.drink_sat[1] : s.drink_sat[0], fs = a1 ? s.food_sat[1] : s.food_sat[0];
     const bool drink_on = (p[P_MAX0 + 1] > 0.0) | (p[P_MAX0 + 3] > 0.0), food_on = (p[P_MAX0 + 0] > 0.0) | (p[P_MAX0 + 2] > 0.0);
@@ -532,10 +549,8 @@ struct Savanna {
     consume(s.avail[3], fs, ra[FOOD], other_coop, on_f, two, oversat, p[P_SFOOD], p[P_SF_EXTRACT], p[P_F_OVERLIMIT], p[P_SCOOP]);
     ra[FOOD] += (on_F | on_f) ? 0.0 : p[P_NON_FOOD];
     const bool on_G = b3_get(s.gold, pos), on_S = b3_get(s.silver, pos);
-    const int TL = sp.max_iterations + 2;
-    const uint32_t gv = a1 ? s.vis[V_GOLD][1] : s.vis[V_GOLD][0], sv = a1 ? s.vis[V_SILVER][1] : s.vis[V_SILVER][0];
-    if (on_G) ra[GOLD] += a.ftable[gv < (uint32_t)TL ? gv : (uint32_t)TL - 1u];
-    if (on_S) ra[SILVER] += a.ftable[TL + (sv < (uint32_t)TL ? sv : (uint32_t)TL - 1u)];
+    ra[GOLD] += on_G ? gold_reward : 0.0;
+    ra[SILVER] += on_S ? silver_reward : 0.0;
     const bool on_gap = !(b3_get(s.water, pos) | b3_get(s.dyn[L_P], pos) | on_D | b3_get(s.dyn[L_SD], pos) | on_F |
                           b3_get(s.dyn[L_SF], pos) | on_G | on_S);
     ra[FOOD] += on_gap ? p[P_GAP_FOOD] : 0.0; ra[DRINK] += on_gap ? p[P_GAP_DRINK] : 0.0;
@@ -560,28 +575,24 @@ struct Savanna {
     // ---- WaterDrape SV:1065-1079, PredatorDrape SV:1098-1193 (rewards only reach the acting agent)
     double injury = b3_get(s.water, pos) ? p[P_DANGER] : 0.0;
     {
-      const B3 snap = s.dyn[L_P];
+      B3 snap = s.dyn[L_P];
       const int p0 = s.row[0] * W + s.col[0], p1 = s.row[1] * W + s.col[1];
-#pragma unroll
-      for (int wi = 0; wi < 3; ++wi) {
-        uint64_t z = b3_word(snap, wi);
-        while (z) {
-          const int cell = wi * 64 + __builtin_ctzll(z); z &= z - 1;
-          if (cell == p0 || (two && cell == p1)) { injury += (cell == pos) ? p[P_PREDATOR] : 0.0; continue; }
-          if (!last_of_round) continue;
-          const double u = (double)(next64(s.g) >> 11) * (1.0 / 9007199254740992.0);
-          if (u >= p[P_PRED_PROB]) continue;
-          const int ch = lemire(s.g, 3u);                                 // UP DOWN LEFT RIGHT
-          int rr = cell / W, qq = cell - rr * W;
-          if (ch == 0) rr = rr - 1 < 0 ? 0 : rr - 1;
-          else if (ch == 1) rr = rr + 1 > sp.H - 1 ? sp.H - 1 : rr + 1;
-          else if (ch == 2) qq = qq - 1 < 0 ? 0 : qq - 1;
-          else qq = qq + 1 > W - 1 ? W - 1 : qq + 1;
-          const int to = rr * W + qq;
-          if (b3_get(s.dyn[L_P], to) || b3_get(s.wall, to)) continue;
-          b3_clr(s.dyn[L_P], cell); b3_set(s.dyn[L_P], to);
-          injury += (to == pos) ? p[P_PREDATOR] : 0.0;
-        }
+      while (b3_any(snap)) {
+        const int cell = b3_pop_lowest(snap);
+        if (cell == p0 || (two && cell == p1)) { injury += (cell == pos) ? p[P_PREDATOR] : 0.0; continue; }
+        if (!last_of_round) continue;
+        const double u = (double)(next64(s.g) >> 11) * (1.0 / 9007199254740992.0);
+        if (u >= p[P_PRED_PROB]) continue;
+        const int ch = lemire(s.g, 3u);                                 // UP DOWN LEFT RIGHT
+        int rr = row_of(cell, inv), qq = cell - rr * W;
+        if (ch == 0) rr = rr - 1 < 0 ? 0 : rr - 1;
+        else if (ch == 1) rr = rr + 1 > sp.H - 1 ? sp.H - 1 : rr + 1;
+        else if (ch == 2) qq = qq - 1 < 0 ? 0 : qq - 1;
+        else qq = qq + 1 > W - 1 ? W - 1 : qq + 1;
+        const int to = rr * W + qq;
+        if (b3_get(s.dyn[L_P], to) || b3_get(s.wall, to)) continue;
+        b3_clr(s.dyn[L_P], cell); b3_set(s.dyn[L_P], to);
+        injury += (to == pos) ? p[P_PREDATOR] : 0.0;
       }
     }
     ra[INJURY] += injury;

@@ -124,3 +124,10 @@ def test_externally_randomised_scalar_family_source_on_the_host_matches_referenc
   G.assert_same(name + ".board", got["board"].reshape(fx["board"].shape), fx["board"])
   G.assert_same(name + ".reward", got["reward"], fx["reward"].reshape(got["reward"].shape))
 
+
+
+def test_reciprocal_row():
+  """csrc/sgw_savanna.hpp row_of(): cell / W as (cell * (65536 / W + 1)) >> 16 is exact for every board the family can hold."""
+  for W in range(1, 192):
+    inv = 65536 // W + 1
+    assert all(((cell * inv) & 0xffffffff) >> 16 == cell // W for cell in range(192)), W

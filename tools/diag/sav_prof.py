@@ -8,14 +8,15 @@ from ai_safety_gridworlds_amd import _native as N
 from ai_safety_gridworlds_amd.specs import make_spec
 
 NAMES = ["outside play_one (prologue, shuffle, outputs, state store)", "agent move + update_reward", "water + predators", "reward bookkeeping",
-         "resource drape D", "resource drape F", "resource drape d", "resource drape f"]
+         "drape D tail", "drape F tail", "drape d tail", "drape f tail",
+         "drapes: availability (regrowth pow)", "drapes: removal sampling", "drapes: spawn sampling"]
 n, K = 65536, 200
 wl = B.WORKLOADS["aintelope_savanna"]
 spec = make_spec("aintelope_savanna", **wl["kwargs"])
 eng = B.prepare_engine("aintelope_savanna", spec, n, 0, torch.device("cuda:0"), wl["outputs"])
 acts = eng.fill_actions(K, 1)
 lib = N.lib()
-buf = (C.c_ulonglong * (4096 * 8))()
+buf = (C.c_ulonglong * (4096 * 16))()
 eng.step_n(acts); torch.cuda.synchronize()
 lib.sgw_debug_sav_prof(buf, 1)
 t0 = time.perf_counter()
@@ -23,9 +24,9 @@ eng.step_n(acts); torch.cuda.synchronize()
 print("%.2f us per round (profiled build)" % ((time.perf_counter() - t0) / K * 1e6))
 assert lib.sgw_debug_sav_prof(buf, 1) == 0
 waves = n // 64
-arr = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8)[:waves].astype(np.float64)
+arr = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 16)[:waves].astype(np.float64)
 arr[:, 0] = 0.0                      # slot 0 spans launches (the last-stamp array is not reset per launch): not meaningful
 tot = arr.sum()
 print("cycles per wave per round inside the plays: %.0f" % (tot / waves / K))
-for k in range(1, 8):
+for k in range(1, 11):
   print("  %-60s %8.0f  %5.1f %%" % (NAMES[k], arr[:, k].sum() / waves / K, 100.0 * arr[:, k].sum() / tot))
