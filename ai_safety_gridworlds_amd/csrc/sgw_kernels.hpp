@@ -34,6 +34,9 @@ template <class F, class = void> struct has_init_args : std::false_type {};
 template <class F> struct has_init_args<F, std::void_t<decltype(&F::init_args)>> : std::true_type {};
 template <class F, class = void> struct has_board_prepare : std::false_type {};
 template <class F> struct has_board_prepare<F, std::void_t<typename F::BoardPrep>> : std::true_type {};
+// families that write their row of the rendered board into the wave's LDS image themselves
+template <class F, class = void> struct has_board_stage : std::false_type {};
+template <class F> struct has_board_stage<F, std::void_t<decltype(&F::stage_board)>> : std::true_type {};
 
 // ---- a step's outputs: stage (the computing wave, from registers into its LDS buffer) and drain (LDS -> global) ----------
 template <class F> constexpr int per_agent_cols(const KSpec& sp) { return F::PER_AGENT ? sp.A : 1; }
@@ -48,7 +51,9 @@ __device__ inline void emit_stage(const typename F::State& s, const double (&r)[
   const int nd = a.need;
   const int HW = sp.HW, K = sp.A * sp.K, M = sp.M;   // reward rows hold all agents' vectors: [A][K]
   if (nd & (LN_BOARD | LN_OBS)) {
-    if constexpr (has_board_prepare<F>::value) {        // per-step precomputation shared by every dword of the row
+    if constexpr (has_board_stage<F>::value) {
+      F::stage_board(l.board, s, sp, lane);
+    } else if constexpr (has_board_prepare<F>::value) { // per-step precomputation shared by every dword of the row
       const auto bp = F::board_prepare(s, sp);
       lds_write_board_row_fn(l.board, HW, lane, [&](int i) { return F::board_dword(bp, s, sp, i); });
     } else if constexpr (F::CUSTOM_BOARD) {

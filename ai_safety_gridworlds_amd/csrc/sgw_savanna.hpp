@@ -32,6 +32,8 @@
 // safety output: [N_pad, 2] min distance to water; agent_flags bits 1-2 action direction, 3-4 observation direction
 #pragma once
 
+#include <utility>
+
 #include "sgw_common.hpp"
 #include "sgw_pow.hpp"
 
@@ -49,6 +51,16 @@ __device__ inline void b3_clr(B3& m, int i) {
   m.a &= ~(wi == 0 ? bit : 0ull); m.b &= ~(wi == 1 ? bit : 0ull); m.c &= ~(wi == 2 ? bit : 0ull);
 }
 __device__ inline int b3_count(const B3& m) { return __popcll(m.a) + __popcll(m.b) + __popcll(m.c); }
+// the value as the optimiser cannot see through: a chain of selects over members of the state would otherwise be folded into
+// ONE load through a selected address, and a state whose address is computed at run time lives in scratch memory
+__device__ inline uint64_t opaque64(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+__device__ inline B3 b3_opaque(const B3& m) { return B3{opaque64(m.a), opaque64(m.b), opaque64(m.c)}; }
+__device__ inline B3 b3_select(bool c, const B3& x, const B3& y) { return B3{c ? x.a : y.a, c ? x.b : y.b, c ? x.c : y.c}; }
 __device__ inline void b3_toggle(B3& m, int i) {
   const uint64_t bit = 1ull << (i & 63); const int wi = i >> 6;
   m.a ^= wi == 0 ? bit : 0ull; m.b ^= wi == 1 ? bit : 0ull; m.c ^= wi == 2 ? bit : 0ull;
@@ -90,8 +102,11 @@ __device__ unsigned long long g_sav_prof[4096 * 16];
 __device__ unsigned long long g_sav_last[4096];
 #define SAV_T(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); const int w_ = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 4095; \
                       if ((threadIdx.x & 63) == 0) { g_sav_prof[w_ * 16 + (k)] += n_ - g_sav_last[w_]; g_sav_last[w_] = n_; } } while (0)
+#define SAV_RESET() do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); const int w_ = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 4095; \
+                         if ((threadIdx.x & 63) == 0) g_sav_last[w_] = n_; } while (0)
 #else
 #define SAV_T(k) do { } while (0)
+#define SAV_RESET() do { } while (0)
 #endif
 
 struct Savanna {
@@ -157,6 +172,7 @@ struct Savanna {
   static __device__ __forceinline__ int slot(const KSpec& sp, int u) { return sp.dim_slot[u / NUA][u % NUA]; }
 
   static __device__ __forceinline__ void load(State& s, const KArgs& a, long long env) {
+    SAV_RESET();
     Cursor c(a, env);
     const uint64_t w0 = c.get(), w1 = c.get(), w2 = c.get();
     s.frame = (int)(w0 & 0xffff);
@@ -192,6 +208,7 @@ struct Savanna {
   }
 
   static __device__ __forceinline__ void store(const State& s, const KArgs& a, long long env) {
+    SAV_T(5);                                                   // outputs staged and copied out
     const uint64_t w0 = (uint64_t)(s.frame & 0xffff) | ((uint64_t)(s.ast & 7) << 16) | ((uint64_t)(s.acted[0] & 1) << 26) |
                         ((uint64_t)(s.g.has32 & 1) << 27) | ((uint64_t)(s.adir[0] & 3) << 28) | ((uint64_t)(s.adir[1] & 3) << 30) |
                         ((uint64_t)(s.step_type & 0xf) << 32) | ((uint64_t)(s.term & 0xf) << 36) | ((uint64_t)(s.odir[0] & 3) << 40) |
@@ -221,6 +238,7 @@ struct Savanna {
     for (int d = 0; d < 5; ++d) { c.put(s.dyn[d].a); c.put(s.dyn[d].b); c.put(s.dyn[d].c); }
 #pragma unroll
     for (int u = 0; u < NU; ++u) if (slot(a.sp, u) >= 0) c.putf(s.cum[u]);
+    SAV_T(6);                                                   // state stores issued
   }
 
   // ---- numpy PCG64 ------------------------------------------------------------------------------------------------
@@ -291,14 +309,16 @@ struct Savanna {
   // nobody in the submitted dict on a finished episode: no play, no reset; LAST becomes DEAD (PM:223-233)
   static __device__ __forceinline__ double idle_round(State& s) { s.ast = AST_DEAD; return 1.0; }
 
-  // Drink/FoodDrapeBase.update for resource R (0 D, 1 F, 2 d, 3 f); `showtime`: iteration_index == 0
+  // Drink/FoodDrapeBase.update, first half, for resource R (0 D, 1 F, 2 d, 3 f); `showtime`: iteration_index == 0.
+  // Regrowth of the availability; returns ceil(availability) as the number of tiles that should be visible, or -1 when
+  // this drape places no tiles (not in this game / metric only).  Touches nothing but s.avail[R]: the four drapes'
+  // first halves can all run before any of them samples.
   template <int R>
-  static __device__ __forceinline__ void resource_update(State& s, const KSpec& sp, const Lds& l, bool showtime) {
+  static __device__ __forceinline__ int resource_target(State& s, const KSpec& sp, const Lds& l, bool showtime, int p0, int p1) {
     constexpr bool is_drink = (R == 0 || R == 2);
     const bool two = (sp.flags & F_TWO) != 0;
-    if (sp.flags & (1 << (F_REMOVED_SHIFT + 2 + R))) return;      // no such drape in this game: nothing spawns, no metric
-    const int p0 = s.row[0] * sp.W + s.col[0], p1 = s.row[1] * sp.W + s.col[1];
-    B3& cur = s.dyn[L_D + R];
+    if (sp.flags & (1 << (F_REMOVED_SHIFT + 2 + R))) return -1;   // no such drape in this game: nothing spawns, no metric
+    const B3& cur = s.dyn[L_D + R];
     long long avail_int;
     constexpr int TYPE = (R == 0) ? 1 : (R == 1) ? 0 : (R == 2) ? 3 : 2;     // index into the F D f d ... tables
     if (!(sp.flags & F_SUSTAIN)) {
@@ -316,33 +336,54 @@ struct Savanna {
       }
       avail_int = (long long)ceil(av);
     }
+    if (sp.flags & (is_drink ? F_DRINK_METRIC_ONLY : F_FOOD_METRIC_ONLY)) return -1;
+    // only its order against the tile count (<= 192 cells) and differences up to that count are used
+    return (int)(avail_int < 0 ? 0 : (avail_int > 1024 ? 1024 : avail_int));
+  }
+
+  // The four resource drapes' updates of one play, in the reference's order D F d f (SV:1262-1323 / 1412-1473): tiles are
+  // taken away while more are visible than available (first among the cells no agent stands on, then among all), or put on
+  // free cells while fewer are.  Either way it is a Generator.choice over the ranks of an `allowed` bitmap whose picks flip
+  // their cell, so ONE sampling body serves every drape and both directions: each lane walks through its own pending
+  // drapes in order (its generator sees the same draws in the same order), and the wave runs the body as often as its
+  // busiest lane has work -- mostly once or twice -- instead of once per drape and direction.
+  static __device__ __forceinline__ void resources_update(State& s, const KSpec& sp, const Lds& l, bool showtime) {
+    const bool two = (sp.flags & F_TWO) != 0;
+    const int p0 = s.row[0] * sp.W + s.col[0], p1 = s.row[1] * sp.W + s.col[1];
+    const int t0 = resource_target<0>(s, sp, l, showtime, p0, p1), t1 = resource_target<1>(s, sp, l, showtime, p0, p1);
+    const int t2 = resource_target<2>(s, sp, l, showtime, p0, p1), t3 = resource_target<3>(s, sp, l, showtime, p0, p1);
     SAV_T(8);
-    if (sp.flags & (is_drink ? F_DRINK_METRIC_ONLY : F_FOOD_METRIC_ONLY)) return;
-    // SV:1262-1323 / 1412-1473: tiles are taken away while more are visible than available (first among the cells no agent
-    // stands on, then among all), or put on free cells while fewer are.  Either way a Generator.choice over the ranks of
-    // an `allowed` bitmap whose picks flip their cell: ONE sampling body serves both, so a wave whose lanes want different
-    // things runs it once.
-    int visible = b3_count(cur);
-    int mode = avail_int < visible ? 1 : (avail_int > visible ? 2 : 0);           // 1 take away, 2 put
-    for (int pass = 0; pass < 2 && mode != 0; ++pass) {
-      B3 allowed;
-      if (mode == 1) {
-        allowed = cur;
-      } else {
+    // bit R: drape R has tiles to take away or to put
+    int pending = ((t0 >= 0 && t0 != b3_count(s.dyn[L_D + 0])) ? 1 : 0) | ((t1 >= 0 && t1 != b3_count(s.dyn[L_D + 1])) ? 2 : 0) |
+                  ((t2 >= 0 && t2 != b3_count(s.dyn[L_D + 2])) ? 4 : 0) | ((t3 >= 0 && t3 != b3_count(s.dyn[L_D + 3])) ? 8 : 0);
+    int pass = 0, visible = 0;
+    while (pending != 0) {
+      const int R = __builtin_ctz((unsigned)pending);
+      const int target = R == 0 ? t0 : (R == 1 ? t1 : (R == 2 ? t2 : t3));
+      const B3 d0 = b3_opaque(s.dyn[L_D + 0]), d1 = b3_opaque(s.dyn[L_D + 1]), d2 = b3_opaque(s.dyn[L_D + 2]), d3 = b3_opaque(s.dyn[L_D + 3]);
+      B3 cur = b3_select(R == 0, d0, b3_select(R == 1, d1, b3_select(R == 2, d2, d3)));
+      if (pass == 0) visible = b3_count(cur);
+      const bool take = target < visible;
+      B3 allowed = cur;
+      if (!take) {
         const B3 vm = valid_mask(sp.HW);
         allowed = B3{~cur.a & ~s.wall.a & vm.a, ~cur.b & ~s.wall.b & vm.b, ~cur.c & ~s.wall.c & vm.c};
       }
-      if (mode == 2 || pass == 0) { b3_clr(allowed, p0); if (two) b3_clr(allowed, p1); }
+      if (!take || pass == 0) { b3_clr(allowed, p0); if (two) b3_clr(allowed, p1); }
       const int len = b3_count(allowed);
-      const long long want = mode == 1 ? visible - avail_int : avail_int - visible;
-      const int cnt = (int)(want < len ? want : len);     // putting: the reference raises ValueError beyond len (specs.py rejects such configs)
+      const int want = take ? visible - target : target - visible;
+      const int cnt = want < len ? want : len;     // putting: the reference raises ValueError beyond len (specs.py rejects such configs)
       if (cnt == 0) {
-        if (mode == 1) cur = B3{0ull, 0ull, 0ull};                                // `curtain[()] = False`
+        if (take) cur = B3{0ull, 0ull, 0ull};                                     // `curtain[()] = False`
       } else {
         B3 ch = choose(s.g, len, cnt);
         while (b3_any(ch)) b3_toggle(cur, b3_kth(allowed, b3_pop_lowest(ch)));
       }
-      if (mode == 1 && visible - cnt > avail_int) visible -= cnt; else mode = 0;
+      s.dyn[L_D + 0] = b3_select(R == 0, cur, d0); s.dyn[L_D + 1] = b3_select(R == 1, cur, d1);
+      s.dyn[L_D + 2] = b3_select(R == 2, cur, d2); s.dyn[L_D + 3] = b3_select(R == 3, cur, d3);
+      // a second pass over the same drape (now with the agents' cells allowed) when tiles are still to be taken away
+      if (take && pass == 0 && visible - cnt > target) { visible -= cnt; pass = 1; }
+      else { pending &= pending - 1; pass = 0; }
     }
     SAV_T(9);
   }
@@ -443,8 +484,7 @@ struct Savanna {
 #pragma unroll
     for (int u = 0; u < NU; ++u) s.cum[u] = 0.0;
     // its_showtime's play(None): agents idle, predators stay (no round was stepped), the four resource drapes update
-    resource_update<0>(s, sp, l, true); resource_update<1>(s, sp, l, true);
-    resource_update<2>(s, sp, l, true); resource_update<3>(s, sp, l, true);
+    resources_update(s, sp, l, true);
   }
 
   // MA:566-606 (mode-1 tables), Directions L=0 R=1 U=2 D=3, Actions NOOP=0 L=1 R=2 U=3 D=4
@@ -603,14 +643,14 @@ struct Savanna {
     r[COOP] += a1 ? other_coop : 0.0; r[NUA + COOP] += a1 ? 0.0 : other_coop;
     // ---- resource drapes, update order D F d f
     SAV_T(3);                                                   // reward bookkeeping
-    resource_update<0>(s, sp, l, false); SAV_T(4); resource_update<1>(s, sp, l, false); SAV_T(5);
-    resource_update<2>(s, sp, l, false); SAV_T(6); resource_update<3>(s, sp, l, false); SAV_T(7);
+    resources_update(s, sp, l, false);
   }
 
   // one ROUND
   static __device__ __forceinline__ double play(State& s, const int (&actions)[2], const KArgs& a, const Lds& l, double (&r)[NU], long long env) {
     const KSpec& sp = a.sp;
     const bool two = (sp.flags & F_TWO) != 0;
+    SAV_T(4);                                                   // prologue: state load issued, tables staged, auto-reset
     // a round may carry a subset of the agents (PM:173-246 iterates over the submitted dict; action < 0 = not submitted)
     const bool sub0 = actions[0] >= 0, sub1 = two && actions[1] >= 0;
     int first = sub0 ? 0 : 1;
@@ -673,6 +713,59 @@ struct Savanna {
   }
   static __device__ __forceinline__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds&, int i) {
     return board_dword(board_prepare(s, sp), s, sp, i);
+  }
+  // The env's row of the rendered board, written into the wave's packed LDS image (row `lane` starts at byte lane * HW,
+  // which is a dword boundary for one lane in four when HW is odd).  Instead of shifting bytes into place dword by dword,
+  // the six bit planes are shifted by the row's misalignment (0-3 cells) once; dword i of the shifted planes is then
+  // aligned dword i of the image, every nibble sits at a compile-time position of a plane word, and a dword costs six
+  // bit-field extracts and six 24-bit multiplies.  Only the first and the last dword of a row can be shared with a
+  // neighbouring lane: those are zeroed by both owners and then OR-ed (the wave's LDS instructions execute in order); the
+  // agents are two byte stores on top.
+  template <int I>
+  static __device__ __forceinline__ void stage_board_dword(uint32_t* row, const uint64_t (&P)[6][4], int HW, int last,
+                                                           bool head_shared, bool tail_shared) {
+    if (I * 4 >= HW + 3) return;                                // uniform: no row reaches this dword
+    constexpr int wi = I >> 4, sh = (I & 15) * 4;
+    const uint32_t SPREAD = 0x00204081u, LANES = 0x01010101u;   // nibble bit k -> bit 8k
+    uint32_t v = 0u;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const uint32_t half = sh < 32 ? (uint32_t)P[k][wi] : (uint32_t)(P[k][wi] >> 32);
+      const uint32_t n = (half >> (sh & 31)) & 15u;
+      v |= (__umul24(n, SPREAD) & LANES) << (k < 3 ? k : k + 1);        // character bits 0 1 2 4 5 6
+    }
+    if (I > 0 && I < ((HW - 1) >> 2)) { row[I] = v; return; }   // uniform: a dword inside the row of every lane
+    if (I > last) return;
+    const bool shared = (I == 0 && head_shared) || (I == last && tail_shared);
+    if (shared) { if (v) atomicOr(&row[I], v); } else row[I] = v;
+  }
+  template <int... I>
+  static __device__ __forceinline__ void stage_board_dwords(uint32_t* row, const uint64_t (&P)[6][4], int HW, int last,
+                                                            bool head_shared, bool tail_shared, std::integer_sequence<int, I...>) {
+    (stage_board_dword<I>(row, P, HW, last, head_shared, tail_shared), ...);
+  }
+  static __device__ __forceinline__ void stage_board(uint32_t* img, const State& s, const KSpec& sp, int lane) {
+    const int HW = sp.HW;
+    const BoardPrep bp = board_prepare(s, sp);
+    const B3 vm = valid_mask(HW);
+    const int o = lane * HW, q = o & 3;
+    uint32_t* row = img + (o >> 2);
+    const int last = ((o + HW - 1) >> 2) - (o >> 2);            // index of the last dword this row touches
+    const bool head_shared = q != 0, tail_shared = ((o + HW) & 3) != 0;
+    uint64_t P[6][4];
+    auto shifted = [&](const uint64_t (&p)[3], uint64_t (&out)[4], bool clip) {
+      const uint64_t a = clip ? p[0] & vm.a : p[0], b = clip ? p[1] & vm.b : p[1], c = clip ? p[2] & vm.c : p[2];
+      out[0] = a << q; out[1] = (b << q) | ((a >> 1) >> (63 - q));
+      out[2] = (c << q) | ((b >> 1) >> (63 - q)); out[3] = (c >> 1) >> (63 - q);
+    };
+    shifted(bp.b0, P[0], false); shifted(bp.b1, P[1], false); shifted(bp.b2, P[2], false);
+    shifted(bp.b4, P[3], false); shifted(bp.b5, P[4], true); shifted(bp.b6, P[5], false);   // b5 carries the gaps: set past the board too
+    if (head_shared) row[0] = 0u;
+    if (tail_shared) row[last] = 0u;
+    stage_board_dwords(row, P, HW, last, head_shared, tail_shared, std::make_integer_sequence<int, 49>{});
+    uint8_t* rb = reinterpret_cast<uint8_t*>(img) + o;
+    rb[s.row[0] * sp.W + s.col[0]] = (uint8_t)'0';
+    if (sp.flags & F_TWO) rb[s.row[1] * sp.W + s.col[1]] = (uint8_t)'1';
   }
   static __device__ __forceinline__ const uint8_t* board_layers(const State&, const KSpec&, const Lds& l, int (&)[2], uint8_t (&)[2]) { return l.static_board; }
 

@@ -26,6 +26,7 @@ inline float4 make_float4(float a, float b, float c, float d) { return float4{a,
 inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline long long __double_as_longlong(double x) { long long u; std::memcpy(&u, &x, 8); return u; }
 inline double __longlong_as_double(long long u) { double x; std::memcpy(&x, &u, 8); return x; }
 inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p |= v; return o; }

@@ -41,6 +41,8 @@ template <class F, class = void> struct has_issue : std::false_type {};
 template <class F> struct has_issue<F, std::void_t<decltype(&F::init_issue)>> : std::true_type {};
 template <class F, class = void> struct has_prep : std::false_type {};
 template <class F> struct has_prep<F, std::void_t<typename F::BoardPrep>> : std::true_type {};
+template <class F, class = void> struct has_stage : std::false_type {};
+template <class F> struct has_stage<F, std::void_t<decltype(&F::stage_board)>> : std::true_type {};
 
 struct Host {
   sgw_spec spec; KArgs a; Lds l;
@@ -124,6 +126,21 @@ template <class F> static void emit(Host& h, const typename F::State& s, const d
     const uint8_t* base = F::board_layers(s, sp, h.l, cells, chars);
     std::memcpy(board.data(), base, sp.HW);
     for (int q = 0; q < F::NSPRITE; ++q) board[cells[q]] = chars[q];
+  }
+  if constexpr (has_stage<F>::value) {
+    // the family's own LDS row writer, at this env's lane of a packed 64-row image: the row equals the dword rendering,
+    // and nothing outside the row's first .. last dword is touched
+    const int lane = (int)(env & 63), HW = sp.HW, o = lane * HW;
+    std::vector<uint32_t> img((64 * HW + 3) / 4 + 4, 0xAAAAAAAAu);
+    F::stage_board(img.data(), s, sp, lane);
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(img.data());
+    for (int i = 0; i < HW; ++i)
+      if (b[o + i] != board[i]) { std::fprintf(stderr, "stage_board: cell %d of lane %d is %d, want %d\n", i, lane, b[o + i], board[i]); std::exit(3); }
+    const int first = o / 4 * 4, end = (o + HW + 3) / 4 * 4;
+    for (int i = 0; i < (int)img.size() * 4; ++i)
+      if ((i < first || i >= end) && b[i] != 0xAA) { std::fprintf(stderr, "stage_board: byte %d outside the row of lane %d written\n", i, lane); std::exit(3); }
+    for (int i = first; i < end; ++i)
+      if ((i < o || i >= o + HW) && b[i] != 0) { std::fprintf(stderr, "stage_board: a neighbour's byte %d in a shared dword is not zero\n", i); std::exit(3); }
   }
   fwrite(board.data(), 1, sp.HW, out);
   (void)env;
