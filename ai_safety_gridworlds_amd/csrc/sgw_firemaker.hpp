@@ -34,6 +34,8 @@
 // state words: 0 core | 1 positions | 2 rng buffer | 3-6 PCG64 state/inc | 7-11 fire | 12-15 visits | 16-24 cumulative
 #pragma once
 
+#include <utility>
+
 #include "sgw_common.hpp"
 
 namespace sgw {
@@ -698,6 +700,55 @@ struct Firemaker {
       }
     }
     return v;
+  }
+  // The env's row of the rendered board written into the wave's packed LDS image.  A row is 289 bytes: lane l's row starts
+  // q = l & 3 bytes into a dword.  The fire mask is shifted by q cells once, so that dword I of the row's 73 image dwords
+  // takes its four fire bits from a compile-time position; the static board comes through a byte funnel over two
+  // consecutive table dwords (each read once); fire cells become 'F' through a byte mask.  Dwords 0 and 72 can be
+  // shared with the neighbouring lanes' rows: zeroed by both owners, then OR-ed (the wave's LDS instructions execute in
+  // order); the three sprites are byte stores on top.
+  template <int I>
+  static __device__ __forceinline__ void stage_board_dword(uint32_t* row, const uint32_t* st, uint32_t& lo, const uint64_t (&P)[5], int q) {
+    constexpr int wi = I >> 4, sh = (I & 15) * 4;
+    const uint32_t hi = st[I + 1];
+    uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * ((4 - q) & 3)));
+    lo = hi;
+    const uint32_t half = sh < 32 ? (uint32_t)P[wi] : (uint32_t)(P[wi] >> 32);
+    const uint32_t t = __umul24((half >> (sh & 31)) & 15u, 0x00204081u) & 0x01010101u;      // fire bit k -> bit 8k
+    const uint32_t m = (t << 8) - t;                                                        // -> 0xff in byte k
+    v = (v & ~m) | (0x46464646u & m);                                                       // 'F'
+    if (I == 0) {
+      v &= 0xffffffffu << (8 * q);
+      if (q != 0) { if (v) atomicOr(&row[0], v); } else row[0] = v;
+    } else if (I == 72) {
+      v &= q == 3 ? 0xffffffffu : ((1u << (8 * (q + 1))) - 1u);
+      if (q != 3) { if (v) atomicOr(&row[72], v); } else row[72] = v;
+    } else {
+      row[I] = v;
+    }
+  }
+  template <int... I>
+  static __device__ __forceinline__ void stage_board_dwords(uint32_t* row, const uint32_t* st, uint32_t& lo, const uint64_t (&P)[5], int q,
+                                                            std::integer_sequence<int, I...>) {
+    (stage_board_dword<I>(row, st, lo, P, q), ...);
+  }
+  static __device__ __forceinline__ void stage_board(const Lds& l, const State& s, const KSpec& sp, int lane) {
+    static_assert(CELLS == 289, "73 image dwords per row");
+    const int o = lane * CELLS, q = o & 3;
+    uint32_t* row = l.board + (o >> 2);
+    const uint64_t P[5] = {s.fire.a << q, (s.fire.b << q) | ((s.fire.a >> 1) >> (63 - q)), (s.fire.c << q) | ((s.fire.b >> 1) >> (63 - q)),
+                           (s.fire.d << q) | ((s.fire.c >> 1) >> (63 - q)), (s.fire.e << q) | ((s.fire.d >> 1) >> (63 - q))};
+    // image dword I holds row bytes 4I - q .. 4I - q + 3: the funnel's low dword is table dword I - (q > 0)
+    const uint32_t* table = reinterpret_cast<const uint32_t*>(l.static_board);
+    const uint32_t* st = table - (q != 0 ? 1 : 0);
+    uint32_t lo = q != 0 ? 0u : table[0];
+    if (q != 0) row[0] = 0u;
+    if (q != 3) row[72] = 0u;
+    stage_board_dwords(row, st, lo, P, q, std::make_integer_sequence<int, 73>{});
+    uint8_t* rb = reinterpret_cast<uint8_t*>(l.board) + o;
+#pragma unroll
+    for (int ag = 0; ag < 3; ++ag)
+      if (present(sp, ag)) rb[s.row[ag] * W + s.col[ag]] = (uint8_t)(ag == 0 ? '1' : (ag == 1 ? '2' : 'S'));
   }
   static __device__ const uint8_t* board_layers(const State&, const KSpec&, const Lds& l, int (&)[3], uint8_t (&)[3]) {
     return l.static_board;

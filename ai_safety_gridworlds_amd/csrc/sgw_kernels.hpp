@@ -52,7 +52,7 @@ __device__ inline void emit_stage(const typename F::State& s, const double (&r)[
   const int HW = sp.HW, K = sp.A * sp.K, M = sp.M;   // reward rows hold all agents' vectors: [A][K]
   if (nd & (LN_BOARD | LN_OBS)) {
     if constexpr (has_board_stage<F>::value) {
-      F::stage_board(l.board, s, sp, lane);
+      F::stage_board(l, s, sp, lane);
     } else if constexpr (has_board_prepare<F>::value) { // per-step precomputation shared by every dword of the row
       const auto bp = F::board_prepare(s, sp);
       lds_write_board_row_fn(l.board, HW, lane, [&](int i) { return F::board_dword(bp, s, sp, i); });

@@ -744,7 +744,8 @@ struct Savanna {
                                                             bool head_shared, bool tail_shared, std::integer_sequence<int, I...>) {
     (stage_board_dword<I>(row, P, HW, last, head_shared, tail_shared), ...);
   }
-  static __device__ __forceinline__ void stage_board(uint32_t* img, const State& s, const KSpec& sp, int lane) {
+  static __device__ __forceinline__ void stage_board(const Lds& l, const State& s, const KSpec& sp, int lane) {
+    uint32_t* img = l.board;
     const int HW = sp.HW;
     const BoardPrep bp = board_prepare(s, sp);
     const B3 vm = valid_mask(HW);

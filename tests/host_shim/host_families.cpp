@@ -132,7 +132,8 @@ template <class F> static void emit(Host& h, const typename F::State& s, const d
     // and nothing outside the row's first .. last dword is touched
     const int lane = (int)(env & 63), HW = sp.HW, o = lane * HW;
     std::vector<uint32_t> img((64 * HW + 3) / 4 + 4, 0xAAAAAAAAu);
-    F::stage_board(img.data(), s, sp, lane);
+    Lds li = h.l; li.board = img.data();
+    F::stage_board(li, s, sp, lane);
     const uint8_t* b = reinterpret_cast<const uint8_t*>(img.data());
     for (int i = 0; i < HW; ++i)
       if (b[o + i] != board[i]) { std::fprintf(stderr, "stage_board: cell %d of lane %d is %d, want %d\n", i, lane, b[o + i], board[i]); std::exit(3); }

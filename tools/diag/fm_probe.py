@@ -8,8 +8,9 @@ from ai_safety_gridworlds_amd.specs import make_spec
 
 dev, n, K = "cuda:0", 16384, 400
 spec = make_spec("firemaker_ex_ma", amount_agents=3)
-for mode in ("noop", "random"):
-  eng = BatchedEngine(spec, n, device=dev, outputs=("board", "reward", "step_type", "term_reason", "agent_pos"))
+for mode in ("noop", "random", "random-noboard"):
+  eng = BatchedEngine(spec, n, device=dev, outputs=("board", "reward", "step_type", "term_reason", "agent_pos") if mode != "random-noboard"
+                      else ("reward", "step_type", "term_reason", "agent_pos"))
   eng.set_rng_seeds(np.arange(n))
   eng.reset()
   acts = eng.fill_actions(K, 1)
@@ -24,6 +25,10 @@ for mode in ("noop", "random"):
     out = eng.step_n(acts)
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / (3 * K)
+  if mode == "random-noboard":
+    print("%-7s %.2f us per round without the board output" % (mode, dt * 1e6), flush=True)
+    eng.close()
+    continue
   b = out["board"][:n]
   burning = (b == ord('F')).any(dim=1).float().mean().item() if True else 0
   fires = (b == ord('F')).sum(dim=1).float().mean().item()
