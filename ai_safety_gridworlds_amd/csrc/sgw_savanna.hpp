@@ -310,31 +310,29 @@ struct Savanna {
   static __device__ __forceinline__ double idle_round(State& s) { s.ast = AST_DEAD; return 1.0; }
 
   // Drink/FoodDrapeBase.update, first half, for resource R (0 D, 1 F, 2 d, 3 f); `showtime`: iteration_index == 0.
-  // Regrowth of the availability; returns ceil(availability) as the number of tiles that should be visible, or -1 when
-  // this drape places no tiles (not in this game / metric only).  Touches nothing but s.avail[R]: the four drapes'
-  // first halves can all run before any of them samples.
+  // Does the availability regrow in this update (SV:1243-1259 / 1393-1409)?
   template <int R>
-  static __device__ __forceinline__ int resource_target(State& s, const KSpec& sp, const Lds& l, bool showtime, int p0, int p1) {
+  static __device__ __forceinline__ bool resource_regrows(const State& s, const KSpec& sp, const Lds& l, bool showtime, int p0, int p1) {
     constexpr bool is_drink = (R == 0 || R == 2);
-    const bool two = (sp.flags & F_TWO) != 0;
-    if (sp.flags & (1 << (F_REMOVED_SHIFT + 2 + R))) return -1;   // no such drape in this game: nothing spawns, no metric
+    if ((sp.flags & (1 << (F_REMOVED_SHIFT + 2 + R))) || !(sp.flags & F_SUSTAIN) || showtime) return false;
     const B3& cur = s.dyn[L_D + R];
-    long long avail_int;
+    const bool under = b3_get(cur, p0) || ((sp.flags & F_TWO) && b3_get(cur, p1));
+    const double cmp_limit = is_drink ? 20.0 : l.params[P_F_GROWTH_LIMIT];     // SV:1251 module constant / SV:1401 flag
+    return !under && s.avail[R] >= 1.0 && s.avail[R] < cmp_limit;
+  }
+  // ceil(availability) as the number of tiles that should be visible, or -1 when this drape places no tiles (not in this
+  // game / metric only)
+  template <int R>
+  static __device__ __forceinline__ int resource_target(State& s, const KSpec& sp, const Lds& l) {
+    constexpr bool is_drink = (R == 0 || R == 2);
+    if (sp.flags & (1 << (F_REMOVED_SHIFT + 2 + R))) return -1;   // no such drape in this game: nothing spawns, no metric
     constexpr int TYPE = (R == 0) ? 1 : (R == 1) ? 0 : (R == 2) ? 3 : 2;     // index into the F D f d ... tables
+    long long avail_int;
     if (!(sp.flags & F_SUSTAIN)) {
       const double amt = l.params[P_MAX0 + TYPE];
       s.avail[R] = amt; avail_int = (long long)amt;
     } else {
-      double av = s.avail[R];
-      const bool under = b3_get(cur, p0) || (two && b3_get(cur, p1));
-      const double cmp_limit = is_drink ? 20.0 : l.params[P_F_GROWTH_LIMIT];   // SV:1251 module constant / SV:1401 flag
-      if (!showtime && !under && av >= 1.0 && av < cmp_limit) {
-        const double min_limit = is_drink ? l.params[P_D_GROWTH_LIMIT] : l.params[P_F_GROWTH_LIMIT];
-        av = fmin(min_limit, sgw_glibc_pow(av + 1.0, l.params[P_D_EXPONENT]));   // math.pow = libm pow; both raise to the DRINK exponent
-        av = fmin(av, l.params[P_USABLE_HALF]);
-        s.avail[R] = av;
-      }
-      avail_int = (long long)ceil(av);
+      avail_int = (long long)ceil(s.avail[R]);
     }
     if (sp.flags & (is_drink ? F_DRINK_METRIC_ONLY : F_FOOD_METRIC_ONLY)) return -1;
     // only its order against the tile count (<= 192 cells) and differences up to that count are used
@@ -350,8 +348,25 @@ struct Savanna {
   static __device__ __forceinline__ void resources_update(State& s, const KSpec& sp, const Lds& l, bool showtime) {
     const bool two = (sp.flags & F_TWO) != 0;
     const int p0 = s.row[0] * sp.W + s.col[0], p1 = s.row[1] * sp.W + s.col[1];
-    const int t0 = resource_target<0>(s, sp, l, showtime, p0, p1), t1 = resource_target<1>(s, sp, l, showtime, p0, p1);
-    const int t2 = resource_target<2>(s, sp, l, showtime, p0, p1), t3 = resource_target<3>(s, sp, l, showtime, p0, p1);
+    // regrowth: availability -> min(limit, pow(availability + 1, exponent)), one pow body for the drapes that regrow.
+    // Nothing here depends on another drape's tiles or on the generator, so all four run before any sampling.
+    int grow = (resource_regrows<0>(s, sp, l, showtime, p0, p1) ? 1 : 0) | (resource_regrows<1>(s, sp, l, showtime, p0, p1) ? 2 : 0) |
+               (resource_regrows<2>(s, sp, l, showtime, p0, p1) ? 4 : 0) | (resource_regrows<3>(s, sp, l, showtime, p0, p1) ? 8 : 0);
+    while (grow != 0) {
+      const int R = __builtin_ctz((unsigned)grow);
+      grow &= grow - 1;
+      const uint64_t a0 = opaque64((uint64_t)__double_as_longlong(s.avail[0])), a1 = opaque64((uint64_t)__double_as_longlong(s.avail[1])),
+                     a2 = opaque64((uint64_t)__double_as_longlong(s.avail[2])), a3 = opaque64((uint64_t)__double_as_longlong(s.avail[3]));
+      const double av = __longlong_as_double((long long)(R == 0 ? a0 : (R == 1 ? a1 : (R == 2 ? a2 : a3))));
+      const double min_limit = (R & 1) ? l.params[P_F_GROWTH_LIMIT] : l.params[P_D_GROWTH_LIMIT];
+      double nv = fmin(min_limit, sgw_glibc_pow(av + 1.0, l.params[P_D_EXPONENT]));   // math.pow = libm pow; both raise to the DRINK exponent
+      nv = fmin(nv, l.params[P_USABLE_HALF]);
+      const uint64_t nb = (uint64_t)__double_as_longlong(nv);
+      s.avail[0] = __longlong_as_double((long long)(R == 0 ? nb : a0)); s.avail[1] = __longlong_as_double((long long)(R == 1 ? nb : a1));
+      s.avail[2] = __longlong_as_double((long long)(R == 2 ? nb : a2)); s.avail[3] = __longlong_as_double((long long)(R == 3 ? nb : a3));
+    }
+    const int t0 = resource_target<0>(s, sp, l), t1 = resource_target<1>(s, sp, l);
+    const int t2 = resource_target<2>(s, sp, l), t3 = resource_target<3>(s, sp, l);
     SAV_T(8);
     // bit R: drape R has tiles to take away or to put
     int pending = ((t0 >= 0 && t0 != b3_count(s.dyn[L_D + 0])) ? 1 : 0) | ((t1 >= 0 && t1 != b3_count(s.dyn[L_D + 1])) ? 2 : 0) |
