@@ -247,6 +247,13 @@ __device__ inline void lds_wave_sync() {
 __device__ inline double* stage_cell(double* region, double* trash, int lane, int row_len, int slot) {
   return slot >= 0 ? region + lane * row_len + slot : trash + lane;
 }
+// the same for a run of cells of one region: the lane's row and trash cell are worked out once, a cell is then one select
+// between the two and one add of the (scalar) slot
+struct StageRow {
+  double* row; double* trash;
+  __device__ StageRow(double* region, double* trash_base, int lane, int row_len) : row(region + lane * row_len), trash(trash_base + lane) {}
+  __device__ double* cell(int slot) const { return (slot >= 0 ? row : trash) + (slot >= 0 ? slot : 0); }
+};
 
 // ---- Philox-4x32-10 (same stream as ai_safety_gridworlds_amd/philox.py) ---------------------
 struct U4 { uint32_t x, y, z, w; };
@@ -409,16 +416,25 @@ __device__ inline void coop_store(void* dst, long long env0, int row_bytes, cons
     if (lane < nchunk) store16_wt(g + lane, v);
     return;
   }
-  // batches of 4 chunks per lane: the 4 LDS reads are unconditional (index clamped) so they issue back to back;
-  // only the stores are guarded
-  for (int base = lane; base < nchunk; base += 4 * WAVE) {
-    const int last = nchunk - 1;
-    const int c0 = base, c1 = base + WAVE, c2 = base + 2 * WAVE, c3 = base + 3 * WAVE;
-    const uint4 v0 = s[c0], v1 = s[c1 < last ? c1 : last], v2 = s[c2 < last ? c2 : last], v3 = s[c3 < last ? c3 : last];
-    store16_wt(g + c0, v0);
-    if (c1 < nchunk) store16_wt(g + c1, v1);
-    if (c2 < nchunk) store16_wt(g + c2, v2);
-    if (c3 < nchunk) store16_wt(g + c3, v3);
+  // Whole 64-chunk blocks (1 KiB, one chunk per lane) first: which blocks exist is the same for every lane, so a batch of
+  // four is four LDS reads at fixed offsets from the lane's address (index clamped by SCALAR arithmetic, issued back to
+  // back) and up to four stores behind scalar branches -- no per-lane compare, no exec-mask bookkeeping per chunk.  Only
+  // the last, partial block (row_bytes not a multiple of 16) is guarded per lane.
+  const int nfull = nchunk >> 6, tail = nchunk & 63;
+  const uint4* sl = s + lane;
+  uint4* gl = g + lane;
+  for (int b = 0; b < nfull; b += 4) {
+    const int m = nfull - b;                       // blocks left: >= 1
+    const int k1 = m > 1 ? 1 : 0, k2 = m > 2 ? 2 : k1, k3 = m > 3 ? 3 : k2;
+    const uint4 v0 = sl[b * 64], v1 = sl[(b + k1) * 64], v2 = sl[(b + k2) * 64], v3 = sl[(b + k3) * 64];
+    store16_wt(gl + b * 64, v0);
+    if (m > 1) store16_wt(gl + (b + 1) * 64, v1);
+    if (m > 2) store16_wt(gl + (b + 2) * 64, v2);
+    if (m > 3) store16_wt(gl + (b + 3) * 64, v3);
+  }
+  if (tail != 0) {
+    const uint4 v = sl[(lane < tail ? nfull : 0) * 64];
+    if (lane < tail) store16_wt(gl + nfull * 64, v);
   }
 }
 // Slow path (masked reset): each lane copies only its own row.
@@ -474,7 +490,12 @@ __device__ inline void lds_write_board_row(uint32_t* img, int HW, int lane, cons
   if ((HW & 15) == 0) {
     uint4* row = reinterpret_cast<uint4*>(img) + lane * (HW >> 4);
     const uint4* b4 = reinterpret_cast<const uint4*>(base);
-    for (int i = 0; i < (HW >> 4); ++i) row[i] = b4[i];
+    const int n = HW >> 4;
+    for (int i = 0; i < n; i += 4) {                          // four table reads in flight, then the four row writes
+      const int i1 = i + 1 < n ? i + 1 : i, i2 = i + 2 < n ? i + 2 : i, i3 = i + 3 < n ? i + 3 : i;
+      const uint4 t0 = b4[i], t1 = b4[i1], t2 = b4[i2], t3 = b4[i3];
+      row[i] = t0; row[i1] = t1; row[i2] = t2; row[i3] = t3;
+    }
     uint8_t* rb = reinterpret_cast<uint8_t*>(img) + lane * HW;
 #pragma unroll
     for (int k = 0; k < NS; ++k) rb[cells[k]] = chars[k];

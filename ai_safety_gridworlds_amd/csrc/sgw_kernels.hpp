@@ -65,12 +65,14 @@ __device__ inline void emit_stage(const typename F::State& s, const double (&r)[
     }
   }
   if (nd & LN_REWARD) {
+    const StageRow row_r(l.vec_r, l.trash, lane, K);
 #pragma unroll
-    for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_r, l.trash, lane, K, F::slot(sp, u)) = r[u];
+    for (int u = 0; u < F::NU; ++u) *row_r.cell(F::slot(sp, u)) = r[u];
   }
   if (nd & LN_CUMULATIVE) {
+    const StageRow row_c(l.vec_c, l.trash, lane, K);
 #pragma unroll
-    for (int u = 0; u < F::NU; ++u) *stage_cell(l.vec_c, l.trash, lane, K, F::slot(sp, u)) = s.cum[u];
+    for (int u = 0; u < F::NU; ++u) *row_c.cell(F::slot(sp, u)) = s.cum[u];
   }
   if ((nd & LN_METRICS) && o.metrics && M > 0) {
 #pragma unroll
@@ -530,8 +532,9 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
       if (ae.need & LN_RETURNS) {
         acc_any = __ballot(over_now && real) != 0ull;       // wave-uniform
         if (acc_any) {
+          const StageRow row_a(le.vec_a, le.trash, lane, C);
 #pragma unroll
-          for (int u = 0; u < F::NU; ++u) *stage_cell(le.vec_a, le.trash, lane, C, F::slot(ae.sp, u)) = over_now ? s.cum[u] : 0.0;
+          for (int u = 0; u < F::NU; ++u) *row_a.cell(F::slot(ae.sp, u)) = over_now ? s.cum[u] : 0.0;
           le.vec_a[lane * C + C - 1] = over_now ? 1.0 : 0.0;
         }
         if constexpr (PIPE) { if (lane == 0) le.flag[0] = acc_any ? 1u : 0u; }
