@@ -40,6 +40,18 @@ namespace sgw {
 
 struct Map4 { uint64_t a, b, c, d; };      // 64 cells x 4 bits
 
+// out byte k = table byte sel.byte[k], table = {hi, lo} (bytes 0-3 of lo, then bytes 0-3 of hi); every selector byte is 0..7
+__device__ inline uint32_t byte_lut8(uint32_t hi, uint32_t lo, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+  const uint64_t t = ((uint64_t)hi << 32) | lo;
+  uint32_t v = 0;
+  for (int k = 0; k < 4; ++k) v |= (uint32_t)((t >> (8 * ((sel >> (8 * k)) & 7u))) & 0xffull) << (8 * k);
+  return v;
+#endif
+}
+
 struct IslandMa {
   static constexpr int NA = 2;
   static constexpr int NUA = 12;            // reward units per agent
@@ -403,14 +415,15 @@ struct IslandMa {
   // rendered board: backdrop / drapes from the map codes, then the two sprites
   static __device__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds& l, int i) {
     const uint32_t nib = (uint32_t)(mword(s.map, i >> 2) >> ((i & 3) * 16)) & 0xffffu;
-    const uint64_t lut = 0x5553474644572320ull;                  // ' ','#','W','D','F','G','S','U' (codes 0..7), low byte first
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t code = (nib >> (4 * k)) & 15u;
-      const uint32_t ch = code >= 8u ? 0x20u : (uint32_t)((lut >> (code * 8)) & 0xffull);
-      v |= (4 * i + k < sp.HW ? ch : 0u) << (8 * k);              // bytes past the board stay zero: with H*W not a multiple of 4 the
-    }                                                             // row is OR-ed into place next to the neighbouring env's bytes
+    // the four 4-bit map codes of this dword -> one selector byte each, then ONE byte permute looks all four up in
+    // ' ','#','W','D' | 'F','G','S','U' (codes 0..7; a code >= 8 renders as ' ': its selector is cleared to 0)
+    uint32_t z = (nib | (nib << 8)) & 0x00ff00ffu;
+    z = (z | (z << 4)) & 0x0f0f0f0fu;
+    const uint32_t big = z & 0x08080808u;
+    z &= ~((big << 1) - (big >> 3));
+    uint32_t v = byte_lut8(0x55534746u, 0x44572320u, z);
+    const int left = sp.HW - 4 * i;                               // bytes past the board stay zero: with H*W not a multiple of 4 the
+    v &= left >= 4 ? 0xffffffffu : ((1u << (8 * (left > 0 ? left : 0))) - 1u);   // row is OR-ed into place next to the neighbouring env's bytes
 #pragma unroll
     for (int ag = 0; ag < 2; ++ag) {
       const int cell = s.row[ag] * sp.W + s.col[ag];
