@@ -708,12 +708,17 @@ struct Firemaker {
   // shared with the neighbouring lanes' rows: zeroed by both owners, then OR-ed (the wave's LDS instructions execute in
   // order); the three sprites are byte stores on top.
   template <int I>
-  static __device__ __forceinline__ void stage_board_dword(uint32_t* row, const uint32_t* st, uint32_t& lo, const uint64_t (&P)[5], int q) {
+  static __device__ __forceinline__ void stage_board_dword(uint32_t* row, const uint32_t* st, uint32_t& lo, uint64_t& pw, const M5& fire, int q) {
     constexpr int wi = I >> 4, sh = (I & 15) * 4;
+    if constexpr ((I & 15) == 0) {                              // the next 64 cells of the fire mask, shifted by the row's misalignment
+      const uint64_t cur = wi == 0 ? fire.a : (wi == 1 ? fire.b : (wi == 2 ? fire.c : (wi == 3 ? fire.d : fire.e)));
+      const uint64_t below = wi == 0 ? 0ull : (wi == 1 ? fire.a : (wi == 2 ? fire.b : (wi == 3 ? fire.c : fire.d)));
+      pw = (cur << q) | ((below >> 1) >> (63 - q));
+    }
     const uint32_t hi = st[I + 1];
     uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * ((4 - q) & 3)));
     lo = hi;
-    const uint32_t half = sh < 32 ? (uint32_t)P[wi] : (uint32_t)(P[wi] >> 32);
+    const uint32_t half = sh < 32 ? (uint32_t)pw : (uint32_t)(pw >> 32);
     const uint32_t t = __umul24((half >> (sh & 31)) & 15u, 0x00204081u) & 0x01010101u;      // fire bit k -> bit 8k
     const uint32_t m = (t << 8) - t;                                                        // -> 0xff in byte k
     v = (v & ~m) | (0x46464646u & m);                                                       // 'F'
@@ -728,23 +733,22 @@ struct Firemaker {
     }
   }
   template <int... I>
-  static __device__ __forceinline__ void stage_board_dwords(uint32_t* row, const uint32_t* st, uint32_t& lo, const uint64_t (&P)[5], int q,
+  static __device__ __forceinline__ void stage_board_dwords(uint32_t* row, const uint32_t* st, uint32_t& lo, uint64_t& pw, const M5& fire, int q,
                                                             std::integer_sequence<int, I...>) {
-    (stage_board_dword<I>(row, st, lo, P, q), ...);
+    (stage_board_dword<I>(row, st, lo, pw, fire, q), ...);
   }
   static __device__ __forceinline__ void stage_board(const Lds& l, const State& s, const KSpec& sp, int lane) {
     static_assert(CELLS == 289, "73 image dwords per row");
     const int o = lane * CELLS, q = o & 3;
     uint32_t* row = l.board + (o >> 2);
-    const uint64_t P[5] = {s.fire.a << q, (s.fire.b << q) | ((s.fire.a >> 1) >> (63 - q)), (s.fire.c << q) | ((s.fire.b >> 1) >> (63 - q)),
-                           (s.fire.d << q) | ((s.fire.c >> 1) >> (63 - q)), (s.fire.e << q) | ((s.fire.d >> 1) >> (63 - q))};
     // image dword I holds row bytes 4I - q .. 4I - q + 3: the funnel's low dword is table dword I - (q > 0)
     const uint32_t* table = reinterpret_cast<const uint32_t*>(l.static_board);
     const uint32_t* st = table - (q != 0 ? 1 : 0);
     uint32_t lo = q != 0 ? 0u : table[0];
+    uint64_t pw = 0ull;
     if (q != 0) row[0] = 0u;
     if (q != 3) row[72] = 0u;
-    stage_board_dwords(row, st, lo, P, q, std::make_integer_sequence<int, 73>{});
+    stage_board_dwords(row, st, lo, pw, s.fire, q, std::make_integer_sequence<int, 73>{});
     uint8_t* rb = reinterpret_cast<uint8_t*>(l.board) + o;
 #pragma unroll
     for (int ag = 0; ag < 3; ++ag)
