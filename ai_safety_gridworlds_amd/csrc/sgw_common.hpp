@@ -473,6 +473,63 @@ __device__ inline void lds_write_row_unaligned(uint32_t* img, int HW, int lane, 
   }
 }
 
+// A row written 16 bytes at a time: quad(j) returns bytes 16j .. 16j+15 of the ROW (row-relative; what it holds past the
+// row's end is masked away here).  The callback reads its tables as 16-byte LDS loads and keeps everything that does not
+// depend on j outside; the four dwords are funnelled to the row's alignment (row `lane` starts at byte lane * HW) and
+// stored.  Dwords strictly inside every lane's row take a plain store behind a SCALAR test; only dword 0 and the row's
+// last dword can be shared with a neighbouring row (zeroed by both owners, then OR-ed).  Sprites and other single cells
+// go on top afterwards as byte stores into the lane's own row (lds_put_cell): the wave's LDS instructions execute in order.
+template <class QuadFn>
+__device__ inline void lds_write_row_quads(uint32_t* img, int HW, int lane, QuadFn quad) {
+  const int o = lane * HW, q = o & 3, sr = 32 - 8 * q;                 // sr = 32 (aligned row), 24, 16, 8
+  uint32_t* row = img + (o >> 2);
+  const int last = ((o + HW - 1) >> 2) - (o >> 2);                     // index of the last dword this row touches
+  const bool head_shared = q != 0, tail_shared = ((o + HW) & 3) != 0;
+  if (head_shared) row[0] = 0u;
+  if (tail_shared) row[last] = 0u;
+  const int nq = (HW + 15) >> 4, inner = (HW - 1) >> 2;                // dwords 1 .. inner - 1 lie inside every lane's row
+#if defined(__HIP_DEVICE_COMPILE__)
+  auto funnel = [&](uint32_t lo, uint32_t hi) { return q == 0 ? hi : __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sr); };   // one full-rate v_alignbit_b32
+#else
+  auto funnel = [&](uint32_t lo, uint32_t hi) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sr); };
+#endif
+  auto put = [&](int i, uint32_t v) {
+    if (i > 0 && i < inner) { row[i] = v; return; }                    // scalar test
+    if (i > last) return;
+    if ((i == 0 && head_shared) || (i == last && tail_shared)) { if (v) atomicOr(&row[i], v); } else row[i] = v;
+  };
+  auto keep = [](int bytes) { return bytes >= 4 ? 0xffffffffu : (bytes <= 0 ? 0u : ((1u << (8 * bytes)) - 1u)); };
+  uint32_t prev = 0u;
+  for (int j = 0; j < nq; ++j) {
+    uint4 c = quad(j);
+    const int left = HW - 16 * j;                                      // bytes of the row in this quad (scalar)
+    if (left < 16) { c.x &= keep(left); c.y &= keep(left - 4); c.z &= keep(left - 8); c.w &= keep(left - 12); }
+    put(4 * j, funnel(prev, c.x)); put(4 * j + 1, funnel(c.x, c.y)); put(4 * j + 2, funnel(c.y, c.z)); put(4 * j + 3, funnel(c.z, c.w));
+    prev = c.w;
+  }
+  put(4 * nq, funnel(prev, 0u));
+}
+// 0xff in every byte of v that equals the byte replicated in x4 (exact per byte: no carry crosses a byte)
+__device__ inline uint32_t bytes_equal_mask(uint32_t v, uint32_t x4) {
+  const uint32_t y = v ^ x4;
+  const uint32_t nz = ((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y;           // bit 7 of a byte set <=> the byte of y is not zero
+  const uint32_t one = (~nz & 0x80808080u) >> 7;
+  return (one << 8) - one;
+}
+// bytes of `idx` are table indices + 1 (0 = none): 0xff in every byte whose index has its bit set in `bits`
+__device__ inline uint32_t bytes_bit_mask(uint32_t idx, uint32_t bits) {
+  uint32_t m = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t q = (idx >> (8 * k)) & 0xffu;
+    m |= (q != 0u && ((bits >> ((q - 1u) & 31u)) & 1u)) ? (0xffu << (8 * k)) : 0u;
+  }
+  return m;
+}
+__device__ inline void lds_put_cell(uint32_t* img, int HW, int lane, int cell, uint32_t ch) {
+  reinterpret_cast<uint8_t*>(img)[lane * HW + cell] = (uint8_t)ch;
+}
+
 template <int NS>
 __device__ inline uint32_t patched_dword(const uint32_t* base, int i, const int (&cells)[NS], const uint8_t (&chars)[NS]) {
   uint32_t v = base[i];
@@ -486,7 +543,6 @@ template <int NS>
 __device__ inline void lds_write_board_row(uint32_t* img, int HW, int lane, const uint8_t* base_bytes,
                                            const int (&cells)[NS], const uint8_t (&chars)[NS]) {
   const uint32_t* base = reinterpret_cast<const uint32_t*>(base_bytes);
-  const int ndw = (HW + 3) >> 2;
   if ((HW & 15) == 0) {
     uint4* row = reinterpret_cast<uint4*>(img) + lane * (HW >> 4);
     const uint4* b4 = reinterpret_cast<const uint4*>(base);
@@ -499,18 +555,11 @@ __device__ inline void lds_write_board_row(uint32_t* img, int HW, int lane, cons
     uint8_t* rb = reinterpret_cast<uint8_t*>(img) + lane * HW;
 #pragma unroll
     for (int k = 0; k < NS; ++k) rb[cells[k]] = chars[k];
-  } else if ((HW & 3) == 0) {
-    uint32_t* row = img + lane * ndw;
-    for (int i = 0; i < ndw; ++i) row[i] = base[i];
-    uint8_t* rb = reinterpret_cast<uint8_t*>(img) + lane * HW;
+  } else {                                                  // any other size: 16 table bytes per pass, funnelled to the row's alignment
+    const uint4* b4 = reinterpret_cast<const uint4*>(base);
+    lds_write_row_quads(img, HW, lane, [&](int j) { return b4[j]; });
 #pragma unroll
-    for (int k = 0; k < NS; ++k) rb[cells[k]] = chars[k];
-  } else {
-    lds_write_row_unaligned(img, HW, lane, [&](int i) {
-      uint32_t v = patched_dword<NS>(base, i, cells, chars);
-      const int left = HW - 4 * i;                            // bytes of the table past the row are not part of it
-      return left >= 4 ? v : (v & ((1u << (8 * left)) - 1u));
-    });
+    for (int k = 0; k < NS; ++k) lds_put_cell(img, HW, lane, cells[k], chars[k]);
   }
 }
 // Boards with per-cell dynamic content (fire): the family supplies each dword of its row.

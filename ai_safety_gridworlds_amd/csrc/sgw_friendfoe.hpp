@@ -146,6 +146,25 @@ struct FriendFoe {
     put(s.row * sp.W + s.col, (uint32_t)'A');
     return v;
   }
+  // the same rendering into the wave's LDS image: 16 static bytes at a time with the bandit's tile substituted for the
+  // placeholder byte 1, then the goal digits and the agent as byte stores
+  static __device__ __forceinline__ void stage_board(const Lds& l, const State& s, const KSpec& sp, int lane) {
+    const uint4* st = reinterpret_cast<const uint4*>(l.static_board);
+    const uint32_t tile4 = 0x01010101u * (s.bandit == 0 ? (uint32_t)'F' : (s.bandit == 1 ? (uint32_t)'N' : (uint32_t)'B'));
+    lds_write_row_quads(l.board, sp.HW, lane, [&](int j) {
+      uint4 v = st[j];
+      const uint32_t mx = bytes_equal_mask(v.x, 0x01010101u), my = bytes_equal_mask(v.y, 0x01010101u),
+                     mz = bytes_equal_mask(v.z, 0x01010101u), mw = bytes_equal_mask(v.w, 0x01010101u);
+      v.x = (v.x & ~mx) | (tile4 & mx); v.y = (v.y & ~my) | (tile4 & my); v.z = (v.z & ~mz) | (tile4 & mz); v.w = (v.w & ~mw) | (tile4 & mw);
+      return v;
+    });
+    if (s.showing) {                                         // show_goals FF:204-212: one row above each box
+      const int ca = (int)l.params[P_BOX_A] - sp.W, cb = (int)l.params[P_BOX_B] - sp.W;
+      lds_put_cell(l.board, sp.HW, lane, ca, s.level == 0 ? '1' : '0');
+      lds_put_cell(l.board, sp.HW, lane, cb, s.level == 0 ? '0' : '1');
+    }
+    lds_put_cell(l.board, sp.HW, lane, s.row * sp.W + s.col, 'A');
+  }
   static __device__ const uint8_t* board_layers(const State&, const KSpec&, const Lds& l, int (&)[1], uint8_t (&)[1]) { return l.static_board; }
   static __device__ int actual(const State& s, int) { return s.actual; }
   static __device__ void agent_pos(const State& s, int, int& r, int& c) { r = s.row; c = s.col; }

@@ -149,6 +149,19 @@ struct Rocks {
     put((int)p[P_DIA_SW], s.dia_high ? (uint32_t)'Q' : (uint32_t)'q');
     return v;
   }
+  // the same rendering into the wave's LDS image: the static row 16 bytes at a time, the sprites as byte stores in z-order
+  static __device__ __forceinline__ void stage_board(const Lds& l, const State& s, const KSpec& sp, int lane) {
+    const uint4* st = reinterpret_cast<const uint4*>(l.static_board);
+    lds_write_row_quads(l.board, sp.HW, lane, [&](int j) { return st[j]; });
+    const double* p = l.params;
+    const int nrock = (int)p[P_NROCK];
+    lds_put_cell(l.board, sp.HW, lane, s.row * sp.W + s.col, 'A');
+#pragma unroll
+    for (int k = 1; k < NL; ++k) if (k <= nrock) lds_put_cell(l.board, sp.HW, lane, s.lr[k] * sp.W + s.lc[k], (uint32_t)('0' + k));
+    lds_put_cell(l.board, sp.HW, lane, s.lr[0] * sp.W + s.lc[0], 'D');
+    lds_put_cell(l.board, sp.HW, lane, (int)p[P_ROCK_SW], s.rock_high ? 'P' : 'p');
+    lds_put_cell(l.board, sp.HW, lane, (int)p[P_DIA_SW], s.dia_high ? 'Q' : 'q');
+  }
   static __device__ const uint8_t* board_layers(const State&, const KSpec&, const Lds& l, int (&)[1], uint8_t (&)[1]) { return l.static_board; }
   static __device__ int actual(const State& s, int) { return s.actual; }
   static __device__ void agent_pos(const State& s, int, int& r, int& c) { r = s.row; c = s.col; }

@@ -165,6 +165,24 @@ struct Sokoban {
     put(s.row * sp.W + s.col, (uint32_t)'A');
     return v;
   }
+  // the same rendering into the wave's LDS image: the static row 16 bytes at a time, then boxes, live coins and the agent
+  // as byte stores in z-order; the cells and characters come from the spec's tables, all read before the first store
+  static __device__ __forceinline__ void stage_board(const Lds& l, const State& s, const KSpec& sp, int lane) {
+    const uint4* st = reinterpret_cast<const uint4*>(l.static_board);
+    lds_write_row_quads(l.board, sp.HW, lane, [&](int j) { return st[j]; });
+    const double* p = l.params;
+    const int nb = (int)p[P_NBOX], nc = (int)p[P_NCOIN];
+    double chr[MAXBOX], ccell[MAXCOIN];
+#pragma unroll
+    for (int j = 0; j < MAXBOX; ++j) chr[j] = p[P_BOXCHR0 + j];
+#pragma unroll
+    for (int j = 0; j < MAXCOIN; ++j) ccell[j] = p[P_COINCELL0 + j];
+#pragma unroll
+    for (int j = 0; j < MAXBOX; ++j) if (j < nb) lds_put_cell(l.board, sp.HW, lane, s.brow[j] * sp.W + s.bcol[j], (uint32_t)chr[j]);
+#pragma unroll
+    for (int j = 0; j < MAXCOIN; ++j) if (j < nc && ((s.coins >> j) & 1u)) lds_put_cell(l.board, sp.HW, lane, (int)ccell[j], 'C');
+    lds_put_cell(l.board, sp.HW, lane, s.row * sp.W + s.col, 'A');
+  }
   static __device__ const uint8_t* board_layers(const State&, const KSpec&, const Lds& l, int (&)[1], uint8_t (&)[1]) { return l.static_board; }
   static __device__ int actual(const State& s, int) { return s.actual; }
   static __device__ void agent_pos(const State& s, int, int& r, int& c) { r = s.row; c = s.col; }

@@ -153,6 +153,36 @@ struct Tomato {
     put(acell, (uint32_t)'A');
     return v;
   }
+  // the same rendering into the wave's LDS image: the static row 16 bytes at a time (with every cell but walls, the
+  // transformer and the padding turned into 'T' when the agent stands on the transformer), then one byte store per watered
+  // tomato -- its cell comes from the spec's index -> cell table, read eight entries at a time -- and the agent
+  static __device__ __forceinline__ void stage_board(const Lds& l, const State& s, const KSpec& sp, int lane) {
+    const uint4* st = reinterpret_cast<const uint4*>(l.static_board);
+    const int acell = s.row * sp.W + s.col;
+    const bool all_watered = l.art[acell] == 'O' && l.params[P_CRMDP] == 0.0;      // TC:139
+    const uint32_t T4 = 0x54545454u;
+    lds_write_row_quads(l.board, sp.HW, lane, [&](int j) {
+      uint4 v = st[j];
+      if (all_watered) {
+        const uint32_t mx = ~(bytes_equal_mask(v.x, 0x23232323u) | bytes_equal_mask(v.x, 0x4f4f4f4fu) | bytes_equal_mask(v.x, 0u));
+        const uint32_t my = ~(bytes_equal_mask(v.y, 0x23232323u) | bytes_equal_mask(v.y, 0x4f4f4f4fu) | bytes_equal_mask(v.y, 0u));
+        const uint32_t mz = ~(bytes_equal_mask(v.z, 0x23232323u) | bytes_equal_mask(v.z, 0x4f4f4f4fu) | bytes_equal_mask(v.z, 0u));
+        const uint32_t mw = ~(bytes_equal_mask(v.w, 0x23232323u) | bytes_equal_mask(v.w, 0x4f4f4f4fu) | bytes_equal_mask(v.w, 0u));
+        v.x = (v.x & ~mx) | (T4 & mx); v.y = (v.y & ~my) | (T4 & my); v.z = (v.z & ~mz) | (T4 & mz); v.w = (v.w & ~mw) | (T4 & mw);
+      }
+      return v;
+    });
+    const int n = (int)l.params[P_NTOMATO];
+    for (int i0 = 0; i0 < n; i0 += 8) {
+      double c[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c[k] = l.params[P_CELL0 + (i0 + k < n ? i0 + k : n - 1)];      // scalar clamp: eight reads in flight
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + k < n && !all_watered && ((s.watered >> (i0 + k)) & 1u)) lds_put_cell(l.board, sp.HW, lane, (int)c[k], 'T');
+    }
+    lds_put_cell(l.board, sp.HW, lane, acell, 'A');
+  }
   static __device__ const uint8_t* board_layers(const State&, const KSpec&, const Lds& l, int (&)[1], uint8_t (&)[1]) { return l.static_board; }
   static __device__ int actual(const State& s, int) { return s.actual; }
   static __device__ void agent_pos(const State& s, int, int& r, int& c) { r = s.row; c = s.col; }

@@ -108,6 +108,14 @@ struct Whisky {
     put(s.row * sp.W + s.col, (uint32_t)'A');
     return v;
   }
+  // the same rendering into the wave's LDS image: the static row 16 bytes at a time, then the marks and the agent as byte stores
+  static __device__ __forceinline__ void stage_board(const Lds& l, const State& s, const KSpec& sp, int lane) {
+    const uint4* st = reinterpret_cast<const uint4*>(l.static_board);
+    lds_write_row_quads(l.board, sp.HW, lane, [&](int j) { return st[j]; });
+    if (s.marked) for (int c = 0; c < sp.W; ++c) lds_put_cell(l.board, sp.HW, lane, c, 'W');
+    lds_put_cell(l.board, sp.HW, lane, (int)l.params[P_WCELL], 'W');
+    lds_put_cell(l.board, sp.HW, lane, s.row * sp.W + s.col, 'A');
+  }
   static __device__ const uint8_t* board_layers(const State&, const KSpec&, const Lds& l, int (&)[1], uint8_t (&)[1]) { return l.static_board; }
   static __device__ int actual(const State& s, int) { return s.actual; }
   static __device__ void agent_pos(const State& s, int, int& r, int& c) { r = s.row; c = s.col; }
