@@ -481,6 +481,19 @@ __device__ inline void lds_write_row_unaligned(uint32_t* img, int HW, int lane, 
 // go on top afterwards as byte stores into the lane's own row (lds_put_cell): the wave's LDS instructions execute in order.
 template <class QuadFn>
 __device__ inline void lds_write_row_quads(uint32_t* img, int HW, int lane, QuadFn quad) {
+  if ((HW & 3) == 0) {                                                 // every row starts on a dword and shares none: plain stores
+    const int ndw = HW >> 2, nq = (HW + 15) >> 4;
+    uint32_t* row = img + lane * ndw;
+    for (int j = 0; j < nq; ++j) {
+      const uint4 c = quad(j);
+      const int i = 4 * j;                                             // the guards are scalar
+      row[i] = c.x;
+      if (i + 1 < ndw) row[i + 1] = c.y;
+      if (i + 2 < ndw) row[i + 2] = c.z;
+      if (i + 3 < ndw) row[i + 3] = c.w;
+    }
+    return;
+  }
   const int o = lane * HW, q = o & 3, sr = 32 - 8 * q;                 // sr = 32 (aligned row), 24, 16, 8
   uint32_t* row = img + (o >> 2);
   const int last = ((o + HW - 1) >> 2) - (o >> 2);                     // index of the last dword this row touches
