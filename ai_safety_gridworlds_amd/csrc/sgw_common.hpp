@@ -449,30 +449,6 @@ __device__ inline void lane_store(void* dst, long long env, int row_bytes, const
 // HW % 4 == 0: copy the base row with the widest aligned LDS accesses, then patch single bytes.
 // Otherwise rows are not dword aligned: each lane shifts its row into place and ORs the dwords into a
 // zeroed image (boundary dwords are shared by two neighbouring lanes).
-// Rows that are not a whole number of dwords (H*W % 4 != 0): lane l's row starts at byte l*HW of the packed image, so
-// each lane shifts its dwords into place.  Only the first and the last dword of a row can be shared with a neighbouring
-// lane: those two are zeroed (by both owners) and then OR-ed; every dword in between is owned by one lane and stored plainly.
-// The wave's LDS instructions execute in order, so the zero stores of all lanes precede the ORs without a barrier.
-template <class DwordFn>
-__device__ inline void lds_write_row_unaligned(uint32_t* img, int HW, int lane, DwordFn dword_at) {
-  const int ndw = (HW + 3) >> 2;
-  const int o = lane * HW;
-  uint32_t* row = img + (o >> 2);
-  const int sh = (o & 3) * 8;
-  const int last = ((o + HW - 1) >> 2) - (o >> 2);          // index of the last dword this row touches
-  const bool head_shared = sh != 0, tail_shared = ((o + HW) & 3) != 0;
-  if (head_shared) row[0] = 0u;
-  if (tail_shared) row[last] = 0u;
-  uint32_t prev = 0;
-  for (int i = 0; i <= last; ++i) {
-    const uint32_t cur = (i < ndw) ? dword_at(i) : 0u;
-    const uint32_t v = sh ? ((prev >> (32 - sh)) | (cur << sh)) : cur;
-    if ((i == 0 && head_shared) || (i == last && tail_shared)) { if (v) atomicOr(&row[i], v); }
-    else row[i] = v;
-    prev = cur;
-  }
-}
-
 // A row written 16 bytes at a time: quad(j) returns bytes 16j .. 16j+15 of the ROW (row-relative; what it holds past the
 // row's end is masked away here).  The callback reads its tables as 16-byte LDS loads and keeps everything that does not
 // depend on j outside; the four dwords are funnelled to the row's alignment (row `lane` starts at byte lane * HW) and
@@ -544,15 +520,6 @@ __device__ inline void lds_put_cell(uint32_t* img, int HW, int lane, int cell, u
 }
 
 template <int NS>
-__device__ inline uint32_t patched_dword(const uint32_t* base, int i, const int (&cells)[NS], const uint8_t (&chars)[NS]) {
-  uint32_t v = base[i];
-#pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    if ((cells[k] >> 2) == i) { int sh = (cells[k] & 3) * 8; v = (v & ~(0xffu << sh)) | ((uint32_t)chars[k] << sh); }
-  }
-  return v;
-}
-template <int NS>
 __device__ inline void lds_write_board_row(uint32_t* img, int HW, int lane, const uint8_t* base_bytes,
                                            const int (&cells)[NS], const uint8_t (&chars)[NS]) {
   const uint32_t* base = reinterpret_cast<const uint32_t*>(base_bytes);
@@ -573,17 +540,6 @@ __device__ inline void lds_write_board_row(uint32_t* img, int HW, int lane, cons
     lds_write_row_quads(img, HW, lane, [&](int j) { return b4[j]; });
 #pragma unroll
     for (int k = 0; k < NS; ++k) lds_put_cell(img, HW, lane, cells[k], chars[k]);
-  }
-}
-// Boards with per-cell dynamic content (fire): the family supplies each dword of its row.
-template <class DwordFn>
-__device__ inline void lds_write_board_row_fn(uint32_t* img, int HW, int lane, DwordFn dword_at) {
-  const int ndw = (HW + 3) >> 2;
-  if ((HW & 3) == 0) {
-    uint32_t* row = img + lane * ndw;
-    for (int i = 0; i < ndw; ++i) row[i] = dword_at(i);
-  } else {
-    lds_write_row_unaligned(img, HW, lane, dword_at);       // dword_at returns zero bytes past the row's end
   }
 }
 __device__ inline void lds_zero_board(uint32_t* img, int HW) {

@@ -415,13 +415,7 @@ struct IslandMa {
   // rendered board: backdrop / drapes from the map codes, then the two sprites
   static __device__ uint32_t board_dword(const State& s, const KSpec& sp, const Lds& l, int i) {
     const uint32_t nib = (uint32_t)(mword(s.map, i >> 2) >> ((i & 3) * 16)) & 0xffffu;
-    // the four 4-bit map codes of this dword -> one selector byte each, then ONE byte permute looks all four up in
-    // ' ','#','W','D' | 'F','G','S','U' (codes 0..7; a code >= 8 renders as ' ': its selector is cleared to 0)
-    uint32_t z = (nib | (nib << 8)) & 0x00ff00ffu;
-    z = (z | (z << 4)) & 0x0f0f0f0fu;
-    const uint32_t big = z & 0x08080808u;
-    z &= ~((big << 1) - (big >> 3));
-    uint32_t v = byte_lut8(0x55534746u, 0x44572320u, z);
+    uint32_t v = code_chars(nib);
     const int left = sp.HW - 4 * i;                               // bytes past the board stay zero: with H*W not a multiple of 4 the
     v &= left >= 4 ? 0xffffffffu : ((1u << (8 * (left > 0 ? left : 0))) - 1u);   // row is OR-ed into place next to the neighbouring env's bytes
 #pragma unroll
@@ -433,6 +427,25 @@ struct IslandMa {
       }
     }
     return v;
+  }
+  // four map codes (16 bits) -> their four characters: one selector byte per code, then ONE byte permute over
+  // ' ','#','W','D' | 'F','G','S','U' (codes 0..7; a code >= 8 renders as ' ': its selector is cleared to 0)
+  static __device__ __forceinline__ uint32_t code_chars(uint32_t nib) {
+    uint32_t z = (nib | (nib << 8)) & 0x00ff00ffu;
+    z = (z | (z << 4)) & 0x0f0f0f0fu;
+    const uint32_t big = z & 0x08080808u;
+    z &= ~((big << 1) - (big >> 3));
+    return byte_lut8(0x55534746u, 0x44572320u, z);
+  }
+  // the same rendering into the wave's LDS image: a map word is 16 cells = one 16-byte pass; the two sprites are byte stores
+  static __device__ __forceinline__ void stage_board(const Lds& l, const State& s, const KSpec& sp, int lane) {
+    lds_write_row_quads(l.board, sp.HW, lane, [&](int j) {
+      const uint64_t w = mword(s.map, j);
+      return make_uint4(code_chars((uint32_t)w & 0xffffu), code_chars((uint32_t)(w >> 16) & 0xffffu),
+                        code_chars((uint32_t)(w >> 32) & 0xffffu), code_chars((uint32_t)(w >> 48)));
+    });
+    lds_put_cell(l.board, sp.HW, lane, s.row[0] * sp.W + s.col[0], '1');
+    lds_put_cell(l.board, sp.HW, lane, s.row[1] * sp.W + s.col[1], '2');
   }
   static __device__ const uint8_t* board_layers(const State&, const KSpec&, const Lds& l, int (&)[2], uint8_t (&)[2]) { return l.static_board; }
 

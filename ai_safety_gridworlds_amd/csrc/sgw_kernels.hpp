@@ -32,8 +32,6 @@ template <class F, class = void> struct rollout_rereads : std::true_type {};
 template <class F> struct rollout_rereads<F, std::void_t<decltype(F::ROLLOUT_KEEPS_ARGS)>> : std::integral_constant<bool, !F::ROLLOUT_KEEPS_ARGS> {};
 template <class F, class = void> struct has_init_args : std::false_type {};
 template <class F> struct has_init_args<F, std::void_t<decltype(&F::init_args)>> : std::true_type {};
-template <class F, class = void> struct has_board_prepare : std::false_type {};
-template <class F> struct has_board_prepare<F, std::void_t<typename F::BoardPrep>> : std::true_type {};
 // families that write their row of the rendered board into the wave's LDS image themselves
 template <class F, class = void> struct has_board_stage : std::false_type {};
 template <class F> struct has_board_stage<F, std::void_t<decltype(&F::stage_board)>> : std::true_type {};
@@ -51,14 +49,10 @@ __device__ inline void emit_stage(const typename F::State& s, const double (&r)[
   const int nd = a.need;
   const int HW = sp.HW, K = sp.A * sp.K, M = sp.M;   // reward rows hold all agents' vectors: [A][K]
   if (nd & (LN_BOARD | LN_OBS)) {
-    if constexpr (has_board_stage<F>::value) {
+    if constexpr (has_board_stage<F>::value) {            // boards with dynamic content: the family writes its row itself
       F::stage_board(l, s, sp, lane);
-    } else if constexpr (has_board_prepare<F>::value) { // per-step precomputation shared by every dword of the row
-      const auto bp = F::board_prepare(s, sp);
-      lds_write_board_row_fn(l.board, HW, lane, [&](int i) { return F::board_dword(bp, s, sp, i); });
-    } else if constexpr (F::CUSTOM_BOARD) {
-      lds_write_board_row_fn(l.board, HW, lane, [&](int i) { return F::board_dword(s, sp, l, i); });
     } else {
+      static_assert(!F::CUSTOM_BOARD, "a family with a custom board provides stage_board()");
       int cells[F::NSPRITE]; uint8_t chars[F::NSPRITE];
       const uint8_t* base = F::board_layers(s, sp, l, cells, chars);
       lds_write_board_row<F::NSPRITE>(l.board, HW, lane, base, cells, chars);
