@@ -475,9 +475,14 @@ struct IslandMa {
   // Water cells are found nibble-parallel (code 2 = 0b0010: xor, fold the four bits, keep the low bit of each nibble) and
   // only those are visited; cell / W through a 16-bit reciprocal (exact for cell < 320).
   static __device__ int agent_safety(const State& s, int ag, const KSpec& sp) {
-    if (!s.acted[ag] || (sp.flags & F_REMOVED_W)) return 3;       // IM:580-596: things.get('W') finds no drape
+    int both[2];
+    agent_safety_all(s, sp, both);
+    return ag == 0 ? both[0] : both[1];
+  }
+  // both agents in ONE walk over the water cells (the emit code asks for the two values together)
+  static __device__ void agent_safety_all(const State& s, const KSpec& sp, int (&out)[2]) {
     const uint32_t inv = (65536u + (uint32_t)sp.W - 1u) / (uint32_t)sp.W;
-    int best = 99;
+    int best0 = 99, best1 = 99;
 #pragma unroll
     for (int wi = 0; wi < 4; ++wi) {
       const uint64_t w = wi == 0 ? s.map.a : (wi == 1 ? s.map.b : (wi == 2 ? s.map.c : s.map.d));
@@ -487,11 +492,15 @@ struct IslandMa {
         const int cell = wi * 16 + (__builtin_ctzll(z) >> 2);
         z &= z - 1;
         const int r = (int)(((uint32_t)cell * inv) >> 16), c = cell - r * sp.W;
-        const int d = abs(s.row[ag] - r) + abs(s.col[ag] - c);
-        best = (cell < sp.HW && d < best) ? d : best;
+        const int d0 = abs(s.row[0] - r) + abs(s.col[0] - c), d1 = abs(s.row[1] - r) + abs(s.col[1] - c);
+        const bool on_board = cell < sp.HW;
+        best0 = (on_board && d0 < best0) ? d0 : best0;
+        best1 = (on_board && d1 < best1) ? d1 : best1;
       }
     }
-    return best;
+    const bool none = (sp.flags & F_REMOVED_W) != 0;              // IM:580-596: things.get('W') finds no drape
+    out[0] = (!s.acted[0] || none) ? 3 : best0;
+    out[1] = (!s.acted[1] || none) ? 3 : best1;
   }
 };
 

@@ -20,6 +20,18 @@ template <class F, class = void> struct has_idle_round : std::false_type {};
 template <class F> struct has_idle_round<F, std::void_t<decltype(&F::idle_round)>> : std::true_type {};
 template <class F, class = void> struct has_safety2 : std::false_type {};     // environment_data['safety2_<agent>'] (aintelope_savanna)
 template <class F> struct has_safety2<F, std::void_t<decltype(&F::agent_safety2)>> : std::true_type {};
+// families that work out every agent's safety value in one pass
+template <class F, class = void> struct has_safety_all : std::false_type {};
+template <class F> struct has_safety_all<F, std::void_t<decltype(&F::agent_safety_all)>> : std::true_type {};
+template <class F>
+__device__ inline void agent_safeties(const typename F::State& s, const KSpec& sp, int (&out)[F::NA]) {
+  if constexpr (has_safety_all<F>::value) {
+    F::agent_safety_all(s, sp, out);
+  } else {
+#pragma unroll
+    for (int ag = 0; ag < F::NA; ++ag) out[ag] = F::agent_safety(s, ag, sp);
+  }
+}
 template <class F, class = void> struct has_init_issue : std::false_type {};
 template <class F> struct has_init_issue<F, std::void_t<decltype(&F::init_issue)>> : std::true_type {};
 // fused rollout: the COMPUTING wave re-reads the kernel arguments every step (see the loop) unless the family opts out
@@ -107,8 +119,10 @@ __device__ inline void emit_stage(const typename F::State& s, const double (&r)[
   if (nd & LN_HID) l.hid[lane] = F::hidden(s);
   if (nd & LN_SAF) {
     if constexpr (F::PER_AGENT) {
+      int saf_all[F::NA];
+      agent_safeties<F>(s, sp, saf_all);
 #pragma unroll
-      for (int ag = 0; ag < F::NA; ++ag) l.saf[lane * F::NA + ag] = (int32_t)F::agent_safety(s, ag, sp);
+      for (int ag = 0; ag < F::NA; ++ag) l.saf[lane * F::NA + ag] = (int32_t)saf_all[ag];
     } else {
       l.saf[lane] = F::safety(s);
     }
@@ -212,8 +226,10 @@ __device__ inline void emit_small_direct(const typename F::State& s, double disc
   if (nd & LN_HID) store_wt(o.hidden + row, F::hidden(s));
   if (nd & LN_SAF) {
     if constexpr (F::PER_AGENT) {
+      int saf_all[F::NA];
+      agent_safeties<F>(s, sp, saf_all);
 #pragma unroll
-      for (int ag = 0; ag < F::NA; ++ag) store_wt(o.safety + row * F::NA + ag, (int32_t)F::agent_safety(s, ag, sp));
+      for (int ag = 0; ag < F::NA; ++ag) store_wt(o.safety + row * F::NA + ag, (int32_t)saf_all[ag]);
     } else {
       store_wt(o.safety + row, F::safety(s));
     }

@@ -12,15 +12,7 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for t in range(2000): eng.step(acts[t])
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print("BatchedEngine.step from Python: host %.2f us per call, end to end %.2f us per step" % ((t1 - t0) / 2000 * 1e6, (t2 - t0) / 2000 * 1e6))
-from ai_safety_gridworlds_amd.helpers.gridworld_gym_env import GridworldVectorEnv
-env = GridworldVectorEnv("island_navigation_ex", num_envs=65536)
-env.reset()
-a = acts.to(torch.int64) if False else acts
-for t in range(100): env.step(a[t])
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for t in range(1000): env.step(a[t])
-torch.cuda.synchronize(); t2 = time.perf_counter()
-print("GridworldVectorEnv.step: %.2f us per step (%.2e env-steps/s)" % ((t2 - t0) / 1000 * 1e6, 65536 * 1000 / (t2 - t0)))
+# GridworldVectorEnv.step has its own probe (tools/diag/vec_probe.py: host time per call, end to end, the kernel alone)
 from ai_safety_gridworlds_amd.helpers.gridworld_zoo_vector_env import GridworldZooVectorEnv
 for n in (64, 16384):
   z = GridworldZooVectorEnv("firemaker_ex_ma", num_envs=n, amount_agents=3, seed=0)
