@@ -295,6 +295,13 @@ extern "C" int sgw_debug_sav_prof(unsigned long long* out, int clear) {      // 
   return 0;
 }
 #endif
+#ifdef SGW_PHASE_PROF   // diagnostic build only
+extern "C" int sgw_debug_phase_prof(unsigned long long* out, int clear) {    // out[4096 * 8]
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_prof), 4096 * 8 * 8) != hipSuccess) return -1;
+  if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase_prof)) != hipSuccess || hipMemset(p, 0, 4096 * 8 * 8) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 #ifdef SGW_FM_PROF      // diagnostic build only
 extern "C" int sgw_debug_fm_prof(unsigned long long* out, int clear) {      // out[4096 * 16]
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fm_prof), 4096 * 16 * 8) != hipSuccess) return -1;

@@ -82,6 +82,21 @@ struct KArgs {
     __builtin_amdgcn_sched_barrier(0);                                                           \
     if ((threadIdx.x & 63) == 0) (a).sgw_stamps[sgw_stamp_wave * 8 + (k)] = t_;                   \
   } while (0)
+#elif defined(SGW_PHASE_PROF)
+// diagnostic LIBRARY build (tools/diag/phase_prof.py): wave cycles between the same marks, summed per wave over launches,
+// for whatever family runs -- slot k = cycles from mark k-1 to mark k
+__device__ unsigned long long g_phase_prof[4096 * 8];
+__device__ unsigned long long g_phase_last[4096];
+#define SGW_STAMP(a, k)                                                                          \
+  do {                                                                                           \
+    unsigned long long t_;                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    const int w_ = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 4095;                   \
+    if ((threadIdx.x & 63) == 0) { if ((k) != 0) g_phase_prof[w_ * 8 + (k)] += t_ - g_phase_last[w_]; g_phase_last[w_] = t_; } \
+  } while (0)
+#define SGW_STAMP_RT(a, k) do { } while (0)
 #else
 #define SGW_STAMP(a, k) do { } while (0)
 #define SGW_STAMP_RT(a, k) do { } while (0)

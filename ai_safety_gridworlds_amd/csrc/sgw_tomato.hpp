@@ -179,7 +179,8 @@ struct Tomato {
       for (int k = 0; k < 8; ++k) c[k] = l.params[P_CELL0 + (i0 + k < n ? i0 + k : n - 1)];      // scalar clamp: eight reads in flight
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        if (i0 + k < n && !all_watered && ((s.watered >> (i0 + k)) & 1u)) lds_put_cell(l.board, sp.HW, lane, (int)c[k], 'T');
+        if (i0 + k < n)                                        // scalar guard; a dry tomato's cell is rewritten with its own 't': no per-lane branch
+          lds_put_cell(l.board, sp.HW, lane, (int)c[k], (all_watered || ((s.watered >> (i0 + k)) & 1u)) ? 'T' : 't');
     }
     lds_put_cell(l.board, sp.HW, lane, acell, 'A');
   }
