@@ -538,43 +538,14 @@ template <int NS>
 __device__ inline void lds_write_board_row(uint32_t* img, int HW, int lane, const uint8_t* base_bytes,
                                            const int (&cells)[NS], const uint8_t (&chars)[NS]) {
   const uint32_t* base = reinterpret_cast<const uint32_t*>(base_bytes);
-  // does every lane render from the same table?  (absent_supervisor picks the table by the env's state)
-#if defined(__HIP_DEVICE_COMPILE__)
-  const uint32_t b_lo = (uint32_t)reinterpret_cast<uintptr_t>(base_bytes);
-  const bool same_table = __ballot(b_lo != (uint32_t)__builtin_amdgcn_readfirstlane((int)b_lo)) == 0ull;
-#else
-  const bool same_table = true;
-#endif
-  if ((HW & 15) == 0 && !same_table) {                       // a row per lane, four table reads in flight
+  if ((HW & 15) == 0) {
     uint4* row = reinterpret_cast<uint4*>(img) + lane * (HW >> 4);
     const uint4* b4 = reinterpret_cast<const uint4*>(base);
     const int n = HW >> 4;
-    for (int i = 0; i < n; i += 4) {
+    for (int i = 0; i < n; i += 4) {                          // four table reads in flight, then the four row writes
       const int i1 = i + 1 < n ? i + 1 : i, i2 = i + 2 < n ? i + 2 : i, i3 = i + 3 < n ? i + 3 : i;
       const uint4 t0 = b4[i], t1 = b4[i1], t2 = b4[i2], t3 = b4[i3];
       row[i] = t0; row[i1] = t1; row[i2] = t2; row[i3] = t3;
-    }
-    uint8_t* rb = reinterpret_cast<uint8_t*>(img) + lane * HW;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) rb[cells[k]] = chars[k];
-  } else if ((HW & 15) == 0) {
-    // Every row is the same table plus its sprites, and emit_stage runs with the whole wave: the 64 x (HW / 16) chunks of the
-    // image are filled COOPERATIVELY, chunk lane + 64 k by lane `lane` -- consecutive lanes write consecutive 16 bytes (a
-    // lane writing its own row strides by HW bytes: a 16-way LDS bank conflict at HW = 64) -- and each lane then drops its
-    // sprites into its own row (the wave's LDS instructions execute in order).
-    uint4* img16 = reinterpret_cast<uint4*>(img);
-    const uint4* b4 = reinterpret_cast<const uint4*>(base);
-    const int cpe = HW >> 4;                                  // chunks per env
-    if ((cpe & (cpe - 1)) == 0 && cpe <= 64) {                // 64 % cpe == 0: a lane's chunks all hold the same table segment
-      const uint4 t = b4[lane & (cpe - 1)];
-      for (int k = 0; k < cpe; ++k) img16[lane + 64 * k] = t;
-    } else {
-      int seg = lane % cpe;
-      const int step = 64 % cpe;
-      for (int k = 0; k < cpe; ++k) {
-        img16[lane + 64 * k] = b4[seg];
-        seg += step; seg -= seg >= cpe ? cpe : 0;
-      }
     }
     uint8_t* rb = reinterpret_cast<uint8_t*>(img) + lane * HW;
 #pragma unroll
