@@ -61,7 +61,7 @@ struct sgw_engine {
   const double* rand_stream;
   int rand_n;
   unsigned long long rand_seed;
-  double* acc_dev;         // [n_pad/64][A*K+1] per-wave episodic-return accumulators (lazily allocated)
+  double* acc_dev;         // [n_pad/64 * SGW_ACC_PARTS][A*K+1] episodic-return accumulators, one row per 16 envs (lazily allocated)
   int rng_set;
   double* ftable_dev;      // sgw_set_family_table
   long long ftable_n;
@@ -324,7 +324,7 @@ int sgw_pow_f64(const double* x_dev, double y, double* out_dev, int64_t n, int d
 static int ensure_acc(sgw_engine* e, hipStream_t st) {
   if (e->acc_dev) return SGW_OK;
   HIP_TRY(hipSetDevice(e->device));
-  const size_t bytes = (size_t)(e->spec.A * e->spec.K + 1) * (size_t)(e->n_pad / WAVE) * 8;   // [waves][A*K+1]
+  const size_t bytes = (size_t)(e->spec.A * e->spec.K + 1) * (size_t)(e->n_pad / WAVE) * SGW_ACC_PARTS * 8;   // [waves * parts][A*K+1]
   HIP_TRY(hipMalloc((void**)&e->acc_dev, bytes));
   HIP_TRY(hipMemsetAsync(e->acc_dev, 0, bytes, st));
   return SGW_OK;
@@ -516,7 +516,7 @@ int sgw_read_returns(sgw_engine* e, double* out_dev, int clear, void* stream) {
   int rc = ensure_acc(e, (hipStream_t)stream);
   if (rc) return rc;
   hipLaunchKernelGGL(k_read_returns, dim3(e->spec.A * e->spec.K + 1), dim3(256), 0, (hipStream_t)stream, e->acc_dev,
-                     e->n_pad / WAVE, e->spec.A * e->spec.K + 1, out_dev, clear);
+                     e->n_pad / WAVE * SGW_ACC_PARTS, e->spec.A * e->spec.K + 1, out_dev, clear);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }

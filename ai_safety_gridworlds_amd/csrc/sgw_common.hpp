@@ -62,6 +62,7 @@ struct KArgs {
 
 // leading scalar kernel arguments of k_engine (preloaded into SGPRs at wave launch): what the prologue's loads need
 #define SGW_HOT_ARGS(a) (a).state, (a).tables, (a).actions, (a).n_pad, (a).n_envs, (a).sp.words
+#define SGW_ACC_PARTS 4          // accumulator rows per env-wave: one per 16 envs (sgw_kernels.hpp accumulate_returns)
 #define SGW_KARGS_OFFSET 48      // byte offset of the KArgs block in k_engine's kernarg segment: 5 x 8 + 4 (+4 padding)
 
 // In-kernel phase stamps: compiled in ONLY by the diagnostic probe (-DSGW_STAMPS); libsgw.so carries none.

@@ -177,11 +177,6 @@ __device__ inline void emit_drain(const KArgs& a, const Lds& l, long long env0, 
   }
 }
 
-// Episodic-return accumulators (end-of-batch all-reduce buffer).  Lanes whose episode just ended have staged their return
-// vector in l.vec_a (zeros otherwise); lanes 0..A*K then each sum one column over the wave in a FIXED order (deterministic,
-// no atomics) and add it to this wave's row.  Traffic: one 8-byte RMW per column per WAVE, not per env.
-// lane = part*16 + column: 4 partial sums of 16 rows each (reads batched), combined in a fixed tree; 16 columns per pass
-// (one pass for C <= 16: every single-agent family and firemaker; island_navigation_ex_ma has 2K + 1 = 17..25).
 // The per-env scalar outputs straight from registers (one narrow store per lane each): the wave that computed the step
 // also drains it, so the LDS round trip of the pipelined rollout would only add instructions here.
 template <class F>
@@ -254,6 +249,12 @@ __device__ inline void atomic_add_f64_noret(double* p, double v) {
   *p += v;
 #endif
 }
+// Episodic-return accumulators (end-of-batch all-reduce buffer).  Lanes whose episode just ended have staged their return
+// vector in l.vec_a (zeros otherwise).  lane = part * 16 + column: each lane sums one column over its part's 16 rows (reads
+// batched, a fixed add tree) and adds the sum to the part's own accumulator row -- four rows per env-wave, no exchange between
+// lanes; 16 columns per pass (one pass for C <= 16: every single-agent family and firemaker; island_navigation_ex_ma has
+// 2K + 1 = 17..25).  Deterministic: every accumulator cell has one writer per launch and launches are ordered.  Traffic: one
+// 8-byte RMW per column per 16 envs.
 __device__ inline void accumulate_returns(const KArgs& a, const Lds& l, long long wave_id, long long env0, int lane) {
   const int C = a.sp.A * a.sp.K + 1;
   const int part = lane >> 4;
@@ -265,12 +266,14 @@ __device__ inline void accumulate_returns(const KArgs& a, const Lds& l, long lon
       const int row = part * 16 + j;
       v[j] = (col < C && env0 + row < a.n_envs) ? l.vec_a[row * C + col] : 0.0;
     }
-    double p = 0.0;
+    // a fixed tree over the part's 16 rows (four add levels instead of a chain of sixteen); the four parts keep their own
+    // accumulator rows -- no cross-lane exchange -- and k_read_returns adds the rows up in a fixed order
 #pragma unroll
-    for (int j = 0; j < 16; ++j) p += v[j];
-    p += __shfl_xor(p, 16, WAVE);
-    p += __shfl_xor(p, 32, WAVE);
-    if (part == 0 && col < C) atomic_add_f64_noret(&a.ep_acc[wave_id * C + col], p);
+    for (int w = 8; w >= 1; w >>= 1) {
+#pragma unroll
+      for (int j = 0; j < w; ++j) v[j] += v[j + w];
+    }
+    if (col < C) atomic_add_f64_noret(&a.ep_acc[(wave_id * SGW_ACC_PARTS + part) * C + col], v[0]);
   }
 }
 

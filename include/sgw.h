@@ -212,7 +212,7 @@ int sgw_replay(sgw_engine* e, const int8_t* actions_dev, int T, int write_every,
 
 /* End-of-batch episodic returns: out_dev double [A*K + 1] = (sum over finished episodes of the
  * episode return vector, number of finished episodes), summed over this engine's envs in a fixed
- * order (deterministic, no atomics: per-wave accumulator rows summed in lane order + a tree reduction).  This is the
+ * order (deterministic: one accumulator row per 16 envs, each cell with a single adder per launch, + a tree reduction).  This is the
  * buffer a multi-GPU job all-reduces once per batch.  clear != 0 zeroes the accumulators after. */
 int sgw_read_returns(sgw_engine* e, double* out_dev, int clear, void* stream);
 
