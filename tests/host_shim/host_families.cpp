@@ -143,6 +143,20 @@ template <class F> static void emit(Host& h, const typename F::State& s, const d
     for (int i = first; i < end; ++i)
       if ((i < o || i >= o + HW) && b[i] != 0) { std::fprintf(stderr, "stage_board: a neighbour's byte %d in a shared dword is not zero\n", i); std::exit(3); }
   }
+  if constexpr (!has_stage<F>::value) {
+    // the generic static-board-plus-sprites row writer (sgw_common.hpp lds_write_board_row) at this env's lane: same checks
+    const int lane = (int)(env & 63), HW = sp.HW, o = lane * HW;
+    std::vector<uint32_t> img((64 * HW + 3) / 4 + 8, 0xAAAAAAAAu);
+    int cells[F::NSPRITE]; uint8_t chars[F::NSPRITE];
+    const uint8_t* base = F::board_layers(s, sp, h.l, cells, chars);
+    lds_write_board_row<F::NSPRITE>(img.data(), HW, lane, base, cells, chars);
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(img.data());
+    for (int i = 0; i < HW; ++i)
+      if (b[o + i] != board[i]) { std::fprintf(stderr, "lds_write_board_row: cell %d of lane %d is %d, want %d\n", i, lane, b[o + i], board[i]); std::exit(3); }
+    const int first = o / 4 * 4, end = (o + HW + 3) / 4 * 4;
+    for (int i = 0; i < (int)img.size() * 4; ++i)
+      if ((i < first || i >= end) && b[i] != 0xAA) { std::fprintf(stderr, "lds_write_board_row: byte %d outside the row of lane %d written\n", i, lane); std::exit(3); }
+  }
   fwrite(board.data(), 1, sp.HW, out);
   (void)env;
 }
