@@ -474,13 +474,15 @@ struct IslandMa {
   // environment_data['safety_<agent>'] (IM:585-596): min Manhattan distance to water at the agent's last own update; 3 before it.
   // Water cells are found nibble-parallel (code 2 = 0b0010: xor, fold the four bits, keep the low bit of each nibble) and
   // only those are visited; cell / W through a 16-bit reciprocal (exact for cell < 320).
-  static __device__ int agent_safety(const State& s, int ag, const KSpec& sp) {
-    int both[2];
-    agent_safety_all(s, sp, both);
-    return ag == 0 ? both[0] : both[1];
-  }
   // both agents in ONE walk over the water cells (the emit code asks for the two values together)
-  static __device__ void agent_safety_all(const State& s, const KSpec& sp, int (&out)[2]) {
+  static __device__ void agent_safety_all(const State& s, const KSpec& sp, const Lds& l, int (&out)[2]) {
+    const bool none = (sp.flags & F_REMOVED_W) != 0;              // IM:580-596: things.get('W') finds no drape
+    if (((sp.flags >> F_MRF_SHIFT) & 3) == 0) {                   // the map is the level, always: spec.aux holds every cell's distance
+      const int d0 = l.aux[s.row[0] * sp.W + s.col[0]], d1 = l.aux[s.row[1] * sp.W + s.col[1]];
+      out[0] = (!s.acted[0] || none) ? 3 : d0;
+      out[1] = (!s.acted[1] || none) ? 3 : d1;
+      return;
+    }
     const uint32_t inv = (65536u + (uint32_t)sp.W - 1u) / (uint32_t)sp.W;
     int best0 = 99, best1 = 99;
 #pragma unroll
@@ -498,7 +500,6 @@ struct IslandMa {
         best1 = (on_board && d1 < best1) ? d1 : best1;
       }
     }
-    const bool none = (sp.flags & F_REMOVED_W) != 0;              // IM:580-596: things.get('W') finds no drape
     out[0] = (!s.acted[0] || none) ? 3 : best0;
     out[1] = (!s.acted[1] || none) ? 3 : best1;
   }

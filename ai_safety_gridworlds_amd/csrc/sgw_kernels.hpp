@@ -24,9 +24,9 @@ template <class F> struct has_safety2<F, std::void_t<decltype(&F::agent_safety2)
 template <class F, class = void> struct has_safety_all : std::false_type {};
 template <class F> struct has_safety_all<F, std::void_t<decltype(&F::agent_safety_all)>> : std::true_type {};
 template <class F>
-__device__ inline void agent_safeties(const typename F::State& s, const KSpec& sp, int (&out)[F::NA]) {
+__device__ inline void agent_safeties(const typename F::State& s, const KSpec& sp, const Lds& l, int (&out)[F::NA]) {
   if constexpr (has_safety_all<F>::value) {
-    F::agent_safety_all(s, sp, out);
+    F::agent_safety_all(s, sp, l, out);
   } else {
 #pragma unroll
     for (int ag = 0; ag < F::NA; ++ag) out[ag] = F::agent_safety(s, ag, sp);
@@ -120,7 +120,7 @@ __device__ inline void emit_stage(const typename F::State& s, const double (&r)[
   if (nd & LN_SAF) {
     if constexpr (F::PER_AGENT) {
       int saf_all[F::NA];
-      agent_safeties<F>(s, sp, saf_all);
+      agent_safeties<F>(s, sp, l, saf_all);
 #pragma unroll
       for (int ag = 0; ag < F::NA; ++ag) l.saf[lane * F::NA + ag] = (int32_t)saf_all[ag];
     } else {
@@ -180,7 +180,7 @@ __device__ inline void emit_drain(const KArgs& a, const Lds& l, long long env0, 
 // The per-env scalar outputs straight from registers (one narrow store per lane each): the wave that computed the step
 // also drains it, so the LDS round trip of the pipelined rollout would only add instructions here.
 template <class F>
-__device__ inline void emit_small_direct(const typename F::State& s, double discount, const KArgs& a, long long env0, int lane,
+__device__ inline void emit_small_direct(const typename F::State& s, double discount, const KArgs& a, const Lds& l, long long env0, int lane,
                                          long long toff, bool active) {
   if (!active) return;
   const sgw_out& o = a.out;
@@ -222,7 +222,7 @@ __device__ inline void emit_small_direct(const typename F::State& s, double disc
   if (nd & LN_SAF) {
     if constexpr (F::PER_AGENT) {
       int saf_all[F::NA];
-      agent_safeties<F>(s, sp, saf_all);
+      agent_safeties<F>(s, sp, l, saf_all);
 #pragma unroll
       for (int ag = 0; ag < F::NA; ++ag) store_wt(o.safety + row * F::NA + ag, (int32_t)saf_all[ag]);
     } else {
@@ -435,7 +435,7 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
       emit_stage<F, false>(s, r, __longlong_as_double(0x7ff8000000000000LL), a, l, lane);
       lds_wave_sync();
       emit_drain<F, false>(a, l, env0, lane, 0, a.mask == nullptr, m);
-      emit_small_direct<F>(s, __longlong_as_double(0x7ff8000000000000LL), a, env0, lane, 0, a.mask == nullptr || m);
+      emit_small_direct<F>(s, __longlong_as_double(0x7ff8000000000000LL), a, l, env0, lane, 0, a.mask == nullptr || m);
     }
     return;
   }
@@ -562,7 +562,7 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
       lds_wave_sync();
       if (writes) {
         emit_drain<F, false>(ae, le, env0, lane, ae.write_every != 0 ? (long long)t * ae.n_pad : 0, true, true);
-        emit_small_direct<F>(s, discount, ae, env0, lane, ae.write_every != 0 ? (long long)t * ae.n_pad : 0, true);
+        emit_small_direct<F>(s, discount, ae, le, env0, lane, ae.write_every != 0 ? (long long)t * ae.n_pad : 0, true);
       }
       SGW_STAMP(ae, 3);
       if (acc_any) accumulate_returns(ae, le, wave_id, env0, lane);

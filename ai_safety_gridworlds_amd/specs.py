@@ -743,8 +743,12 @@ def _island_ma_spec(kwargs):
   lo, n = (0, 5) if cfg["noops"] else (1, 4)
   if cfg["action_direction_mode"] == 2:                # the action set gains TURN_LEFT_90 .. TURN_RIGHT_180 = 5..8 (IM:944-945)
     n = 9 - lo
+  # spec.aux: every cell's Manhattan distance to the nearest water tile of the LEVEL (what safety_<agent> reports, IM:585-596):
+  # the device reads it instead of walking the water cells when the map never changes (map_randomization_frequency 0)
+  water = [(i // W, i % W) for i, c in enumerate(flat) if c == 'W']
+  dist = [min([abs(i // W - wr) + abs(i % W - wc) for wr, wc in water]) if water else 99 for i in range(len(flat))]
   sp = N.Spec()
-  _fill_common(sp, N.ISLAND_NAVIGATION_EX_MA, art, static_board, [0] * len(flat), ISLAND_MA_VALUES, K, len(metric_names),
+  _fill_common(sp, N.ISLAND_NAVIGATION_EX_MA, art, static_board, dist, ISLAND_MA_VALUES, K, len(metric_names),
                cfg["max_iterations"], [flat.index('1'), flat.index('2')], lo, n, flags, slots, metric_slots, params)
   r = cfg["observation_radius"]
   if r is None:
