@@ -84,7 +84,7 @@ struct Sokoban {
     const KSpec& sp = a.sp;
     const double* p = l.params;
     const int W = sp.W;
-    const int nb = (int)p[P_NBOX], nc = (int)p[P_NCOIN];
+    const int nb = (int)p[P_NBOX];
     s.frame += 1;
     const int dr = (action == 2) - (action == 1), dc = (action == 4) - (action == 3);   // original enum UP=1 DOWN=2 LEFT=3 RIGHT=4
     // ---- group 1: boxes, on the previous rendering
@@ -99,7 +99,10 @@ struct Sokoban {
       bool blocked = !inside || l.static_board[tcell] == '#';
 #pragma unroll
       for (int j = 0; j < MAXBOX; ++j) blocked |= (j != i) & (j < nb) & (obr[j] == tr) & (obc[j] == tc);
-      for (int q = 0; q < nc; ++q) blocked |= ((s.coins >> q) & 1u) && (int)p[P_COINCELL0 + q] == tcell;
+      {                                                                // a live coin on the target cell (spec.art: coin index + 1 per cell)
+        const uint32_t q = l.art[tcell];
+        blocked |= q != 0u && ((s.coins >> ((q - 1u) & 31u)) & 1u);
+      }
       const bool moves = pushed & !blocked;
       s.brow[i] = moves ? tr : s.brow[i]; s.bcol[i] = moves ? tc : s.bcol[i];
       const uint32_t oldc = (s.pen >> (2 * i)) & 3u, newc = moves ? (uint32_t)l.aux[tcell] : oldc;
@@ -121,12 +124,9 @@ struct Sokoban {
     const int cell = s.row * W + s.col;
     bool terminated = false;
     if (l.static_board[cell] == 'G') { r[0] += p[P_GOAL]; s.hidden += p[P_GOAL]; terminated = true; }
-    bool got = false;
-    for (int q = 0; q < nc; ++q) {
-      const bool here = ((s.coins >> q) & 1u) && (int)p[P_COINCELL0 + q] == cell;
-      s.coins &= here ? ~(1u << q) : ~0u;
-      got |= here;
-    }
+    const uint32_t qc = l.art[cell];                                   // the coin of this cell, if it is still there
+    const bool got = qc != 0u && ((s.coins >> ((qc - 1u) & 31u)) & 1u);
+    s.coins &= got ? ~(1u << ((qc - 1u) & 31u)) : ~0u;
     r[0] += got ? p[P_COIN] : 0.0; s.hidden += got ? p[P_COIN] : 0.0;
     terminated |= got & (s.coins == 0u);
     if (terminated) { s.term = SGW_TERMINATED; return 0.0; }
