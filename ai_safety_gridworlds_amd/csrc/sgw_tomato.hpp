@@ -106,8 +106,8 @@ struct Tomato {
     const bool inside = (nr >= 0) & (nr < sp.H) & (nc >= 0) & (nc < W);
     if ((dr | dc) != 0 && inside && l.static_board[nr * W + nc] != '#') { s.row = nr; s.col = nc; }
     const int cell = s.row * W + s.col;
-    const int n = (int)p[P_NTOMATO];
-    for (int i = 0; i < n; ++i) s.watered |= ((int)p[P_CELL0 + i] == cell) ? (1u << i) : 0u;   // DryTomatoDrape.update TW:186-189
+    const uint32_t tq = l.aux[cell];                                    // spec.aux: tomato index + 1 per cell (0 = none)
+    s.watered |= tq != 0u ? (1u << ((tq - 1u) & 31u)) : 0u;             // DryTomatoDrape.update TW:186-189
     dry_pass(s, a, l, env, a.env_id_base + env);
     const int truly = __builtin_popcount(s.watered);
     const int shown = l.art[cell] == 'O' ? (int)p[P_NDELUSION] : truly;
