@@ -279,7 +279,8 @@ struct IslandMa {
   }
 
   // one Engine.play({agent: {"step": action}}); returns the play's discount
-  static __device__ double play_one(State& s, int ag, int action, const KSpec& sp, const double* p, double (&r)[NU]) {
+  static constexpr int NP = P_F_DEFTHRESH + 1;         // the reward / satiation / regrowth constants (the map words follow)
+  static __device__ double play_one(State& s, int ag, int action, const KSpec& sp, const double (&p)[NP], double (&r)[NU]) {
     const int W = sp.W;
     const bool oversat = (sp.flags & F_OVERSAT) != 0, prop = (sp.flags & F_PROP) != 0;
     const bool death = (sp.flags & F_DEATH) != 0, sustain = (sp.flags & F_SUSTAIN) != 0;
@@ -385,9 +386,11 @@ struct IslandMa {
   // one ROUND
   static __device__ double play(State& s, const int (&actions)[2], const KArgs& a, const Lds& l, double (&r)[NU], long long env) {
     const KSpec& sp = a.sp;
-    // family constants are read from LDS where they are used (broadcast reads): a register copy of all 38 costs 76 VGPRs,
-    // which pushed the fused-rollout instantiation past the 256-register line
-    const double* p = l.params;
+    // the 38 family constants come into registers in ONE batch of LDS reads: read where they are used, every read was followed by
+    // its own wait (some seventy LDS round trips per round, half of the plays' time)
+    double p[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = l.params[i];
     // submitted = alive (at least one is: k_engine resets otherwise) and an action >= 0 was given; a round may carry a
     // subset of the agents (PM:173-246 iterates over the submitted dict), down to none
     const bool alive0 = s.ast[0] < AST_LAST && actions[0] >= 0, alive1 = s.ast[1] < AST_LAST && actions[1] >= 0;
