@@ -95,9 +95,14 @@ struct Tile {
     const int ch = shown[cell];
     const int n = (int)p[P_NEVENTS];
     bool terminated = false;
-    for (int i = 0; i < n; ++i) {                                      // wave-uniform trip count
-      const double* ev = p + P_EV0 + 6 * i;
-      const bool hit = ch == (int)ev[E_CHR];
+    // the whole event table comes in one batch of LDS reads; a loop over the n events read (and waited for) five values per event
+    double evt[6 * MAX_EVENTS];
+#pragma unroll
+    for (int k = 0; k < 6 * MAX_EVENTS; ++k) evt[k] = p[P_EV0 + k];
+#pragma unroll
+    for (int i = 0; i < MAX_EVENTS; ++i) {                             // adds in event order, as the reference's drapes run
+      const double* ev = evt + 6 * i;
+      const bool hit = (i < n) & (ch == (int)ev[E_CHR]);
       r[0] += hit ? (s.variant ? ev[E_OBS1] : ev[E_OBS0]) : 0.0;
       s.hidden += hit ? ev[E_HID] : 0.0;
       terminated |= hit & (ev[E_TERM] != 0.0);
@@ -128,7 +133,11 @@ struct Tile {
     const int ch = base[cell];
     bool covered = false;                                              // a drape later in the z-order hides the sprite
     const int n = (int)l.params[P_NEVENTS];
-    for (int i = 0; i < n; ++i) covered |= (ch == (int)l.params[P_EV0 + 6 * i + E_CHR]) & (l.params[P_EV0 + 6 * i + E_COVERS] != 0.0);
+    double chr[MAX_EVENTS], cov[MAX_EVENTS];                           // read together, used together
+#pragma unroll
+    for (int i = 0; i < MAX_EVENTS; ++i) { chr[i] = l.params[P_EV0 + 6 * i + E_CHR]; cov[i] = l.params[P_EV0 + 6 * i + E_COVERS]; }
+#pragma unroll
+    for (int i = 0; i < MAX_EVENTS; ++i) covered |= (i < n) & (ch == (int)chr[i]) & (cov[i] != 0.0);
     cells[0] = cell; chars[0] = covered ? (uint8_t)ch : (uint8_t)'A';
     return base;
   }
