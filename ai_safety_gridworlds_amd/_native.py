@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsgw.so")
 
 MAX_CELLS, MAX_K, MAX_M, MAX_AGENTS, N_PARAMS, ENV_ALIGN = 320, 16, 32, 4, 72, 64
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ISLAND_NAVIGATION_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INTERRUPTIBILITY, FIREMAKER_EX_MA, ISLAND_NAVIGATION_EX_MA, TILE_EVENTS, SIDE_EFFECTS_SOKOBAN, CONVEYOR_BELT, TOMATO_WATERING, FRIEND_FOE, WHISKY_GOLD, ROCKS_DIAMONDS, AINTELOPE_SAVANNA = range(14)
 FIRST, MID, LAST, DEAD = 0, 1, 2, 3
@@ -26,7 +26,8 @@ class Spec(C.Structure):
       ("start_cell", C.c_int32 * MAX_AGENTS),
       ("action_lo", C.c_int32), ("n_actions", C.c_int32), ("flags", C.c_int32),
       ("view_radius", (C.c_int32 * 4) * MAX_AGENTS),
-      ("reserved", C.c_int32 * 3),
+      ("view_outside", C.c_int32),
+      ("reserved", C.c_int32 * 2),
       ("dim_slot", (C.c_int8 * MAX_K) * MAX_AGENTS),
       ("metric_slot", C.c_int8 * MAX_M),
       ("params", C.c_double * N_PARAMS),
@@ -38,7 +39,8 @@ class Spec(C.Structure):
 
 
 OUT_FIELDS = ("board", "obs_board", "reward", "cumulative", "step_type", "term_reason",
-              "actual_action", "discount", "hidden", "safety", "metrics", "frame", "agent_pos", "agent_flags", "safety2")
+              "actual_action", "discount", "hidden", "safety", "metrics", "frame", "agent_pos", "agent_flags", "safety2",
+              "views", "obs_views")
 
 
 class Out(C.Structure):

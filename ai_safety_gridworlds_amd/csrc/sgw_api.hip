@@ -70,6 +70,7 @@ struct sgw_engine {
   long long graph_tick;
   std::vector<StepGraph> graphs;
   hipStream_t capture_stream;
+  unsigned lds_cap_raised; // bit KIND: this engine's k_engine<F, KIND> may use more than 64 KiB of dynamic LDS (set once)
 };
 
 static void drop_graphs(sgw_engine* e) {      // any setter that changes what a launch's arguments hold invalidates the captures
@@ -175,7 +176,7 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   e->n_envs = n_envs;
   e->n_pad = (n_envs + SGW_ENV_ALIGN - 1) / SGW_ENV_ALIGN * SGW_ENV_ALIGN;
   e->env_id_base = env_id_base;
-  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0; e->rand_stream = nullptr; e->rand_n = 0; e->rand_seed = 0; e->acc_dev = nullptr; e->rng_set = 0; e->ftable_dev = nullptr; e->ftable_n = 0; e->capture_stream = nullptr; e->graph_tick = 0;
+  e->ep_bits = nullptr; e->ep_bits_n = 0; e->ep_seed = 0; e->rand_stream = nullptr; e->rand_n = 0; e->rand_seed = 0; e->acc_dev = nullptr; e->rng_set = 0; e->ftable_dev = nullptr; e->ftable_n = 0; e->capture_stream = nullptr; e->graph_tick = 0; e->lds_cap_raised = 0;
 
   KSpec& k = e->ks;
   memset(&k, 0, sizeof(k));
@@ -185,6 +186,7 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   k.action_lo = spec->action_lo; k.n_actions = spec->n_actions; k.words = words;
   memcpy(k.start_cell, spec->start_cell, sizeof(k.start_cell));
   kspec_derive(k);
+  kspec_views(k, *spec);
   memcpy(k.dim_slot, spec->dim_slot, sizeof(k.dim_slot));
   memcpy(k.metric_slot, spec->metric_slot, sizeof(k.metric_slot));
 
@@ -219,7 +221,12 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   }
   // the state / table initialisation above went through the null stream: finished before the caller can launch on any
   // (possibly non-blocking) stream of its own
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  err = hipStreamSynchronize(nullptr);
+  if (err != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "sgw_create: initialisation did not complete: %s", hipGetErrorString(err));
+    sgw_destroy(e); *out_engine = nullptr;
+    return SGW_ERR_HIP;
+  }
   return SGW_OK;
 }
 
@@ -356,8 +363,11 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
   do {                                                                                                 \
     constexpr int EW = env_waves<F, KIND>(), NB = lds_buffers<F, KIND>();                                    \
     const int need = lds_need(a, F::LDS_SCRATCH_M), pa = F::PER_AGENT ? F::NA : 1;                     \
-    a.lp = lds_plan(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need); a.need = need;                                        \
-    lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, F::LDS_EXTRA, EW, NB);      \
+    if ((need & (LN_VIEWS | LN_OBSVIEWS)) && (!has_views<F>::value || a.sp.view_total <= 0))           \
+      return fail(SGW_ERR_UNSUPPORTED, "launch: the views / obs_views outputs exist for families with agent windows only (firemaker_ex_ma)"); \
+    const int vb = a.sp.view_total > 0 ? a.sp.view_total : 0;                                          \
+    a.lp = lds_plan(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, vb); a.need = need;                     \
+    lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, vb, F::LDS_EXTRA, EW, NB);  \
     const dim3 grid((unsigned)((n_waves + EW - 1) / EW));                                              \
     const dim3 block(wg_threads<F, KIND>());                                                           \
     /* the bytes requested == the bytes the plan hands out (checked on every launch) */                \
@@ -365,8 +375,12 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
         (a.lp.wave_bytes & 15) != 0 || (a.lp.st & 15) != 0)                                            \
       return fail(SGW_ERR_ARG, "launch: LDS footprint mismatch between the launcher and the kernel's plan"); \
     if (lds_bytes > 160 * 1024) return fail(SGW_ERR_UNSUPPORTED, "launch: the requested outputs need more than 160 KiB of LDS per workgroup"); \
-    if (lds_bytes > 65536)   /* above the default dynamic-LDS cap */                                   \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+    /* above the default dynamic-LDS cap: raised ONCE per engine and kernel kind, to the CU's 160 KiB -- a launch that   \
+       needs it is then never the first inside a stream capture (sgw_step_n) */                                           \
+    if (lds_bytes > 65536 && !(e->lds_cap_raised & (1u << KIND))) {                                    \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      e->lds_cap_raised |= 1u << KIND;                                                                 \
+    }                                                                                                  \
     hipLaunchKernelGGL((k_engine<F, KIND>), grid, block, lds_bytes, st, SGW_HOT_ARGS(a), a);         \
   } while (0)
 #define SGW_LAUNCH(F)                                                                                  \
@@ -419,6 +433,11 @@ int sgw_step(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, void*
   return launch(e, a, (hipStream_t)stream);
 }
 
+static long long kspec_view_total(const sgw_spec& sp) {
+  long long off = 0;
+  for (int a = 0; a < sp.A; ++a) if (sp.view_radius[a][0] >= 0) off += (long long)(sp.view_radius[a][0] + sp.view_radius[a][1] + 1) * (sp.view_radius[a][2] + sp.view_radius[a][3] + 1);
+  return off;
+}
 static void offset_out(sgw_out& o, const sgw_spec& sp, long long n_pad, long long t) {
   const long long HW = sp.H * sp.W, AK = sp.A * sp.K, A = sp.A, M = sp.M, r = t * n_pad;
   const long long PA = (sp.family == SGW_ISLAND_NAVIGATION_EX_MA || sp.family == SGW_AINTELOPE_SAVANNA) ? A : 1;   // term_reason / safety are [N_pad, A] there (IslandMa::PER_AGENT)
@@ -437,6 +456,9 @@ static void offset_out(sgw_out& o, const sgw_spec& sp, long long n_pad, long lon
   if (o.frame) o.frame += r;
   if (o.agent_pos) o.agent_pos += r * A * 2;
   if (o.agent_flags) o.agent_flags += r * A;
+  const long long VB = kspec_view_total(sp);
+  if (o.views) o.views += r * VB;
+  if (o.obs_views) o.obs_views += r * VB;
 }
 
 static int step_n_launches(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out,
@@ -507,6 +529,7 @@ int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every,
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) { hit->exec = nullptr; return fail(SGW_ERR_HIP, "sgw_step_n: hipGraphInstantiate failed"); }
   }
+  HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipGraphLaunch(hit->exec, st));
   return SGW_OK;
 }

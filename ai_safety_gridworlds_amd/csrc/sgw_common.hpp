@@ -26,11 +26,16 @@ struct KSpec {
   int start_row[SGW_MAX_AGENTS], start_col[SGW_MAX_AGENTS];   // start_cell / W and % W (host-computed: no scalar division per launch)
   int8_t dim_slot[SGW_MAX_AGENTS][SGW_MAX_K];
   int8_t metric_slot[SGW_MAX_M];
+  // agent-centric windows (sgw_out.views): geometry of agent a's window (0 x 0 = none), its byte offset in the env's row of
+  // `view_total` bytes, reciprocals for the row / column split of a cell index (host-computed: no division on the device)
+  uint8_t view_up[SGW_MAX_AGENTS], view_left[SGW_MAX_AGENTS], view_h[SGW_MAX_AGENTS], view_w[SGW_MAX_AGENTS];
+  uint16_t view_off[SGW_MAX_AGENTS], view_recip[SGW_MAX_AGENTS];     // recip = ceil(65536 / view_w): (k * recip) >> 16 == k / view_w for k < 320
+  int view_total, view_pad, view_prefill, recip_W;                   // pad character; any window larger than the board; ceil(65536 / W)
 };
 
 // byte offsets of one env-wave staging buffer's regions, computed ONCE per launch on the host (lds_plan) and read from the
 // kernarg segment where needed: deriving them on the device cost a ~30-instruction scalar chain per region with spilled terms
-struct LdsPlan { int wave_bytes, vec_r, vec_c, vec_m, vec_a, trash, flag, ain, st, tr, act, pos, flg, disc, hid, saf, frm; };
+struct LdsPlan { int wave_bytes, vec_r, vec_c, vec_m, vec_a, trash, flag, ain, st, tr, act, pos, flg, disc, hid, saf, frm, views; };
 
 struct KArgs {
   KSpec sp;
@@ -106,6 +111,25 @@ __device__ unsigned long long g_phase_last[4096];
 __host__ __device__ inline void kspec_derive(KSpec& k) {
   for (int ag = 0; ag < SGW_MAX_AGENTS; ++ag) { k.start_row[ag] = k.W > 0 ? k.start_cell[ag] / k.W : 0; k.start_col[ag] = k.W > 0 ? k.start_cell[ag] % k.W : 0; }
 }
+// window geometry from the spec's radii (up, down, left, right; < 0 = the agent has no window)
+__host__ inline void kspec_views(KSpec& k, const sgw_spec& sp) {
+  int off = 0;
+  k.view_prefill = 0;
+  for (int ag = 0; ag < SGW_MAX_AGENTS; ++ag) {
+    const int32_t* rad = sp.view_radius[ag];
+    k.view_off[ag] = (uint16_t)off; k.view_up[ag] = k.view_left[ag] = k.view_h[ag] = k.view_w[ag] = 0; k.view_recip[ag] = 0;
+    if (ag >= sp.A || rad[0] < 0) continue;
+    const int vh = rad[0] + rad[1] + 1, vw = rad[2] + rad[3] + 1;
+    if (vh > 255 || vw > 255 || off + vh * vw > 65535) { k.view_total = -1; return; }     // refused by the launcher when `views` is asked for
+    k.view_up[ag] = (uint8_t)rad[0]; k.view_left[ag] = (uint8_t)rad[2]; k.view_h[ag] = (uint8_t)vh; k.view_w[ag] = (uint8_t)vw;
+    k.view_recip[ag] = (uint16_t)((65536 + vw - 1) / vw);
+    if (vh * vw > sp.H * sp.W) k.view_prefill = 1;
+    off += vh * vw;
+  }
+  k.view_total = off;
+  k.view_pad = sp.view_outside ? sp.view_outside : '#';
+  k.recip_W = (65536 + sp.W - 1) / sp.W;
+}
 
 enum { MODE_STEP = 0, MODE_RESET = 1 };
 enum { ST_FIRST = 0, ST_MID = 1, ST_LAST = 2, ST_NONE = 3 };   // ST_NONE: never reset yet
@@ -131,6 +155,7 @@ struct Lds {
   int8_t* act;                       // actual_action [64][A]
   double *disc, *hid;                // discount [64], hidden [64]
   int32_t *saf, *frm;                // safety [64][PA], frame [64]
+  uint8_t* views;          // 64 * view_total bytes: the wave's 64 rows of agent windows, contiguous as in global memory
   double* vec_a;           // 64*(A*K+1) doubles: finished-episode returns staged for the per-wave sum
   uint32_t* flag;          // [4] per-step words handed from the computing wave to the draining wave (pipelined rollout)
   int8_t* ain;             // [A][64] synthetic actions handed from the draining wave to the computing wave (pipelined rollout)
@@ -142,15 +167,17 @@ __host__ __device__ inline size_t lds_board_bytes(int HW) { return ((size_t)64 *
 // KArgs): the LDS footprint of a wave decides how many waves a CU keeps resident when a launch has more than one per SIMD.
 enum { LN_REWARD = 1, LN_CUMULATIVE = 2, LN_METRICS = 4, LN_RETURNS = 8, LN_ST = 16, LN_TR = 32, LN_ACT = 64, LN_POS = 128,
        LN_FLG = 256, LN_DISC = 512, LN_HID = 1024, LN_SAF = 2048, LN_FRM = 4096, LN_BOARD = 8192, LN_OBS = 16384,
-       LN_SAF2 = 32768 };   // safety2: written straight from registers (emit_small_direct), no staging region
+       LN_SAF2 = 32768,     // safety2: written straight from registers (emit_small_direct), no staging region
+       LN_VIEWS = 65536, LN_OBSVIEWS = 131072 };   // agent windows (u8 / value-mapped f32): one LDS image serves both
 __host__ __device__ inline int lds_need(const KArgs& a, bool family_scratch_m) {
   const sgw_out& o = a.out;
   return (o.reward ? LN_REWARD : 0) | (o.cumulative ? LN_CUMULATIVE : 0) | ((o.metrics || family_scratch_m) ? LN_METRICS : 0) |
          (a.ep_acc ? LN_RETURNS : 0) | (o.step_type ? LN_ST : 0) | (o.term_reason ? LN_TR : 0) | (o.actual_action ? LN_ACT : 0) |
          (o.agent_pos ? LN_POS : 0) | (o.agent_flags ? LN_FLG : 0) | (o.discount ? LN_DISC : 0) | (o.hidden ? LN_HID : 0) |
          (o.safety ? LN_SAF : 0) | (o.frame ? LN_FRM : 0) | (o.board ? LN_BOARD : 0) | (o.obs_board ? LN_OBS : 0) |
-         (o.safety2 ? LN_SAF2 : 0);
+         (o.safety2 ? LN_SAF2 : 0) | (o.views ? LN_VIEWS : 0) | (o.obs_views ? LN_OBSVIEWS : 0);
 }
+__host__ __device__ inline size_t lds_view_bytes(int vb, int need) { return (need & (LN_VIEWS | LN_OBSVIEWS)) ? ((size_t)64 * vb + 15) / 16 * 16 : 0; }
 __host__ __device__ inline size_t lds_rows(int A, int K, int M, int need, int which) {
   const int ak = A * K > 0 ? A * K : 1;
   switch (which) {
@@ -176,18 +203,18 @@ __host__ __device__ inline size_t lds_small_bytes(int A, int pa, int need, int w
   }
 }
 // one staging buffer of one env-wave
-__host__ __device__ inline size_t lds_wave_bytes(int HW, int A, int K, int M, int pa, int need) {
+__host__ __device__ inline size_t lds_wave_bytes(int HW, int A, int K, int M, int pa, int need, int vb) {
   const size_t rows = lds_rows(A, K, M, need, LN_REWARD) + lds_rows(A, K, M, need, LN_CUMULATIVE) +
                       lds_rows(A, K, M, need, LN_METRICS) + lds_rows(A, K, M, need, LN_RETURNS) + 1;   // + trash
   size_t small = 16 + (size_t)(64 * A + 15) / 16 * 16;                  // flag words + the synthetic-action inbox (pipelined rollout)
   for (int w = LN_ST; w <= LN_FRM; w <<= 1) small += lds_small_bytes(A, pa, need, w);
-  return lds_board_bytes(HW) + rows * 64 * 8 + small;
+  return lds_board_bytes(HW) + rows * 64 * 8 + small + lds_view_bytes(vb, need);
 }
-__host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M, int pa, int need, int extra, int env_waves, int buffers) {
-  return TABLE_BYTES + (size_t)extra + (size_t)env_waves * buffers * lds_wave_bytes(HW, A, K, M, pa, need);
+__host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M, int pa, int need, int vb, int extra, int env_waves, int buffers) {
+  return TABLE_BYTES + (size_t)extra + (size_t)env_waves * buffers * lds_wave_bytes(HW, A, K, M, pa, need, vb);
 }
 
-__host__ __device__ inline LdsPlan lds_plan(int HW, int A, int K, int M, int pa, int need) {
+__host__ __device__ inline LdsPlan lds_plan(int HW, int A, int K, int M, int pa, int need, int vb) {
   LdsPlan p;
   int o = (int)lds_board_bytes(HW);
   p.vec_r = o; o += 512 * (int)lds_rows(A, K, M, need, LN_REWARD);
@@ -206,6 +233,7 @@ __host__ __device__ inline LdsPlan lds_plan(int HW, int A, int K, int M, int pa,
   p.hid = o; o += (int)lds_small_bytes(A, pa, need, LN_HID);
   p.saf = o; o += (int)lds_small_bytes(A, pa, need, LN_SAF);
   p.frm = o; o += (int)lds_small_bytes(A, pa, need, LN_FRM);
+  p.views = o; o += (int)lds_view_bytes(vb, need);
   p.wave_bytes = o;
   return p;
 }
@@ -230,6 +258,7 @@ __host__ __device__ inline Lds lds_carve(uint8_t* smem, const LdsPlan& p, int ex
   l.st = w + p.st; l.tr = w + p.tr; l.act = reinterpret_cast<int8_t*>(w + p.act); l.pos = w + p.pos; l.flg = w + p.flg;
   l.disc = reinterpret_cast<double*>(w + p.disc); l.hid = reinterpret_cast<double*>(w + p.hid);
   l.saf = reinterpret_cast<int32_t*>(w + p.saf); l.frm = reinterpret_cast<int32_t*>(w + p.frm);
+  l.views = w + p.views;
   return l;
 }
 

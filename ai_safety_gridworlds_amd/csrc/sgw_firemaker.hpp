@@ -69,6 +69,7 @@ struct Firemaker {
   static constexpr int NSPRITE = 3;
   static constexpr bool CUSTOM_BOARD = true;
   static constexpr bool PER_AGENT = false;
+  static constexpr bool VIEWS = true;       // sgw_out.views: the agent windows leave with the round's launch
   static __device__ int slot(const KSpec& sp, int u) { return sp.dim_slot[0][u]; }
   static constexpr bool LDS_SCRATCH_M = false;
   static constexpr int W = 17, H = 17, CELLS = 289;
@@ -753,6 +754,56 @@ struct Firemaker {
 #pragma unroll
     for (int ag = 0; ag < 3; ++ag)
       if (present(sp, ag)) rb[s.row[ag] * W + s.col[ag]] = (uint8_t)(ag == 0 ? '1' : (ag == 1 ? '2' : 'S'));
+  }
+  // The same rows written by the WORKGROUP: every wave holds the same 64 envs, so wave w writes a slice of the 73 image dwords
+  // of every lane's row (the funnel's running dword and the shifted fire word are re-derived at the slice's start).  Dwords 0
+  // and 72 -- the two a row can share with its neighbours' rows (zeroed, then OR-ed) -- belong to ONE wave, so their zero /
+  // OR order is that wave's program order; an agent's sprite byte is stored by the wave that wrote the dword under it.
+  template <int LO, int HI>
+  static __device__ __forceinline__ void stage_board_range(uint32_t* row, const uint32_t* table, const M5& fire, int q) {
+    const uint32_t* st = table - (q != 0 ? 1 : 0);
+    uint32_t lo = LO == 0 ? (q != 0 ? 0u : table[0]) : st[LO];
+    constexpr int wi = LO >> 4;
+    const uint64_t cur = wi == 0 ? fire.a : (wi == 1 ? fire.b : (wi == 2 ? fire.c : (wi == 3 ? fire.d : fire.e)));
+    const uint64_t below = wi == 0 ? 0ull : (wi == 1 ? fire.a : (wi == 2 ? fire.b : (wi == 3 ? fire.c : fire.d)));
+    uint64_t pw = (cur << q) | ((below >> 1) >> (63 - q));
+    stage_board_from<LO>(row, st, lo, pw, fire, q, std::make_integer_sequence<int, HI - LO>{});
+  }
+  template <int LO, int... J>
+  static __device__ __forceinline__ void stage_board_from(uint32_t* row, const uint32_t* st, uint32_t& lo, uint64_t& pw, const M5& fire, int q,
+                                                          std::integer_sequence<int, J...>) {
+    (stage_board_dword<LO + J>(row, st, lo, pw, fire, q), ...);
+  }
+  template <int LO, int HI>
+  static __device__ __forceinline__ void stage_sprites_range(uint8_t* rb, const State& s, const KSpec& sp, int q) {
+#pragma unroll
+    for (int ag = 0; ag < 3; ++ag) {
+      const int cell = s.row[ag] * W + s.col[ag], i = (q + cell) >> 2;
+      if (present(sp, ag) && i >= LO && i < HI) rb[cell] = (uint8_t)(ag == 0 ? '1' : (ag == 1 ? '2' : 'S'));
+    }
+  }
+  static __device__ __forceinline__ void stage_board_part(const Lds& l, const State& s, const KSpec& sp, int lane, int w) {
+    static_assert(CELLS == 289 && WAVES == 8, "73 image dwords per row, dealt to 8 waves");
+    const int o = lane * CELLS, q = o & 3;
+    uint32_t* row = l.board + (o >> 2);
+    uint8_t* rb = reinterpret_cast<uint8_t*>(l.board) + o;
+    const uint32_t* table = reinterpret_cast<const uint32_t*>(l.static_board);
+#define FM_PART(LO, HI) do { stage_board_range<LO, HI>(row, table, s.fire, q); stage_sprites_range<LO, HI>(rb, s, sp, q); } while (0)
+    switch (w) {                                               // scalar
+      case 0:
+        if (q != 0) row[0] = 0u;
+        if (q != 3) row[72] = 0u;
+        FM_PART(0, 8); FM_PART(72, 73);
+        break;
+      case 1: FM_PART(8, 17); break;
+      case 2: FM_PART(17, 26); break;
+      case 3: FM_PART(26, 35); break;
+      case 4: FM_PART(35, 44); break;
+      case 5: FM_PART(44, 53); break;
+      case 6: FM_PART(53, 62); break;
+      default: FM_PART(62, 72); break;
+    }
+#undef FM_PART
   }
   static __device__ const uint8_t* board_layers(const State&, const KSpec&, const Lds& l, int (&)[3], uint8_t (&)[3]) {
     return l.static_board;

@@ -7,6 +7,7 @@
 //                                                                    safety_game_mo.py:971-1066
 #pragma once
 
+#include <cstddef>
 #include <type_traits>
 
 #include "sgw_common.hpp"
@@ -53,14 +54,14 @@ template <class F> constexpr int per_agent_cols(const KSpec& sp) { return F::PER
 
 // Every requested output of one step is written into the wave's staging buffer in the byte order of the env-major global
 // arrays (the wave's 64 rows are contiguous there).  `finished` / `real`: the returns staging of the accumulators.
-template <class F, bool SMALL = true>
+template <class F, bool SMALL = true, bool BOARD = true>
 __device__ inline void emit_stage(const typename F::State& s, const double (&r)[F::NU], double discount, const KArgs& a,
                                   const Lds& l, int lane) {
   const sgw_out& o = a.out;
   const KSpec& sp = a.sp;
   const int nd = a.need;
   const int HW = sp.HW, K = sp.A * sp.K, M = sp.M;   // reward rows hold all agents' vectors: [A][K]
-  if (nd & (LN_BOARD | LN_OBS)) {
+  if (BOARD && (nd & (LN_BOARD | LN_OBS | LN_VIEWS | LN_OBSVIEWS))) {
     if constexpr (has_board_stage<F>::value) {            // boards with dynamic content: the family writes its row itself
       F::stage_board(l, s, sp, lane);
     } else {
@@ -133,7 +134,7 @@ __device__ inline void emit_stage(const typename F::State& s, const double (&r)[
 
 // The wave streams its 64 contiguous rows of every requested output from LDS, 16 B per lane per instruction, no waits in
 // between.  coop == false (masked reset): each ACTIVE lane copies only its own rows.
-template <class F, bool SMALL = true>
+template <class F, bool SMALL = true, bool BOARD = true>
 __device__ inline void emit_drain(const KArgs& a, const Lds& l, long long env0, int lane, long long toff, bool coop,
                                   bool lane_active) {
   const sgw_out& o = a.out;
@@ -146,8 +147,8 @@ __device__ inline void emit_drain(const KArgs& a, const Lds& l, long long env0, 
     if (coop) coop_store(dst, env0, (int)row_bytes, src, lane);
     else if (lane_active) lane_store(dst, env, (int)row_bytes, src, lane);
   };
-  if (nd & LN_BOARD) rows(o.board, HW, l.board);
-  if (nd & LN_OBS) {                                     // value_mapping LUT (rendering.py:491-549)
+  if (BOARD && (nd & LN_BOARD)) rows(o.board, HW, l.board);
+  if (BOARD && (nd & LN_OBS)) {                          // value_mapping LUT (rendering.py:491-549)
     float* dst = o.obs_board + (toff + env0) * HW;
     const uint8_t* img = reinterpret_cast<const uint8_t*>(l.board);
     if (coop) {
@@ -238,6 +239,236 @@ __device__ inline void emit_small_direct(const typename F::State& s, double disc
   if (nd & LN_FRM) store_wt(o.frame + row, s.frame);
 }
 
+// workgroup barrier that orders LDS only: __syncthreads() also drains the wave's global stores (s_waitcnt vmcnt(0)),
+// which is exactly what the draining wave of the pipelined rollout must not wait for
+__device__ inline void lds_workgroup_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---- agent-centric windows inside the step launch (sgw_out.views / obs_views; get_agent_perspective, safety_game_moma.py:1996-2101) ----
+// The wave's 64 rendered board rows are in LDS already (emit_stage); the windows are assembled next to them in an LDS image laid
+// out exactly like the wave's 64 rows of the [N, view_total] output and leave as plain 16-byte-per-lane stores: no second
+// launch, no re-read of the board from HBM, no byte-granular global stores.
+template <class F, class = void> struct has_views : std::false_type {};
+template <class F> struct has_views<F, std::void_t<decltype(F::VIEWS)>> : std::integral_constant<bool, F::VIEWS> {};
+template <class F, class = void> struct has_view_dir : std::false_type {};
+template <class F> struct has_view_dir<F, std::void_t<decltype(&F::view_dir)>> : std::true_type {};
+
+// rot90 by the agent's observation direction (Directions LEFT=0 RIGHT=1 UP=2 DOWN=3): first crop, then rotate
+// (safety_game_moma.py:2085-2096).  (vr, vc) of the OUTPUT -> (row, col) of the crop; square windows only.
+__device__ inline void view_unrotate(int dir, int n, int& vr, int& vc) {
+  const int r = vr, c = vc;
+  if (dir == 3) { vr = n - 1 - r; vc = n - 1 - c; }          // DOWN: rot90 k=2
+  else if (dir == 0) { vr = n - 1 - c; vc = r; }             // LEFT: rot90 k=-1 (clockwise)
+  else if (dir == 1) { vr = c; vc = n - 1 - r; }             // RIGHT: rot90 k=1 (counter-clockwise)
+}
+// the inverse: (cr, cc) of the crop -> (vr, vc) of the output
+__device__ inline void view_rotate(int dir, int n, int& cr, int& cc) {
+  const int r = cr, c = cc;
+  if (dir == 3) { cr = n - 1 - r; cc = n - 1 - c; }
+  else if (dir == 0) { cr = c; cc = n - 1 - r; }
+  else if (dir == 1) { cr = n - 1 - c; cc = r; }
+}
+
+// ONE wave assembles the windows of envs [e_lo, e_hi) of its env-wave, an env at a time with all 64 lanes.  Everything that
+// does not depend on the env is worked out once per agent, outside the env loop:
+//   * a window no larger than the board is gathered (a lane per output byte): the lane's window coordinates are constants,
+//     an env adds its agent's position (v_readlane of lane e's registers -> scalars);
+//   * a window LARGER than the board (firemaker's supervisor: 33 x 33 around 17 x 17) is mostly padding: the block is filled
+//     with the pad byte first and the BOARD's cells are dropped where they land.  The landing offset of board cell (r, c) is
+//     (r - pr) * n + (c - pc) unrotated and, rot90-ed by the observation direction, one of +-(r * n + c), +-(c * n - r) plus a
+//     term that only depends on the env -- so a lane keeps two constants per cell and an env costs one scalar and one add
+//     per cell.  When the window covers the board wherever the agent stands (radius >= board size - 1: the reference's
+//     `None` radius) no cell can fall outside and the bounds test is skipped.
+template <class F>
+__device__ inline void views_stage_wave_per_env(const typename F::State& s, const KSpec& sp, const Lds& l, int e_lo, int e_hi, int lane) {
+  const int VB = sp.view_total, HW = sp.HW, W = sp.W, H = sp.H;
+  const uint32_t pad = (uint32_t)sp.view_pad & 0xffu;
+  uint8_t* img = l.views;
+  const uint8_t* boards = reinterpret_cast<const uint8_t*>(l.board);
+  if (sp.view_prefill) {                                     // (e_hi - e_lo) * VB is a multiple of 8 for blocks of 8 envs
+    const uint64_t p8 = 0x0101010101010101ull * pad;
+    uint64_t* blk = reinterpret_cast<uint64_t*>(img + e_lo * VB);
+    const int n8 = ((e_hi - e_lo) * VB) >> 3;
+    for (int i = lane; i < n8; i += WAVE) blk[i] = p8;
+  }
+  lds_wave_sync();
+#pragma unroll
+  for (int ag = 0; ag < F::NA; ++ag) {
+    const int vh = sp.view_h[ag], vw = sp.view_w[ag], len = vh * vw;
+    if (len == 0) continue;                                  // scalar: an agent without a window (absent firemaker agents)
+    int prow, pcol, pdir = 2;
+    F::agent_pos(s, ag, prow, pcol);
+    if constexpr (has_view_dir<F>::value) pdir = F::view_dir(s, ag);
+    const int up = sp.view_up[ag], left = sp.view_left[ag], off = sp.view_off[ag];
+    if (len > HW) {
+      // board cells k = lane + 64 j, j < 5 (H * W <= 320): row / column and the two rotation constants, once
+      constexpr int NP = (SGW_MAX_CELLS + WAVE - 1) / WAVE;
+      int rr[NP], cc[NP], P[NP], Q[NP];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int k = lane + WAVE * j;
+        rr[j] = (k * sp.recip_W) >> 16; cc[j] = k - rr[j] * W;
+        P[j] = rr[j] * vw + cc[j]; Q[j] = cc[j] * vw - rr[j];
+      }
+      const bool covers = up >= H - 1 && vh - 1 - up >= H - 1 && left >= W - 1 && vw - 1 - left >= W - 1;
+      const int npass = (HW + WAVE - 1) / WAVE;
+      for (int e = e_lo; e < e_hi; ++e) {
+        const int pr = __builtin_amdgcn_readlane(prow, e) - up, pc = __builtin_amdgcn_readlane(pcol, e) - left;
+        const int dir = has_view_dir<F>::value ? __builtin_amdgcn_readlane(pdir, e) : 2;
+        // at = sgn * (rotated ? Q : P) + base   (scalars per env)
+        const int n1 = vw - 1;
+        const int base = dir == 2 ? -(pr * vw + pc) : (dir == 3 ? (n1 + pr) * vw + n1 + pc : (dir == 0 ? n1 + pr - pc * vw : (n1 + pc) * vw - pr));
+        const bool useQ = dir < 2, neg = dir == 3 || dir == 1;
+        const uint8_t* src = boards + e * HW;
+        uint8_t* dst = img + e * VB + off + base;
+        uint8_t val[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) if (j < npass) val[j] = src[lane + WAVE * j < HW ? lane + WAVE * j : 0];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          if (j < npass) {
+            const int t = useQ ? Q[j] : P[j];
+            const int at = neg ? -t : t;
+            bool ok = lane + WAVE * j < HW;
+            if (!covers) { const int cr = rr[j] - pr, c2 = cc[j] - pc; ok = ok && cr >= 0 && cr < vh && c2 >= 0 && c2 < vw; }
+            if (ok) dst[at] = val[j];
+          }
+        }
+      }
+    } else {
+      // output bytes k = lane + 64 j of the window: the lane's window coordinates, once
+      constexpr int NP = (SGW_MAX_CELLS + WAVE - 1) / WAVE;
+      const int npass = (len + WAVE - 1) / WAVE;
+      int wr[NP], wc[NP];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) { const int k = lane + WAVE * j; wr[j] = (k * (int)sp.view_recip[ag]) >> 16; wc[j] = k - wr[j] * vw; }
+      for (int e = e_lo; e < e_hi; ++e) {
+        const int pr = __builtin_amdgcn_readlane(prow, e) - up, pc = __builtin_amdgcn_readlane(pcol, e) - left;
+        const int dir = has_view_dir<F>::value ? __builtin_amdgcn_readlane(pdir, e) : 2;
+        const uint8_t* src = boards + e * HW;
+        uint8_t* dst = img + e * VB + off;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          if (j < npass) {
+            int vr = wr[j], vc = wc[j];
+            view_unrotate(dir, vw, vr, vc);                   // dir is a scalar: uniform branches
+            const int r = vr + pr, c = vc + pc;
+            const bool inside = r >= 0 && r < H && c >= 0 && c < W;
+            const uint32_t got = src[inside ? r * W + c : 0];
+            if (lane + WAVE * j < len) dst[lane + WAVE * j] = (uint8_t)(inside ? got : pad);
+          }
+        }
+      }
+    }
+  }
+}
+
+// LDS view image -> global: `nthr` threads (thread `tid` of them) copy the env-wave's 64 contiguous rows, 16 bytes per lane and
+// instruction; the float variant maps four window bytes to four floats per store (value_mapping LUT, rendering.py:491-549)
+__device__ inline void views_drain(const KArgs& a, const Lds& l, long long env0, long long toff, int tid, int nthr) {
+  const int VB = a.sp.view_total;
+  if (a.need & LN_VIEWS) {
+    uint4* g = reinterpret_cast<uint4*>(a.out.views + (toff + env0) * VB);
+    const uint4* src = reinterpret_cast<const uint4*>(l.views);
+    const int n = 4 * VB;
+    int j = tid;
+    for (; j + 3 * nthr < n; j += 4 * nthr) {                // four LDS reads in flight, then the four stores
+      const uint4 v0 = src[j], v1 = src[j + nthr], v2 = src[j + 2 * nthr], v3 = src[j + 3 * nthr];
+      store16_wt(g + j, v0); store16_wt(g + j + nthr, v1); store16_wt(g + j + 2 * nthr, v2); store16_wt(g + j + 3 * nthr, v3);
+    }
+    for (; j < n; j += nthr) store16_wt(g + j, src[j]);
+  }
+  if (a.need & LN_OBSVIEWS) {
+    uint4* g = reinterpret_cast<uint4*>(a.out.obs_views + (toff + env0) * VB);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(l.views);
+    const int n = 16 * VB;
+    for (int j = tid; j < n; j += nthr) {
+      const uint32_t q = src[j];
+      const float f0 = l.value_map[q & 0x7f], f1 = l.value_map[(q >> 8) & 0x7f], f2 = l.value_map[(q >> 16) & 0x7f], f3 = l.value_map[(q >> 24) & 0x7f];
+      store16_wt(g + j, make_uint4(__float_as_uint(f0), __float_as_uint(f1), __float_as_uint(f2), __float_as_uint(f3)));
+    }
+  }
+}
+// masked reset: only the rows of the envs that were reset, a wave per env (slow path)
+__device__ inline void views_drain_env(const KArgs& a, const Lds& l, long long env0, int e, int lane) {
+  const int VB = a.sp.view_total;
+  const uint8_t* src = l.views + e * VB;
+  if (a.need & LN_VIEWS) { uint8_t* g = a.out.views + (env0 + e) * VB; for (int k = lane; k < VB; k += WAVE) g[k] = src[k]; }
+  if (a.need & LN_OBSVIEWS) { float* g = a.out.obs_views + (env0 + e) * VB; for (int k = lane; k < VB; k += WAVE) g[k] = l.value_map[src[k] & 0x7f]; }
+}
+
+// families whose workgroup's waves write the board rows together (cooperative families: every wave holds the same envs)
+template <class F, class = void> struct has_board_part : std::false_type {};
+template <class F> struct has_board_part<F, std::void_t<decltype(&F::stage_board_part)>> : std::true_type {};
+// the env-wave's 64 board rows (and their value-mapped float twins) LDS -> global by `nthr` threads
+__device__ inline void board_drain_wg(const KArgs& a, const Lds& l, long long env0, long long toff, int tid, int nthr) {
+  const int HW = a.sp.HW;
+  if (a.need & LN_BOARD) {
+    uint4* g = reinterpret_cast<uint4*>(a.out.board + (toff + env0) * HW);
+    const uint4* src = reinterpret_cast<const uint4*>(l.board);
+    const int n = 4 * HW;
+    int j = tid;
+    for (; j + nthr < n; j += 2 * nthr) {
+      const uint4 v0 = src[j], v1 = src[j + nthr];
+      store16_wt(g + j, v0); store16_wt(g + j + nthr, v1);
+    }
+    if (j < n) store16_wt(g + j, src[j]);
+  }
+  if (a.need & LN_OBS) {
+    uint4* g = reinterpret_cast<uint4*>(a.out.obs_board + (toff + env0) * HW);
+    const int n = 16 * HW;
+    for (int j = tid; j < n; j += nthr) {
+      const uint32_t q = l.board[j];
+      const float f0 = l.value_map[q & 0x7f], f1 = l.value_map[(q >> 8) & 0x7f], f2 = l.value_map[(q >> 16) & 0x7f], f3 = l.value_map[(q >> 24) & 0x7f];
+      store16_wt(g + j, make_uint4(__float_as_uint(f0), __float_as_uint(f1), __float_as_uint(f2), __float_as_uint(f3)));
+    }
+  }
+}
+
+// The windows of one step, after the board rows are staged: cooperative families split the env-wave's 64 envs over the
+// workgroup's F::WAVES waves (every wave holds the same state; two workgroup barriers: the leader's board rows are visible,
+// the image is complete), the others do it within the wave.  `mask_on`: masked reset -- only the rows of the envs whose lane
+// has `lane_active` are written.
+template <class F, bool BOARD_DRAIN = false>
+__device__ inline void views_phase(const typename F::State& s, const KArgs& a_in, uint8_t* smem, int slot, long long env0, int lane, long long t,
+                                   bool mask_on, bool lane_active) {
+  // the phase reads its arguments (window geometry, output pointers, LDS plan) from the kernarg segment itself, through a
+  // pointer the compiler cannot see through: nothing of it is held in SGPRs across the rules
+  KArgs a_seg;
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    typedef const KArgs __attribute__((address_space(4))) * KArgsSeg;
+    KArgsSeg seg = (KArgsSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + SGW_KARGS_OFFSET);
+    asm volatile("" : "+s"(seg) : : "memory");
+    a_seg = *seg;
+  }
+  const KArgs& a = a_seg;
+#else
+  const KArgs& a = a_in;
+#endif
+  const Lds l = lds_carve(smem, a.lp, F::LDS_EXTRA, slot);
+  const long long toff = a.write_every != 0 ? t * a.n_pad : 0;
+  constexpr int NW = F::WAVES, EPW = WAVE / NW;
+  static_assert(NW == 1 || (EPW % 8) == 0, "a wave's block of the view image must be 8-byte aligned");
+  const int w = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  if constexpr (NW > 1) lds_workgroup_barrier(); else lds_wave_sync();
+  // BOARD_DRAIN: the board rows also leave by the whole workgroup (their stores are in flight while the windows are assembled)
+  if constexpr (BOARD_DRAIN) board_drain_wg(a, l, env0, toff, (int)threadIdx.x, NW * WAVE);
+  if (!(a.need & (LN_VIEWS | LN_OBSVIEWS))) return;
+  views_stage_wave_per_env<F>(s, a.sp, l, w * EPW, (w + 1) * EPW, lane);
+  if (!mask_on) {
+    if constexpr (NW > 1) lds_workgroup_barrier(); else lds_wave_sync();
+    views_drain(a, l, env0, toff, NW > 1 ? (int)threadIdx.x : lane, NW * WAVE);
+  } else {
+    lds_wave_sync();
+    const unsigned long long on = __ballot(lane_active);
+    for (int e = w * EPW; e < (w + 1) * EPW; ++e) if ((on >> e) & 1ull) views_drain_env(a, l, env0, e, lane);
+  }
+}
+
 // The wave's accumulator row is updated with no-return f64 atomic adds executed at the memory side: nothing is loaded, so
 // the wave never waits for the row (a load + store pair put a memory round trip on the critical path, and its pending
 // load made the compiler drain vmcnt in the middle of the output staging).  Only this wave touches the row and it does so
@@ -275,14 +506,6 @@ __device__ inline void accumulate_returns(const KArgs& a, const Lds& l, long lon
     }
     if (col < C) atomic_add_f64_noret(&a.ep_acc[(wave_id * SGW_ACC_PARTS + part) * C + col], v[0]);
   }
-}
-
-// workgroup barrier that orders LDS only: __syncthreads() also drains the wave's global stores (s_waitcnt vmcnt(0)),
-// which is exactly what the draining wave of the pipelined rollout must not wait for
-__device__ inline void lds_workgroup_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // KIND: K_STEP = exactly one step (sgw_step / sgw_step_n), K_ROLLOUT = a.T fused steps, K_RESET = sgw_reset.
@@ -433,6 +656,11 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
     if (leader) {
       lds_wave_sync();
       emit_stage<F, false>(s, r, __longlong_as_double(0x7ff8000000000000LL), a, l, lane);
+    }
+    if constexpr (has_views<F>::value) {
+      if (a.need & (LN_VIEWS | LN_OBSVIEWS)) views_phase<F>(s, a, smem, wv * NB, env0, lane, 0, a.mask != nullptr, m);
+    }
+    if (leader) {
       lds_wave_sync();
       emit_drain<F, false>(a, l, env0, lane, 0, a.mask == nullptr, m);
       emit_small_direct<F>(s, __longlong_as_double(0x7ff8000000000000LL), a, l, env0, lane, 0, a.mask == nullptr || m);
@@ -552,7 +780,20 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
         }
         if constexpr (PIPE) { if (lane == 0) le.flag[0] = acc_any ? 1u : 0u; }
       }
-      if (writes) emit_stage<F, PIPE>(s, r, discount, ae, le, lane);
+      if (writes) emit_stage<F, PIPE, !has_board_part<F>::value>(s, r, discount, ae, le, lane);
+    }
+    if constexpr (has_board_part<F>::value) {
+      // cooperative family: the WORKGROUP produces the step's big outputs -- every wave writes a slice of the board rows, then
+      // (one barrier) a share of the board's and (a second barrier) of the windows' stores; the leader keeps the rest
+      static_assert(!PIPE && has_views<F>::value && F::COOPERATIVE, "");
+      if (writes && (ae.need & (LN_BOARD | LN_OBS | LN_VIEWS | LN_OBSVIEWS))) {
+        F::stage_board_part(le, s, ae.sp, lane, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
+        views_phase<F, true>(s, ae, smem, wv * NB, env0, lane, t, false, true);
+      }
+    } else if constexpr (has_views<F>::value) {
+      static_assert(!PIPE, "the pipelined rollout has no window phase (the families with agent views do not pipeline)");
+      if (writes && (ae.need & (LN_VIEWS | LN_OBSVIEWS)))
+        views_phase<F>(s, ae, smem, wv * NB, env0, lane, t, false, true);
     }
     // ... and leave it: the pair's draining wave takes the buffer over at the barrier (pipelined rollout), or this wave
     // copies it out itself
@@ -561,7 +802,7 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
     } else if (leader) {
       lds_wave_sync();
       if (writes) {
-        emit_drain<F, false>(ae, le, env0, lane, ae.write_every != 0 ? (long long)t * ae.n_pad : 0, true, true);
+        emit_drain<F, false, !has_board_part<F>::value>(ae, le, env0, lane, ae.write_every != 0 ? (long long)t * ae.n_pad : 0, true, true);
         emit_small_direct<F>(s, discount, ae, le, env0, lane, ae.write_every != 0 ? (long long)t * ae.n_pad : 0, true);
       }
       SGW_STAMP(ae, 3);
@@ -574,6 +815,11 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
   SGW_STAMP(a, 5);
   SGW_STAMP_RT(a, 7);
 }
+
+// SGW_KARGS_OFFSET (where the fused rollout / the re-reading step kernels find the KArgs block in the kernarg segment) is tied
+// to k_engine's parameter list: a struct with the same members in the same order has the same layout as the segment
+struct EngineKernargMirror { uint64_t* hot_state; const uint8_t* hot_tables; const int8_t* hot_actions; long long hot_n_pad, hot_n_envs; int hot_words; KArgs a_in; };
+static_assert(offsetof(EngineKernargMirror, a_in) == SGW_KARGS_OFFSET, "SGW_KARGS_OFFSET does not match k_engine's leading arguments (SGW_HOT_ARGS)");
 
 // synthetic action stream materialised in HBM: int8 [T, N, A]
 __global__ void k_fill_actions(int8_t* out, long long n, int A, int T, unsigned long long seed, long long step0,
@@ -734,14 +980,7 @@ __global__ void k_observe_layers(const uint8_t* board, long long n, int HW, int 
 
 // agent-centric windows of the rendered board (safety_game_moma.py:1996-2101), one thread per output byte
 struct ViewSpec { int A, H, W, total; int off[SGW_MAX_AGENTS], up[SGW_MAX_AGENTS], left[SGW_MAX_AGENTS], vh[SGW_MAX_AGENTS], vw[SGW_MAX_AGENTS]; };
-// rot90 by the agent's observation direction (Directions LEFT=0 RIGHT=1 UP=2 DOWN=3 in bits 3-4 of agent_flags): first crop,
-// then rotate (safety_game_moma.py:2085-2096).  (vr, vc) of the OUTPUT -> (row, col) of the crop; square windows only.
-__device__ inline void view_unrotate(int dir, int n, int& vr, int& vc) {
-  const int r = vr, c = vc;
-  if (dir == 3) { vr = n - 1 - r; vc = n - 1 - c; }          // DOWN: rot90 k=2
-  else if (dir == 0) { vr = n - 1 - c; vc = r; }             // LEFT: rot90 k=-1 (clockwise)
-  else if (dir == 1) { vr = c; vc = n - 1 - r; }             // RIGHT: rot90 k=1 (counter-clockwise)
-}
+// (view_unrotate: above, with the in-kernel windows)
 // One WAVE produces one agent's window of one env.  The lanes cover whole window rows (64 / vw rows per pass, one byte per lane) and
 // read contiguous board cells (a board row, or a column when the window is rotated); the window is assembled in LDS at the same
 // 16-byte phase as its place in the output and leaves as 16-byte stores (head and tail bytes singly): window bytes are not
@@ -831,6 +1070,7 @@ __global__ void k_agent_views(const uint8_t* board, const uint8_t* pos, const ui
   for (long long wv = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wv < windows; wv += stride) {
     const long long e = wv / v.A;
     const int ag = (int)(wv - e * v.A);
+    if (v.vh[ag] * v.vw[ag] == 0) continue;                      // an agent without a window (absent firemaker agents)
     const int pr = (int)pos[wv * 2] - v.up[ag], pc = (int)pos[wv * 2 + 1] - v.left[ag];
     const int dir = flags ? (flags[wv] >> 3) & 3 : 2;
     view_wave(board + e * (long long)(v.H * v.W), views + e * v.total + v.off[ag], lds, v.H, v.W, v.vh[ag], v.vw[ag], pr, pc, dir,
@@ -889,6 +1129,7 @@ __global__ void k_agent_layer_views(const uint8_t* layers, const uint8_t* pos, c
     const int li = (int)(wv - ea * L);
     const long long e = ea / v.A;
     const int ag = (int)(ea - e * v.A);
+    if (v.vh[ag] * v.vw[ag] == 0) continue;
     const int pr = (int)pos[ea * 2] - v.up[ag], pc = (int)pos[ea * 2 + 1] - v.left[ag];
     const int dir = flags ? (flags[ea] >> 3) & 3 : 2;
     const int cells = v.vh[ag] * v.vw[ag];

@@ -16,7 +16,12 @@ import torch
 from . import _native as N
 
 DEFAULT_OUTPUTS = ("board", "reward", "step_type", "term_reason")
-ALL_OUTPUTS = tuple(f for f in N.OUT_FIELDS if f != "safety2")      # every family's outputs; "safety2": aintelope_savanna only
+# every family's outputs; "safety2": aintelope_savanna only; "views" / "obs_views": the families with agent windows
+ALL_OUTPUTS = tuple(f for f in N.OUT_FIELDS if f not in ("safety2", "views", "obs_views"))
+
+
+# families whose step launch can write the agent windows itself (sgw_out.views / obs_views)
+FUSED_VIEW_FAMILIES = (N.FIREMAKER_EX_MA,)
 
 
 def _dtype_shape(spec, name):
@@ -30,7 +35,13 @@ def _dtype_shape(spec, name):
       "hidden": (torch.float64, ()), "safety": (torch.int32, per_agent),
       "metrics": (torch.float64, (M,)), "frame": (torch.int32, ()), "agent_pos": (torch.uint8, (A * 2,)),
       "agent_flags": (torch.uint8, (A,)), "safety2": (torch.int32, per_agent),
+      "views": (torch.uint8, (_view_bytes(spec),)), "obs_views": (torch.float32, (_view_bytes(spec),)),
   }[name]
+
+
+def _view_bytes(spec):
+  """Bytes of one env's row of agent windows (sgw_view_bytes): the windows of the agents that have one, concatenated."""
+  return int(sum(h * w for (h, w) in (getattr(spec, "view_shapes", None) or ())))
 
 
 class BatchedEngine(object):
@@ -246,6 +257,14 @@ class BatchedEngine(object):
     out, off = [], 0
     for (h, w) in self.spec.view_shapes:
       out.append(views[:, off:off + h * w].reshape(self.n_envs, h, w))
+      off += h * w
+    return out
+
+  def split_views(self, views):
+    """[..., view_bytes] tensor (the `views` / `obs_views` output) -> list over agents of [..., h_a, w_a] views of it."""
+    out, off = [], 0
+    for (h, w) in self.spec.view_shapes:
+      out.append(views[..., off:off + h * w].reshape(views.shape[:-1] + (h, w)))
       off += h * w
     return out
 

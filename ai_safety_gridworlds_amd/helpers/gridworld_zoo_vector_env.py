@@ -18,14 +18,17 @@ helpers/gridworld_zoo_parallel_env.py:429-615) returns for it:
                      "info_observation_layers_cube" uint8 [N, L, H, W] (shared) and "info_agent_observation_layers_cube"
                      uint8 [N, L, h_a, w_a], both in `layers_order` = the sorted layer characters
 A finished env auto-resets at its next round exactly like the reference adapter (the round's actions are discarded); agents of
-the per-agent families that are already LAST/DEAD can be given -1 ("not in the dict").  One round = ONE kernel launch for the
-step (shuffled sequential plays, fire spread, rewards, auto-reset) + one for the agent windows.
+the per-agent families that are already LAST/DEAD can be given -1 ("not in the dict").  One round = ONE kernel launch: the
+step (shuffled sequential plays, fire spread, rewards, auto-reset) writes the agent windows too (sgw_out.views / obs_views;
+families without the in-kernel windows take a second launch, sgw_agent_views).
 """
 import numpy as np
 import torch
 
 from .. import _native as N
+from ..engine import FUSED_VIEW_FAMILIES
 from ..environments import BatchedSafetyEnvironment
+from ..specs import make_spec
 
 OUTS = ("board", "reward", "cumulative", "step_type", "term_reason", "discount", "metrics", "agent_pos", "agent_flags")
 
@@ -35,7 +38,10 @@ class GridworldZooVectorEnv(object):
 
   def __init__(self, env_name, num_envs, ascii_observation_format=True, layers_in_observation=False, seed=None, device="cuda:0",
                env_id_base=0, **kwargs):
-    self._env = BatchedSafetyEnvironment(env_name, num_envs=num_envs, device=device, env_id_base=env_id_base, outputs=OUTS,
+    self._fused = make_spec(env_name, **kwargs).family in FUSED_VIEW_FAMILIES
+    self._ascii = bool(ascii_observation_format)
+    outs = OUTS + ((("views",) if self._ascii else ("obs_views",)) if self._fused else ())
+    self._env = BatchedSafetyEnvironment(env_name, num_envs=num_envs, device=device, env_id_base=env_id_base, outputs=outs,
                                          track_performance=False, **kwargs)
     sp = self.spec_ = self._env.spec
     if sp.A < 2 and not getattr(sp, "per_agent", False):
@@ -47,7 +53,6 @@ class GridworldZooVectorEnv(object):
     self.possible_agents = ["agent_%s" % c for c in sp.agent_chars]
     self.agent_name_mapping = dict(zip(self.possible_agents, sp.agent_chars))
     self._k = {a: len(sp.agent_dim_names[c]) for a, c in self.agent_name_mapping.items()}
-    self._ascii = bool(ascii_observation_format)
     self._layers = bool(layers_in_observation)
     self.layers_order = list(sp.layer_chars)                   # get_layers_order(...) of the reference: sorted layer keys
     self._vm = torch.tensor([sp.native.value_map[i] for i in range(128)], dtype=torch.float32, device=self.device)
@@ -84,9 +89,12 @@ class GridworldZooVectorEnv(object):
     eng = self._env.engine
     if getattr(self, "_packed_for", None) is not o.get("reward"):       # first call, or the engine reallocated its outputs
       self._packed_for = o.get("reward")
-      vb = int(eng._lib.sgw_view_bytes(eng._h))
-      self._view_buf = torch.empty((n, vb), dtype=torch.uint8, device=self.device)
-      views = eng.agent_views(out=self._view_buf)
+      if self._fused:                                              # the step launch wrote the windows (ascii or value-mapped)
+        views = eng.split_views(o["views" if self._ascii else "obs_views"])
+      else:
+        vb = int(eng._lib.sgw_view_bytes(eng._h))
+        self._view_buf = torch.empty((n, vb), dtype=torch.uint8, device=self.device)
+        views = eng.agent_views(out=self._view_buf)
       st = o["step_type"].reshape(n, -1)
       self._st = st
       self._done = torch.empty_like(st, dtype=torch.bool)
@@ -109,7 +117,7 @@ class GridworldZooVectorEnv(object):
                     "observation_direction": self._odir[:, q] if self._turning else self._up,
                     "action_direction": self._adir[:, q] if self._turning else self._up}
       self._cached = (obs, rewards, terms, truncs, infos)
-    else:
+    elif not self._fused:
       eng.agent_views(out=self._view_buf)
     torch.ge(self._st, N.LAST, out=self._done)
     if self._turning:
@@ -117,7 +125,7 @@ class GridworldZooVectorEnv(object):
       torch.bitwise_right_shift(self._flags, 1, out=self._adir).bitwise_and_(3)
     obs, rewards, terms, truncs, infos = self._cached
     obs, infos = dict(obs), {a: dict(d) for a, d in infos.items()}
-    if not self._ascii:
+    if not self._ascii and not self._fused:
       obs = {a: self._vm[v.long()] for a, v in obs.items()}
     if self._layers:                                            # two more launches, tensors stay on the device
       cube = eng.observe_layers()

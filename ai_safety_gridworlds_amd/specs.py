@@ -582,6 +582,7 @@ def _firemaker_spec(kwargs):
   for ag in range(N.MAX_AGENTS):
     for j in range(4):
       sp.view_radius[ag][j] = views[ag][j] if ag < 3 and slots[ag] in agents else -1
+  sp.view_outside = ord('#')
   static_layers = {'-': [1 if t else 0 for t in territory]}   # (a sprite-less character is a backdrop layer: layer_static finds it in the art)
   return GameSpec(name="firemaker_ex_ma", family=N.FIREMAKER_EX_MA, native=sp, art=art, H=H, W=W, K=3,
                   dim_names=["ENERGY", "WORKSHOP", ""], agent_dim_names=names,
@@ -763,6 +764,7 @@ def _island_ma_spec(kwargs):
   for ag in range(N.MAX_AGENTS):
     for j in range(4):
       sp.view_radius[ag][j] = rad[j] if ag < 2 else -1
+  sp.view_outside = ord('W')
   return GameSpec(name="island_navigation_ex_ma", family=N.ISLAND_NAVIGATION_EX_MA, native=sp, art=art, H=H, W=W, K=K,
                   dim_names=dim_names, agent_dim_names={'1': dim_names, '2': dim_names}, M=len(metric_names),
                   metric_names=metric_names, A=2, action_lo=lo, n_actions=n, value_mapping=ISLAND_MA_VALUES,
@@ -1043,6 +1045,7 @@ def _savanna_spec(kwargs):
   for ag in range(N.MAX_AGENTS):
     for j in range(4):
       sp.view_radius[ag][j] = rad[j] if ag < 2 else -1
+  sp.view_outside = ord('#')
   agents = ['0', '1'][:A]
   return GameSpec(name="aintelope_savanna", family=N.AINTELOPE_SAVANNA, native=sp, art=art, H=H, W=W, K=K,
                   dim_names=dim_names, agent_dim_names={c: dim_names for c in agents}, M=len(labels),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SGW_ABI_VERSION 6
+#define SGW_ABI_VERSION 7
 #define SGW_MAX_CELLS 320      /* >= 17*17 */
 #define SGW_MAX_K 16           /* reward dimensions per agent */
 #define SGW_MAX_M 32           /* metrics per env */
@@ -78,7 +78,8 @@ typedef struct sgw_spec {
   int32_t action_lo, n_actions;         /* action range, used by the synthetic rollout */
   int32_t flags;
   int32_t view_radius[SGW_MAX_AGENTS][4]; /* agent-centric view: tiles visible up, down, left, right (-1 = no view) */
-  int32_t reserved[3];
+  int32_t view_outside;                 /* what_lies_outside: the character of window cells beyond the board (0 = '#') */
+  int32_t reserved[2];
   int8_t dim_slot[SGW_MAX_AGENTS][SGW_MAX_K]; /* reward-universe dim -> output column, -1 = not enabled */
   int8_t metric_slot[SGW_MAX_M];              /* family metric id -> output column, -1 = absent */
   double params[SGW_N_PARAMS];
@@ -111,6 +112,16 @@ typedef struct sgw_out {
   int32_t* safety2;      /* [N_pad, A]    environment_data['safety2_<agent>'] (aintelope_savanna.py:619-620, 837-844: Manhattan
                           *               distance to the nearest predator, 99 = none, 3 before the agent's first update);
                           *               aintelope_savanna only, SGW_ERR_UNSUPPORTED elsewhere */
+  uint8_t* views;        /* [N_pad, view_bytes] the agent-centric windows of the rendered board (get_agent_perspective,
+                          *               safety_game_moma.py:1996-2101) produced INSIDE the step launch from the board rows the
+                          *               kernel already holds in LDS: same layout and contents as sgw_agent_views (agent a's window
+                          *               at byte offset sum of the previous agents' window sizes, rot90-ed by the observation
+                          *               direction where the env has one, cells outside the board = spec.view_outside).  What the
+                          *               Zoo wrapper hands to the agents as `obs` (gridworld_zoo_parallel_env.py:541-554): one launch
+                          *               per round instead of step + sgw_agent_views.  Families with agent views only
+                          *               (firemaker_ex_ma, island_navigation_ex_ma, aintelope_savanna), SGW_ERR_UNSUPPORTED elsewhere */
+  float* obs_views;      /* [N_pad, view_bytes] the same windows value-mapped to float32 (ascii_observation_format=False:
+                          *               the window of observation['board'], observation_distiller_ex.py:147-187) */
 } sgw_out;
 
 typedef struct sgw_engine sgw_engine;

@@ -97,9 +97,9 @@ template <class F> static void setup(Host& h, const uint64_t* rng) {
   if (h.nr) { h.a.rand_stream = h.stream.data(); h.a.rand_n = h.nr; }
   // LDS image: the level tables, 64 board rows, and the family's extra region (island: the pow tables)
   const size_t extra = F::LDS_EXTRA;
-  h.lds.assign(lds_total_bytes(k.HW, k.A, k.K, k.M, 1, 0, (int)extra, 1, 1) + 64, 0);
+  h.lds.assign(lds_total_bytes(k.HW, k.A, k.K, k.M, 1, 0, 0, (int)extra, 1, 1) + 64, 0);
   std::memcpy(h.lds.data(), h.tables.data(), TABLE_BYTES);
-  h.a.lp = lds_plan(k.HW, k.A, k.K, k.M, 1, 0);
+  h.a.lp = lds_plan(k.HW, k.A, k.K, k.M, 1, 0, 0);
   h.l = lds_carve(h.lds.data(), h.a.lp, (int)extra, 0);
   if (extra) { for (int t = 0; t < wg_threads_host<F>(); ++t) { threadIdx.x = t; typename F::Ctx cx; if constexpr (has_issue<F>::value) F::init_issue(cx); F::init_ctx(cx, h.l); if constexpr (has_args<F>::value) F::init_args(cx, h.l, h.a); } }
 }

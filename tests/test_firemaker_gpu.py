@@ -12,7 +12,7 @@ from tests import golden_util as G
 pytestmark = pytest.mark.gpu
 
 OUTS = ("board", "reward", "cumulative", "step_type", "term_reason", "discount", "metrics", "frame", "agent_pos",
-        "safety", "obs_board", "agent_flags")
+        "safety", "obs_board", "agent_flags", "views", "obs_views")
 
 
 def run(spec, actions, rng_states):
@@ -32,7 +32,15 @@ def run(spec, actions, rng_states):
     grab(eng.step(acts[t]))
   torch.cuda.synchronize()
   out = {k: torch.stack(v, dim=1).cpu().numpy() for k, v in rec.items()}
+  # the windows written by the step launch itself (sgw_out.views / obs_views) == the separate window kernel's, and the float
+  # windows are the value-mapped ascii ones
+  fused = [w.cpu().numpy() for w in eng.split_views(torch.stack(rec["views"], dim=1))]
+  fused_f = [w.cpu().numpy() for w in eng.split_views(torch.stack(rec["obs_views"], dim=1))]
+  vm = np.array([spec.native.value_map[i] for i in range(128)], np.float32)
   out["views"] = [torch.stack(v, dim=1).cpu().numpy() for v in views]
+  for i in range(3):
+    assert np.array_equal(fused[i], out["views"][i]), "in-kernel window of agent %d differs from sgw_agent_views" % i
+    assert np.array_equal(fused_f[i], vm[fused[i]]), "float window of agent %d" % i
   st = eng.get_state()[:, :E].cpu().numpy().view(np.uint64)
   out["rng_final"] = np.stack([st[3], st[4], st[5], st[6]], axis=1)
   out["rng_has32_final"] = (st[0] >> np.uint64(27)) & np.uint64(1)
@@ -112,17 +120,17 @@ def test_firemaker_needs_rng_and_rollout_matches_steps():
   from ai_safety_gridworlds_amd import _native as N
   spec = make_spec("firemaker_ex_ma", amount_agents=3, max_iterations=90)
   n, T, seed = 640, 48, 3
-  a = BatchedEngine(spec, n, outputs=("board", "reward", "step_type"))
+  a = BatchedEngine(spec, n, outputs=("board", "reward", "step_type", "views"))
   with pytest.raises(N.SgwError, match="sgw_set_rng_state"):
     a.reset()
-  b = BatchedEngine(spec, n, outputs=("board", "reward", "step_type"))
+  b = BatchedEngine(spec, n, outputs=("board", "reward", "step_type", "views"))
   a.set_rng_seeds(np.arange(n) + 11); b.set_rng_seeds(np.arange(n) + 11)
   a.reset(); b.reset()
   acts = a.fill_actions(T, seed)
   assert acts.shape == (T, n, 3)
   ref = philox.actions(seed, np.arange(n), np.arange(T), 0, 5, agent=2)
   assert np.array_equal(acts[..., 2].cpu().numpy(), ref)
-  per = {k: [] for k in ("board", "reward", "step_type")}
+  per = {k: [] for k in ("board", "reward", "step_type", "views")}
   for t in range(T):
     o = a.step(acts[t])
     for k in per:
@@ -156,3 +164,31 @@ def test_firemaker_layers_and_agent_layer_cubes_match_fixture():
   G.assert_same("worker1", cubes[0].cpu().numpy().astype(bool), fx["agent_layers_worker"][:, :, 0].reshape(nl * S, 9, 5, 5))
   G.assert_same("worker2", cubes[1].cpu().numpy().astype(bool), fx["agent_layers_worker"][:, :, 1].reshape(nl * S, 9, 5, 5))
   G.assert_same("supervisor", cubes[2].cpu().numpy().astype(bool), fx["agent_layers_supervisor"].reshape(nl * S, 9, 33, 33))
+
+
+def test_firemaker_views_of_a_masked_reset_and_of_step_n():
+  """sgw_out.views under a masked reset (only the reset envs' rows change) and through sgw_step_n with write_every (the
+  [T, N_pad, view_bytes] time slices), against the separate window kernel on the same boards."""
+  spec = make_spec("firemaker_ex_ma", amount_agents=3, max_iterations=40)
+  n, T = 200, 24                                                    # ragged: the last env-wave is partly padding
+  eng = BatchedEngine(spec, n, outputs=("board", "agent_pos", "step_type", "views"))
+  eng.set_rng_seeds(np.arange(n) + 5)
+  eng.reset()
+  acts = eng.fill_actions(T, 9)
+  o = eng.step_n(acts, write_every=True)
+  boards, pos, views = o["board"].clone(), o["agent_pos"].clone(), o["views"].clone()
+  for t in range(T):
+    want = eng.agent_views(board=boards[t].contiguous(), agent_pos=pos[t].contiguous())
+    got = eng.split_views(views[t])
+    for i in range(3):
+      assert torch.equal(got[i], want[i]), (t, i)
+  before = eng.step(acts[0])["views"].clone()
+  mask = (torch.arange(n, device="cuda:0") % 3 == 0).to(torch.uint8)
+  o = eng.reset(mask)
+  want = eng.agent_views()
+  got = eng.split_views(o["views"])
+  m = mask.bool()
+  for i in range(3):
+    assert torch.equal(got[i][m], want[i][m]), i
+  assert torch.equal(o["views"][~m], before[~m])                    # the other envs' rows were left alone
+  eng.close()

@@ -61,8 +61,8 @@ int main(int argc, char** argv) {
   if (omask & 16) a.out.safety = d_safety;
   if (omask & 32) a.out.frame = d_frame;
   a.sgw_stamps = d_stamps;
-  a.lp = lds_plan(HW, 1, K, 9, 1, lds_need(a, false)); a.need = lds_need(a, false);
-  const size_t lds = lds_total_bytes(HW, 1, K, 9, 1, lds_need(a, false), Fam::LDS_EXTRA, EW, 1) + (argc > 2 ? atoll(argv[2]) : 0);
+  a.lp = lds_plan(HW, 1, K, 9, 1, lds_need(a, false), 0); a.need = lds_need(a, false);
+  const size_t lds = lds_total_bytes(HW, 1, K, 9, 1, lds_need(a, false), 0, Fam::LDS_EXTRA, EW, 1) + (argc > 2 ? atoll(argv[2]) : 0);
   printf("n %lld, %d env-waves per workgroup, dynamic LDS %zu bytes per workgroup\n", n, EW, lds);
   std::vector<unsigned long long> h((size_t)NW * 8);
   std::vector<double> starts, ends;
