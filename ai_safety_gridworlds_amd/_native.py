@@ -93,6 +93,10 @@ def lib():
   L.sgw_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Out), C.c_int, C.c_void_p]
   L.sgw_rollout.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_int, C.POINTER(Out),
                             C.c_int, C.c_void_p]
+  L.sgw_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+  L.sgw_group_destroy.argtypes = [C.c_void_p]
+  L.sgw_group_step_n.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(Out), C.c_int, C.c_void_p]
+  L.sgw_group_rollout.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_int, C.POINTER(Out), C.c_int, C.c_void_p]
   L.sgw_read_returns.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
   L.sgw_fill_actions.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]
   L.sgw_accumulate_returns.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -120,7 +124,7 @@ def lib():
 EXPORTS = [
     "sgw_abi_version", "sgw_last_error", "sgw_sizeof_spec", "sgw_sizeof_out", "sgw_create",
     "sgw_destroy", "sgw_n_envs", "sgw_n_pad", "sgw_state_bytes", "sgw_set_episode_bits",
-    "sgw_set_rng_state", "sgw_set_random_stream", "sgw_set_family_table", "sgw_pow_f64", "sgw_pow_selfcheck", "sgw_reset", "sgw_step", "sgw_step_n", "sgw_rollout", "sgw_replay", "sgw_read_returns", "sgw_fill_actions",
+    "sgw_set_rng_state", "sgw_set_random_stream", "sgw_set_family_table", "sgw_pow_f64", "sgw_pow_selfcheck", "sgw_reset", "sgw_step", "sgw_step_n", "sgw_rollout", "sgw_replay", "sgw_group_create", "sgw_group_destroy", "sgw_group_step_n", "sgw_group_rollout", "sgw_read_returns", "sgw_fill_actions",
     "sgw_accumulate_returns", "sgw_observe", "sgw_derived_stats", "sgw_observe_layers", "sgw_state_layers", "sgw_view_bytes", "sgw_agent_views", "sgw_agent_layer_views", "sgw_state_words", "sgw_get_state", "sgw_set_state"]
 
 

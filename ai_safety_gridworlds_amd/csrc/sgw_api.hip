@@ -23,6 +23,7 @@
 #include "sgw_tile.hpp"
 #include "sgw_tomato.hpp"
 #include "sgw_whisky.hpp"
+#include "sgw_group.hpp"
 
 using namespace sgw;
 
@@ -337,7 +338,40 @@ static int ensure_acc(sgw_engine* e, hipStream_t st) {
   return SGW_OK;
 }
 
-static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
+}  // extern "C"
+
+// ---- launch planning: the same validation and LDS / grid arithmetic for a family's own launch and for a group member ------
+template <class F> struct FamilyType { using type = F; };
+// fn(FamilyType<F>{}, tag) for the family (and state variant) this engine runs
+template <class Fn> static int with_family(const sgw_engine* e, Fn&& fn) {
+  switch (e->spec.family) {
+    case SGW_ISLAND_NAVIGATION_EX:
+      if (e->spec.flags & Island::F_GENERAL) return fn(FamilyType<IslandGeneral>{}, (int)TAG_ISLAND_GENERAL);
+      if (e->ks.flags & Island::F_PACKED) return fn(FamilyType<IslandPacked>{}, (int)TAG_ISLAND_PACKED);
+      return fn(FamilyType<Island>{}, (int)TAG_ISLAND);
+    case SGW_BOAT_RACE_EX:
+    case SGW_BOAT_RACE: return fn(FamilyType<Boat>{}, (int)TAG_BOAT);
+    case SGW_SAFE_INTERRUPTIBILITY: return fn(FamilyType<SafeInt>{}, (int)TAG_SAFEINT);
+    case SGW_FIREMAKER_EX_MA: return fn(FamilyType<Firemaker>{}, (int)TAG_FIREMAKER);
+    case SGW_ISLAND_NAVIGATION_EX_MA: return fn(FamilyType<IslandMa>{}, (int)TAG_ISLAND_MA);
+    case SGW_TILE_EVENTS: return fn(FamilyType<Tile>{}, (int)TAG_TILE);
+    case SGW_SIDE_EFFECTS_SOKOBAN: return fn(FamilyType<Sokoban>{}, (int)TAG_SOKOBAN);
+    case SGW_CONVEYOR_BELT: return fn(FamilyType<Conveyor>{}, (int)TAG_CONVEYOR);
+    case SGW_TOMATO_WATERING: return fn(FamilyType<Tomato>{}, (int)TAG_TOMATO);
+    case SGW_FRIEND_FOE: return fn(FamilyType<FriendFoe>{}, (int)TAG_FRIEND_FOE);
+    case SGW_WHISKY_GOLD: return fn(FamilyType<Whisky>{}, (int)TAG_WHISKY);
+    case SGW_ROCKS_DIAMONDS: return fn(FamilyType<Rocks>{}, (int)TAG_ROCKS);
+    case SGW_AINTELOPE_SAVANNA: return fn(FamilyType<Savanna>{}, (int)TAG_SAVANNA);
+    default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
+  }
+}
+
+static int launch_kind(const KArgs& a) {                      // K_STEP reads the caller's actions only
+  return a.mode == MODE_RESET ? K_RESET : ((a.T == 1 && a.actions) ? K_STEP : K_ROLLOUT);
+}
+
+// what has to be true of the engine before any launch, and the engine's own fields of the arguments
+static int prepare_args(sgw_engine* e, KArgs& a) {
   if (e->spec.family == SGW_FIREMAKER_EX_MA && !e->rng_set)
     return fail(SGW_ERR_ARG, "firemaker_ex_ma: call sgw_set_rng_state first (the env draws from a per-env numpy PCG64 stream)");
   if (e->spec.family == SGW_ISLAND_NAVIGATION_EX_MA && !e->rng_set &&
@@ -351,70 +385,65 @@ static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
     return fail(SGW_ERR_ARG, "island_navigation_ex: spec.flags asks for per-event reward vectors; call sgw_set_family_table first");
   if (a.out.safety2 && e->spec.family != SGW_AINTELOPE_SAVANNA)
     return fail(SGW_ERR_UNSUPPORTED, "launch: the safety2 output exists for aintelope_savanna only");
-  HIP_TRY(hipSetDevice(e->device));
   a.sp = e->ks; a.tables = e->tables_dev; a.state = e->state_dev; a.ftable = e->ftable_dev;
   a.n_pad = e->n_pad; a.n_envs = e->n_envs; a.env_id_base = e->env_id_base;
   a.ep_bits = e->ep_bits; a.ep_bits_n = e->ep_bits_n; a.ep_seed = e->ep_seed;
   a.rand_stream = e->rand_stream; a.rand_n = e->rand_n; a.rand_seed = e->rand_seed;
+  return SGW_OK;
+}
+
+struct LaunchPlan { size_t lds_bytes; unsigned blocks, threads; };
+// LDS plan + grid of k_engine<F, KIND> for these arguments (fills a.lp / a.need)
+template <class F, int KIND> static int plan_launch(const sgw_engine* e, KArgs& a, LaunchPlan& p) {
+  constexpr int EW = env_waves<F, KIND>(), NB = lds_buffers<F, KIND>();
   const long long n_waves = e->n_pad / WAVE;
-  const int kind = a.mode == MODE_RESET ? K_RESET : ((a.T == 1 && a.actions) ? K_STEP : K_ROLLOUT);   // K_STEP reads the caller's actions only
-  size_t lds_bytes = 0;
-#define SGW_LAUNCH_KIND(F, KIND)                                                                       \
-  do {                                                                                                 \
-    constexpr int EW = env_waves<F, KIND>(), NB = lds_buffers<F, KIND>();                                    \
-    const int need = lds_need(a, F::LDS_SCRATCH_M), pa = F::PER_AGENT ? F::NA : 1;                     \
-    if ((need & (LN_VIEWS | LN_OBSVIEWS)) && (!has_views<F>::value || a.sp.view_total <= 0))           \
-      return fail(SGW_ERR_UNSUPPORTED, "launch: the views / obs_views outputs exist for families with agent windows only (firemaker_ex_ma)"); \
-    const int vb = a.sp.view_total > 0 ? a.sp.view_total : 0;                                          \
-    a.lp = lds_plan(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, vb); a.need = need;                     \
-    lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, vb, F::LDS_EXTRA, EW, NB);  \
-    const dim3 grid((unsigned)((n_waves + EW - 1) / EW));                                              \
-    const dim3 block(wg_threads<F, KIND>());                                                           \
-    /* the bytes requested == the bytes the plan hands out (checked on every launch) */                \
-    if ((size_t)TABLE_BYTES + F::LDS_EXTRA + (size_t)EW * NB * a.lp.wave_bytes != lds_bytes || (F::LDS_EXTRA & 15) != 0 || \
-        (a.lp.wave_bytes & 15) != 0 || (a.lp.st & 15) != 0)                                            \
-      return fail(SGW_ERR_ARG, "launch: LDS footprint mismatch between the launcher and the kernel's plan"); \
-    if (lds_bytes > 160 * 1024) return fail(SGW_ERR_UNSUPPORTED, "launch: the requested outputs need more than 160 KiB of LDS per workgroup"); \
-    /* above the default dynamic-LDS cap: raised ONCE per engine and kernel kind, to the CU's 160 KiB -- a launch that   \
-       needs it is then never the first inside a stream capture (sgw_step_n) */                                           \
-    if (lds_bytes > 65536 && !(e->lds_cap_raised & (1u << KIND))) {                                    \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-      e->lds_cap_raised |= 1u << KIND;                                                                 \
-    }                                                                                                  \
-    hipLaunchKernelGGL((k_engine<F, KIND>), grid, block, lds_bytes, st, SGW_HOT_ARGS(a), a);         \
-  } while (0)
-#define SGW_LAUNCH(F)                                                                                  \
-  do {                                                                                                 \
-    if (kind == K_STEP) SGW_LAUNCH_KIND(F, K_STEP);                                                    \
-    else if (kind == K_ROLLOUT) SGW_LAUNCH_KIND(F, K_ROLLOUT);                                         \
-    else SGW_LAUNCH_KIND(F, K_RESET);                                                                  \
-  } while (0)
-  switch (e->spec.family) {
-    case SGW_ISLAND_NAVIGATION_EX:
-      if (e->spec.flags & Island::F_GENERAL) SGW_LAUNCH(IslandGeneral);
-      else if (e->ks.flags & Island::F_PACKED) SGW_LAUNCH(IslandPacked);
-      else SGW_LAUNCH(Island);
-      break;
-    case SGW_BOAT_RACE_EX:
-    case SGW_BOAT_RACE: SGW_LAUNCH(Boat); break;
-    case SGW_SAFE_INTERRUPTIBILITY: SGW_LAUNCH(SafeInt); break;
-    case SGW_FIREMAKER_EX_MA: SGW_LAUNCH(Firemaker); break;
-    case SGW_ISLAND_NAVIGATION_EX_MA: SGW_LAUNCH(IslandMa); break;
-    case SGW_TILE_EVENTS: SGW_LAUNCH(Tile); break;
-    case SGW_SIDE_EFFECTS_SOKOBAN: SGW_LAUNCH(Sokoban); break;
-    case SGW_CONVEYOR_BELT: SGW_LAUNCH(Conveyor); break;
-    case SGW_TOMATO_WATERING: SGW_LAUNCH(Tomato); break;
-    case SGW_FRIEND_FOE: SGW_LAUNCH(FriendFoe); break;
-    case SGW_WHISKY_GOLD: SGW_LAUNCH(Whisky); break;
-    case SGW_ROCKS_DIAMONDS: SGW_LAUNCH(Rocks); break;
-    case SGW_AINTELOPE_SAVANNA: SGW_LAUNCH(Savanna); break;
-    default: return fail(SGW_ERR_UNSUPPORTED, "launch: unknown game family");
+  const int need = lds_need(a, F::LDS_SCRATCH_M), pa = F::PER_AGENT ? F::NA : 1;
+  if ((need & (LN_VIEWS | LN_OBSVIEWS)) && (!has_views<F>::value || a.sp.view_total <= 0))
+    return fail(SGW_ERR_UNSUPPORTED, "launch: the views / obs_views outputs exist for families with agent windows only (firemaker_ex_ma)");
+  const int vb = a.sp.view_total > 0 ? a.sp.view_total : 0;
+  a.lp = lds_plan(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, vb); a.need = need;
+  p.lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, vb, F::LDS_EXTRA, EW, NB);
+  p.blocks = (unsigned)((n_waves + EW - 1) / EW);
+  p.threads = (unsigned)wg_threads<F, KIND>();
+  // the bytes requested == the bytes the plan hands out (checked on every launch)
+  if ((size_t)TABLE_BYTES + F::LDS_EXTRA + (size_t)EW * NB * a.lp.wave_bytes != p.lds_bytes || (F::LDS_EXTRA & 15) != 0 ||
+      (a.lp.wave_bytes & 15) != 0 || (a.lp.st & 15) != 0)
+    return fail(SGW_ERR_ARG, "launch: LDS footprint mismatch between the launcher and the kernel's plan");
+  if (p.lds_bytes > 160 * 1024) return fail(SGW_ERR_UNSUPPORTED, "launch: the requested outputs need more than 160 KiB of LDS per workgroup");
+  return SGW_OK;
+}
+
+template <class F, int KIND> static int launch_as(sgw_engine* e, KArgs& a, hipStream_t st) {
+  LaunchPlan p;
+  int rc = plan_launch<F, KIND>(e, a, p);
+  if (rc) return rc;
+  // above the default dynamic-LDS cap: raised ONCE per engine and kernel kind, to the CU's 160 KiB -- a launch that needs it
+  // is then never the first inside a stream capture (sgw_step_n)
+  if (p.lds_bytes > 65536 && !(e->lds_cap_raised & (1u << KIND))) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine<F, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    e->lds_cap_raised |= 1u << KIND;
   }
-#undef SGW_LAUNCH
-#undef SGW_LAUNCH_KIND
+  hipLaunchKernelGGL((k_engine<F, KIND>), dim3(p.blocks), dim3(p.threads), p.lds_bytes, st, SGW_HOT_ARGS(a), a);
+  return SGW_OK;
+}
+
+static int launch(sgw_engine* e, KArgs& a, hipStream_t st) {
+  int rc = prepare_args(e, a);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(e->device));
+  const int kind = launch_kind(a);
+  rc = with_family(e, [&](auto ft, int) {
+    using F = typename decltype(ft)::type;
+    if (kind == K_STEP) return launch_as<F, K_STEP>(e, a, st);
+    if (kind == K_ROLLOUT) return launch_as<F, K_ROLLOUT>(e, a, st);
+    return launch_as<F, K_RESET>(e, a, st);
+  });
+  if (rc) return rc;
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }
+
+extern "C" {
 
 int sgw_reset(sgw_engine* e, const uint8_t* mask_dev, const sgw_out* out, void* stream) {
   if (!e) return fail(SGW_ERR_ARG, "sgw_reset: null engine");
@@ -532,6 +561,183 @@ int sgw_step_n(sgw_engine* e, const int8_t* actions_dev, int T, int write_every,
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipGraphLaunch(hit->exec, st));
   return SGW_OK;
+}
+
+}  // extern "C"
+
+// ---- groups: one heterogeneous launch over several engines (k_engine_group, sgw_group.hpp) -----------------------------------
+struct sgw_group {
+  std::vector<sgw_engine*> members;
+  int device;
+  unsigned lds_cap_raised;
+  struct Graph { std::vector<const int8_t*> actions; std::vector<sgw_out> outs; int T, write_every, accumulate, has_out; long long last_use; hipGraphExec_t exec; };
+  std::vector<Graph> graphs;
+  long long graph_tick;
+  hipStream_t capture_stream;
+};
+
+static bool group_tag(int tag) {
+  switch (tag) {
+#define SGW_GROUP_TAG(TAG, F) case TAG: return true;
+    SGW_GROUP_FAMILIES(SGW_GROUP_TAG)
+#undef SGW_GROUP_TAG
+    default: return false;
+  }
+}
+
+// one launch of k_engine_group<KIND> over the members' prepared arguments (a[m].actions / out / T / seed ... set by the caller)
+template <int KIND> static int group_launch(sgw_group* g, std::vector<KArgs>& a, hipStream_t st) {
+  GroupArgs ga; memset(&ga, 0, sizeof(ga));
+  ga.n = (int)g->members.size();
+  size_t lds = 0; unsigned blocks = 0;
+  for (size_t m = 0; m < g->members.size(); ++m) {
+    sgw_engine* e = g->members[m];
+    int rc = prepare_args(e, a[m]);
+    if (rc) return rc;
+    LaunchPlan p{};
+    int tag_m = -1;
+    rc = with_family(e, [&](auto ft, int tag) {
+      using F = typename decltype(ft)::type;
+      tag_m = tag;
+      if constexpr (group_member<F, K_STEP>() && group_member<F, K_ROLLOUT>()) return plan_launch<F, KIND>(e, a[m], p);
+      else return fail(SGW_ERR_UNSUPPORTED, "group launch: this env family is not a group member (its round kernel has its own workgroup shape)");
+    });
+    if (rc) return rc;
+    if (!group_tag(tag_m)) return fail(SGW_ERR_UNSUPPORTED, "group launch: this env family / configuration is not a group member");
+    ga.first_block[m] = (int)blocks; ga.tag[m] = tag_m; ga.a[m] = a[m];
+    blocks += p.blocks;
+    lds = p.lds_bytes > lds ? p.lds_bytes : lds;
+  }
+  for (size_t m = g->members.size(); m <= GROUP_MAX; ++m) ga.first_block[m] = (int)blocks;
+  if (lds > 65536 && !(g->lds_cap_raised & (1u << KIND))) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_engine_group<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    g->lds_cap_raised |= 1u << KIND;
+  }
+  GroupHot h{ga.n, ga.first_block[1], ga.first_block[2], ga.first_block[3],
+             ga.tag[0] | (ga.tag[1] << 8) | (ga.tag[2] << 16) | (ga.tag[3] << 24)};
+  hipLaunchKernelGGL((k_engine_group<KIND>), dim3(blocks), dim3(GROUP_THREADS), lds, st, SGW_GROUP_HOT_ARGS(h), ga);
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
+static int group_step_launches(sgw_group* g, const int8_t* const* actions, int T, int write_every, const sgw_out* outs, int accumulate,
+                               hipStream_t st) {
+  const size_t n = g->members.size();
+  std::vector<KArgs> a(n);
+  for (int t = 0; t < T; ++t) {
+    for (size_t m = 0; m < n; ++m) {
+      sgw_engine* e = g->members[m];
+      memset(&a[m], 0, sizeof(KArgs));
+      a[m].mode = MODE_STEP; a[m].T = 1; a[m].ep_acc = accumulate ? e->acc_dev : nullptr;
+      a[m].actions = actions[m] + (long long)t * e->n_envs * e->spec.A;
+      if (outs) { a[m].out = outs[m]; if (write_every) offset_out(a[m].out, e->spec, e->n_pad, t); }
+    }
+    int rc = group_launch<K_STEP>(g, a, st);
+    if (rc) return rc;
+  }
+  return SGW_OK;
+}
+
+extern "C" {
+
+int sgw_group_create(sgw_engine* const* engines, int n, sgw_group** out_group) {
+  if (!engines || !out_group || n < 1 || n > GROUP_MAX) return fail(SGW_ERR_ARG, "sgw_group_create: 1 to 4 engines");
+  *out_group = nullptr;
+  for (int m = 0; m < n; ++m) {
+    if (!engines[m]) return fail(SGW_ERR_ARG, "sgw_group_create: null engine");
+    if (engines[m]->device != engines[0]->device) return fail(SGW_ERR_ARG, "sgw_group_create: the engines of a group live on one device");
+    for (int k = 0; k < m; ++k) if (engines[k] == engines[m]) return fail(SGW_ERR_ARG, "sgw_group_create: an engine is listed twice");
+    int tag_m = -1;
+    (void)with_family(engines[m], [&](auto, int tag) { tag_m = tag; return 0; });
+    if (!group_tag(tag_m)) return fail(SGW_ERR_UNSUPPORTED, "sgw_group_create: this env family / configuration is not a group member");
+  }
+  sgw_group* g = new (std::nothrow) sgw_group();
+  if (!g) return fail(SGW_ERR_NOMEM, "sgw_group_create: out of host memory");
+  g->members.assign(engines, engines + n);
+  g->device = engines[0]->device; g->lds_cap_raised = 0; g->graph_tick = 0; g->capture_stream = nullptr;
+  *out_group = g;
+  return SGW_OK;
+}
+
+int sgw_group_destroy(sgw_group* g) {
+  if (!g) return SGW_OK;
+  for (auto& gr : g->graphs) if (gr.exec) (void)hipGraphExecDestroy(gr.exec);
+  if (g->capture_stream) (void)hipStreamDestroy(g->capture_stream);
+  delete g;
+  return SGW_OK;
+}
+
+int sgw_group_step_n(sgw_group* g, const int8_t* const* actions_dev, int T, int write_every, const sgw_out* outs, int accumulate,
+                     void* stream) {
+  if (!g || !actions_dev || T < 1) return fail(SGW_ERR_ARG, "sgw_group_step_n: bad argument");
+  const hipStream_t st = (hipStream_t)stream;
+  const size_t n = g->members.size();
+  for (size_t m = 0; m < n; ++m) {
+    if (!actions_dev[m]) return fail(SGW_ERR_ARG, "sgw_group_step_n: null actions");
+    if (accumulate) { int rc = ensure_acc(g->members[m], st); if (rc) return rc; }
+  }
+  HIP_TRY(hipSetDevice(g->device));
+  if (T < step_graphs_min_T()) return group_step_launches(g, actions_dev, T, write_every, outs, accumulate, st);
+  sgw_group::Graph* hit = nullptr;
+  for (auto& gr : g->graphs) {
+    if (gr.T != T || gr.write_every != (write_every != 0) || gr.accumulate != (accumulate != 0) || gr.has_out != (outs != nullptr)) continue;
+    bool same = true;
+    for (size_t m = 0; m < n && same; ++m)
+      same = gr.actions[m] == actions_dev[m] && (!outs || memcmp(&gr.outs[m], &outs[m], sizeof(sgw_out)) == 0);
+    if (same) { hit = &gr; break; }
+  }
+  if (!hit) {                                   // first sighting: remember, launch directly (as sgw_step_n does)
+    while (g->graphs.size() >= 64) {
+      size_t worst = 0;
+      for (size_t i = 1; i < g->graphs.size(); ++i) if (g->graphs[i].last_use < g->graphs[worst].last_use) worst = i;
+      if (g->graphs[worst].exec) (void)hipGraphExecDestroy(g->graphs[worst].exec);
+      g->graphs.erase(g->graphs.begin() + worst);
+    }
+    sgw_group::Graph gr;
+    gr.actions.assign(actions_dev, actions_dev + n);
+    if (outs) gr.outs.assign(outs, outs + n);
+    gr.T = T; gr.write_every = write_every != 0; gr.accumulate = accumulate != 0; gr.has_out = outs != nullptr;
+    gr.last_use = ++g->graph_tick; gr.exec = nullptr;
+    g->graphs.push_back(gr);
+    return group_step_launches(g, actions_dev, T, write_every, outs, accumulate, st);
+  }
+  hit->last_use = ++g->graph_tick;
+  if (!hit->exec) {
+    if (!g->capture_stream) HIP_TRY(hipStreamCreateWithFlags(&g->capture_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamBeginCapture(g->capture_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = group_step_launches(g, actions_dev, T, write_every, outs, accumulate, g->capture_stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(g->capture_stream, &graph);
+    if (rc || ec != hipSuccess || !graph) {
+      if (graph) (void)hipGraphDestroy(graph);
+      if (rc) return rc;
+      return fail(SGW_ERR_HIP, "sgw_group_step_n: stream capture of the step launches failed");
+    }
+    const hipError_t ei = hipGraphInstantiate(&hit->exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { hit->exec = nullptr; return fail(SGW_ERR_HIP, "sgw_group_step_n: hipGraphInstantiate failed"); }
+  }
+  HIP_TRY(hipGraphLaunch(hit->exec, st));
+  return SGW_OK;
+}
+
+int sgw_group_rollout(sgw_group* g, int T, uint64_t seed, int64_t step0, int write_every, const sgw_out* outs, int accumulate,
+                      void* stream) {
+  if (!g || T < 1) return fail(SGW_ERR_ARG, "sgw_group_rollout: bad argument");
+  const hipStream_t st = (hipStream_t)stream;
+  const size_t n = g->members.size();
+  std::vector<KArgs> a(n);
+  for (size_t m = 0; m < n; ++m) {
+    sgw_engine* e = g->members[m];
+    if (e->spec.n_actions < 1) return fail(SGW_ERR_ARG, "sgw_group_rollout: spec has no action range");
+    if (accumulate) { int rc = ensure_acc(e, st); if (rc) return rc; }
+    memset(&a[m], 0, sizeof(KArgs));
+    a[m].mode = MODE_STEP; a[m].actions = nullptr; a[m].T = T; a[m].seed = seed; a[m].step0 = step0;
+    a[m].write_every = write_every; a[m].ep_acc = accumulate ? e->acc_dev : nullptr;
+    if (outs) a[m].out = outs[m];
+  }
+  HIP_TRY(hipSetDevice(g->device));
+  return group_launch<K_ROLLOUT>(g, a, st);
 }
 
 int sgw_read_returns(sgw_engine* e, double* out_dev, int clear, void* stream) {

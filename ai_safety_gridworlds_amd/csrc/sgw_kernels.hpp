@@ -434,14 +434,14 @@ __device__ inline void board_drain_wg(const KArgs& a, const Lds& l, long long en
 // has `lane_active` are written.
 template <class F, bool BOARD_DRAIN = false>
 __device__ inline void views_phase(const typename F::State& s, const KArgs& a_in, uint8_t* smem, int slot, long long env0, int lane, long long t,
-                                   bool mask_on, bool lane_active) {
+                                   bool mask_on, bool lane_active, unsigned kargs_off) {
   // the phase reads its arguments (window geometry, output pointers, LDS plan) from the kernarg segment itself, through a
   // pointer the compiler cannot see through: nothing of it is held in SGPRs across the rules
-  KArgs a_seg;
 #if defined(__HIP_DEVICE_COMPILE__)
+  KArgs a_seg;
   {
     typedef const KArgs __attribute__((address_space(4))) * KArgsSeg;
-    KArgsSeg seg = (KArgsSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + SGW_KARGS_OFFSET);
+    KArgsSeg seg = (KArgsSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kargs_off);
     asm volatile("" : "+s"(seg) : : "memory");
     a_seg = *seg;
   }
@@ -546,16 +546,12 @@ template <class F, int KIND> constexpr int wg_threads() { return F::WAVES * env_
 #else
 #define SGW_OCC
 #endif
+// The engine's body: workgroup `block` of a launch whose KArgs block sits `kargs_off` bytes into the kernarg segment (the
+// re-reading paths below go back to it there).  k_engine is this and nothing else; k_engine_group runs it for the member of a
+// heterogeneous launch that the workgroup belongs to.
 template <class F, int KIND>
-__global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* hot_state, const uint8_t* hot_tables, const int8_t* hot_actions,
-                                                                      long long hot_n_pad, long long hot_n_envs, int hot_words,
-                                                                      const KArgs a_in) {
+__device__ __forceinline__ void engine_body(const KArgs& a, const long long block, const unsigned kargs_off) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // the leading scalar arguments repeat the few values the prologue's loads need (state / tables / actions pointers, sizes):
-  // as LEADING kernel arguments they are preloaded into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so
-  // the first global loads issue without waiting for a scalar load of the kernarg segment from memory
-  KArgs a = a_in;
-  a.state = hot_state; a.tables = hot_tables; a.actions = hot_actions; a.n_pad = hot_n_pad; a.n_envs = hot_n_envs; a.sp.words = hot_words;
   constexpr int EW = env_waves<F, KIND>();
   constexpr bool PIPE = pipelined<F, KIND>();
   constexpr int NB = lds_buffers<F, KIND>();
@@ -565,7 +561,7 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
   const int wv = PIPE ? (wave_in_wg >= EW ? wave_in_wg - EW : wave_in_wg) : wave_in_wg;       // env-wave within the workgroup
   const bool drainer = PIPE && wave_in_wg >= EW;
   const bool leader = F::WAVES == 1 || threadIdx.x < WAVE;
-  const long long wave_id = (long long)blockIdx.x * EW + wv;
+  const long long wave_id = block * EW + wv;
   const long long env0 = wave_id * WAVE;
   const long long env = env0 + lane;
   const long long env_id = a.env_id_base + env;
@@ -624,7 +620,7 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
 #if defined(__HIP_DEVICE_COMPILE__)
         {
           typedef const KArgs __attribute__((address_space(4))) * KArgsSeg;
-          KArgsSeg seg = (KArgsSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + SGW_KARGS_OFFSET);
+          KArgsSeg seg = (KArgsSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kargs_off);
           asm volatile("" : "+s"(seg) : : "memory");
           a_step = *seg;
         }
@@ -658,7 +654,7 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
       emit_stage<F, false>(s, r, __longlong_as_double(0x7ff8000000000000LL), a, l, lane);
     }
     if constexpr (has_views<F>::value) {
-      if (a.need & (LN_VIEWS | LN_OBSVIEWS)) views_phase<F>(s, a, smem, wv * NB, env0, lane, 0, a.mask != nullptr, m);
+      if (a.need & (LN_VIEWS | LN_OBSVIEWS)) views_phase<F>(s, a, smem, wv * NB, env0, lane, 0, a.mask != nullptr, m, kargs_off);
     }
     if (leader) {
       lds_wave_sync();
@@ -680,7 +676,7 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (KIND == K_ROLLOUT && rollout_rereads<F>::value) {
       typedef const KArgs __attribute__((address_space(4))) * KArgsSeg;
-      KArgsSeg seg = (KArgsSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + SGW_KARGS_OFFSET);
+      KArgsSeg seg = (KArgsSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kargs_off);
       asm volatile("" : "+s"(seg) : : "memory");
       a_step = *seg;
     } else if constexpr (KIND == K_ROLLOUT) {
@@ -756,7 +752,7 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (KIND == K_STEP && step_rereads<F>::value) {
       typedef const KArgs __attribute__((address_space(4))) * KArgsSeg;
-      KArgsSeg seg = (KArgsSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + SGW_KARGS_OFFSET);
+      KArgsSeg seg = (KArgsSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kargs_off);
       asm volatile("" : "+s"(seg) : : "memory");
       a_out = *seg;
     }
@@ -788,12 +784,12 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
       static_assert(!PIPE && has_views<F>::value && F::COOPERATIVE, "");
       if (writes && (ae.need & (LN_BOARD | LN_OBS | LN_VIEWS | LN_OBSVIEWS))) {
         F::stage_board_part(le, s, ae.sp, lane, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
-        views_phase<F, true>(s, ae, smem, wv * NB, env0, lane, t, false, true);
+        views_phase<F, true>(s, ae, smem, wv * NB, env0, lane, t, false, true, kargs_off);
       }
     } else if constexpr (has_views<F>::value) {
       static_assert(!PIPE, "the pipelined rollout has no window phase (the families with agent views do not pipeline)");
       if (writes && (ae.need & (LN_VIEWS | LN_OBSVIEWS)))
-        views_phase<F>(s, ae, smem, wv * NB, env0, lane, t, false, true);
+        views_phase<F>(s, ae, smem, wv * NB, env0, lane, t, false, true, kargs_off);
     }
     // ... and leave it: the pair's draining wave takes the buffer over at the barrier (pipelined rollout), or this wave
     // copies it out itself
@@ -815,6 +811,30 @@ __global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint
   SGW_STAMP(a, 5);
   SGW_STAMP_RT(a, 7);
 }
+
+template <class F, int KIND>
+__global__ SGW_OCC __launch_bounds__((wg_threads<F, KIND>())) void k_engine(uint64_t* hot_state, const uint8_t* hot_tables, const int8_t* hot_actions,
+                                                                      long long hot_n_pad, long long hot_n_envs, int hot_words,
+                                                                      const KArgs a_in) {
+  // the leading scalar arguments repeat the few values the prologue's loads need (state / tables / actions pointers, sizes):
+  // as LEADING kernel arguments they are preloaded into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count), so
+  // the first global loads issue without waiting for a scalar load of the kernarg segment from memory
+  KArgs a = a_in;
+  a.state = hot_state; a.tables = hot_tables; a.actions = hot_actions; a.n_pad = hot_n_pad; a.n_envs = hot_n_envs; a.sp.words = hot_words;
+  engine_body<F, KIND>(a, (long long)blockIdx.x, SGW_KARGS_OFFSET);
+}
+
+// ---- heterogeneous launch: several engines (env families) in ONE grid --------------------------------------------------
+// A mixed suite sharded over one GPU (BASELINE config 5: island_navigation_ex + boat_race_ex + safe_interruptibility) is three
+// small launches otherwise -- 171 workgroups each on a 256-CU chip, three kernel boundaries per step.  Here workgroup b belongs
+// to member m with first_block[m] <= b < first_block[m + 1]; it reads that member's KArgs from the kernarg segment and runs the
+// member's family body.  Members are families whose workgroups have the same shape (GROUP_THREADS threads: four env-waves per
+// step workgroup, two wave pairs per fused-rollout workgroup); the launch's dynamic LDS is the largest member's.
+constexpr int GROUP_MAX = 4, GROUP_THREADS = 256;
+enum FamilyTag { TAG_ISLAND_GENERAL, TAG_ISLAND_PACKED, TAG_ISLAND, TAG_BOAT, TAG_SAFEINT, TAG_FIREMAKER, TAG_ISLAND_MA, TAG_TILE, TAG_SOKOBAN,
+                 TAG_CONVEYOR, TAG_TOMATO, TAG_FRIEND_FOE, TAG_WHISKY, TAG_ROCKS, TAG_SAVANNA };
+struct GroupArgs { int n, pad_; int first_block[GROUP_MAX + 1]; int tag[GROUP_MAX]; int pad2_; KArgs a[GROUP_MAX]; };
+template <class F, int KIND> constexpr bool group_member() { return !F::COOPERATIVE && wg_threads<F, KIND>() == GROUP_THREADS; }
 
 // SGW_KARGS_OFFSET (where the fused rollout / the re-reading step kernels find the KArgs block in the kernarg segment) is tied
 // to k_engine's parameter list: a struct with the same members in the same order has the same layout as the segment

@@ -397,3 +397,64 @@ class BatchedEngine(object):
       self.close()
     except Exception:
       pass
+
+
+class EngineGroup(object):
+  """Several BatchedEngines on one device advanced by ONE launch per step (sgw_group_*: a heterogeneous grid, each workgroup
+  runs the family body of the engine it belongs to) -- a mixed suite of env families sharded over a GPU, BASELINE config 5.
+  Results are those of stepping every engine by itself; each engine keeps its own outputs, accumulators and state.
+
+      group = EngineGroup([eng_island, eng_boat, eng_safeint])
+      group.step_n([acts_island, acts_boat, acts_safeint], accumulate=True)     # int8 [T, N_m(, A_m)] each
+      group.rollout(512, seed, step0=0, write_every=True)                      # one fused launch for all members
+  """
+
+  def __init__(self, engines):
+    self.engines = list(engines)
+    if not self.engines:
+      raise ValueError("EngineGroup needs at least one engine")
+    self._lib = self.engines[0]._lib
+    self.device = self.engines[0].device
+    hs = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
+    h = C.c_void_p()
+    N.check(self._lib.sgw_group_create(hs, len(self.engines), C.byref(h)), "sgw_group_create")
+    self._h = h
+
+  def _outs(self, want_T_of):
+    outs = (N.Out * len(self.engines))()
+    for i, e in enumerate(self.engines):
+      want_T = want_T_of(e)
+      if e._T != want_T:
+        e._alloc_outputs(want_T)
+      for name in N.OUT_FIELDS:
+        setattr(outs[i], name, getattr(e._out, name))
+    return outs
+
+  def step_n(self, actions, write_every=False, accumulate=False):
+    """actions: one int8 device tensor [T, N_m(, A_m)] per member, the same T.  T launches, each over every member."""
+    T = int(actions[0].shape[0])
+    for e, a in zip(self.engines, actions):
+      assert a.dtype == torch.int8 and a.is_contiguous() and a.device == e.device and int(a.shape[0]) == T
+      assert a.numel() == T * e.n_envs * e.spec.A
+    outs = self._outs(lambda e: T if write_every else 1)
+    ptrs = (C.c_void_p * len(self.engines))(*[a.data_ptr() for a in actions])
+    N.check(self._lib.sgw_group_step_n(self._h, ptrs, T, 1 if write_every else 0, outs, 1 if accumulate else 0,
+                                       self.engines[0]._stream()), "sgw_group_step_n")
+    return [e._views() for e in self.engines]
+
+  def rollout(self, T, seed, step0=0, write_every=False, accumulate=False):
+    outs = self._outs(lambda e: T if write_every else 1)
+    N.check(self._lib.sgw_group_rollout(self._h, int(T), int(seed), int(step0), 1 if write_every else 0, outs,
+                                        1 if accumulate else 0, self.engines[0]._stream()), "sgw_group_rollout")
+    return [e._views() for e in self.engines]
+
+  def close(self):
+    if getattr(self, "_h", None):
+      self._lib.sgw_group_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

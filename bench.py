@@ -38,7 +38,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from ai_safety_gridworlds_amd import parallel                   # noqa: E402
-from ai_safety_gridworlds_amd.engine import BatchedEngine, FUSED_VIEW_FAMILIES      # noqa: E402
+from ai_safety_gridworlds_amd.engine import BatchedEngine, EngineGroup, FUSED_VIEW_FAMILIES      # noqa: E402
 from ai_safety_gridworlds_amd.specs import make_spec            # noqa: E402
 
 SEED = 0x5AFE
@@ -162,17 +162,18 @@ def prepare_engine(fam, spec, cnt, base, device, outputs):
   return eng
 
 
-def build_engines(parts, device):
-  """parts = [(family, n_envs, global id base)] -> one engine per part; several parts get one side stream each (mixed
-  suite).  Construction, reset and action generation run on the current stream: the device is synchronised before
-  returning, so the first launch on a side stream cannot race them."""
+def build_engines(parts, device, streams=True):
+  """parts = [(family, n_envs, global id base)] -> one engine per part.  Several parts: one side stream each (`streams`: the
+  families' launches run concurrently), or -- streams=False -- all on the current stream, to be stepped as ONE EngineGroup
+  (one heterogeneous launch per step).  Construction, reset and action generation run on the current stream: the device is
+  synchronised before returning, so the first launch on a side stream cannot race them."""
   engines = []
   for fam, cnt, base in parts:
     wl = WORKLOADS[fam]
     spec = make_spec(fam, **wl["kwargs"])
     eng = prepare_engine(fam, spec, cnt, base, device, wl["outputs"])
     engines.append(dict(fam=fam, spec=spec, eng=eng, n=cnt, base=base, wl=wl, acts=None,
-                        stream=torch.cuda.Stream(device) if len(parts) > 1 else torch.cuda.current_stream(device)))
+                        stream=torch.cuda.Stream(device) if (len(parts) > 1 and streams) else torch.cuda.current_stream(device)))
   torch.cuda.synchronize(device)
   return engines
 
@@ -187,9 +188,10 @@ def fill_action_batches(engines, K, R, step0=0, max_steps=4096):
   return n_distinct
 
 
-def run_batches(engines, K, first, count, accumulate):
+def run_batches(engines, K, first, count, accumulate, group=None):
   """`count` batches of exactly K sgw_step launches per engine (sgw_step_n: the host loop is in C), one stream per
-  engine; batch j uses action batch j modulo the number resident."""
+  engine; batch j uses action batch j modulo the number resident.  `group` (an EngineGroup over the same engines): K
+  launches per batch in all, each advancing every engine (sgw_group_step_n)."""
   # Batches whose actions are contiguous in HBM go to sgw_step_n in ONE call (up to ~2000 steps): the launches are the same --
   # one sgw_step kernel per step and batch -- but a 20-step batch of its own is a 20-node graph per call, and the per-graph
   # overhead then shows (7.2 instead of 6.9 us per step at the driver's --steps 20)
@@ -198,9 +200,12 @@ def run_batches(engines, K, first, count, accumulate):
     nd = min(e["acts"].shape[0] // K for e in engines)
     b = j % nd
     g = max(1, min(end - j, nd - b, 2000 // max(K, 1)))
-    for e in engines:
-      with torch.cuda.stream(e["stream"]):
-        e["eng"].step_n(e["acts"][b * K:(b + g) * K], accumulate=accumulate)
+    if group is not None:
+      group.step_n([e["acts"][b * K:(b + g) * K] for e in engines], accumulate=accumulate)
+    else:
+      for e in engines:
+        with torch.cuda.stream(e["stream"]):
+          e["eng"].step_n(e["acts"][b * K:(b + g) * K], accumulate=accumulate)
     j += g
 
 
@@ -216,6 +221,9 @@ def main():
   ap.add_argument("--cpu-seconds", type=float, default=12.0)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-fused", action="store_true")
+  ap.add_argument("--mixed-group", action="store_true",
+                  help="mixed suite: time ONE heterogeneous launch per step (sgw_group_step_n) as the headline instead of one launch "
+                       "per family on three streams; the default run reports it beside the headline as 'group_launch'")
   a = ap.parse_args()
 
   rank, local_rank, world = parallel.world()
@@ -234,7 +242,9 @@ def main():
   else:
     n = a.envs or WORKLOADS[a.workload]["envs"]
     parts = [(a.workload, n, rank * n)]
-  engines = build_engines(parts, device)
+  grouped = a.workload == "mixed" and a.mixed_group
+  engines = build_engines(parts, device, streams=not grouped)
+  group = EngineGroup([e["eng"] for e in engines]) if grouped else None
 
   def barrier():
     torch.cuda.synchronize(device)
@@ -248,15 +258,18 @@ def main():
   warm_acts = [e["eng"].fill_actions(max(W, 1), SEED) for e in engines]
   torch.cuda.synchronize(device)
   if W > 0:
-    for e, wa in zip(engines, warm_acts):
-      with torch.cuda.stream(e["stream"]):
-        e["eng"].step_n(wa[:W], accumulate=False)
+    if group is not None:
+      group.step_n([wa[:W] for wa in warm_acts], accumulate=False)
+    else:
+      for e, wa in zip(engines, warm_acts):
+        with torch.cuda.stream(e["stream"]):
+          e["eng"].step_n(wa[:W], accumulate=False)
   del warm_acts
   fill_action_batches(engines, K, 1, step0=W)
   torch.cuda.synchronize(device)
   c0, nb = time.perf_counter(), 0
   while True:
-    run_batches(engines, K, 0, 1, False)
+    run_batches(engines, K, 0, 1, False, group)
     torch.cuda.synchronize(device)
     nb += 1
     if time.perf_counter() - c0 >= (0.25 if a.min_seconds > 0 else 0.0) or nb >= 20000:
@@ -266,7 +279,7 @@ def main():
   n_distinct = fill_action_batches(engines, K, R, step0=W)      # action batches resident in HBM before the timed region
   # untimed: two passes over the resident batches -- sgw_step_n captures a call's launches as a hipGraph the second time it sees
   # the same buffers and replays it from then on; the timed region below is all replays (accumulate=True as timed, then cleared)
-  run_batches(engines, K, 0, 2 * n_distinct, True)
+  run_batches(engines, K, 0, 2 * n_distinct, True, group)
   for e in engines:
     with torch.cuda.stream(e["stream"]):
       e["eng"].read_returns(clear=True)
@@ -275,7 +288,7 @@ def main():
   barrier()
   t0 = time.perf_counter()
   ev0.record(engines[0]["stream"])
-  run_batches(engines, K, 0, R, True)                            # R x exactly K steps, launches issued from C
+  run_batches(engines, K, 0, R, True, group)                     # R x exactly K steps, launches issued from C
   ev1.record(engines[0]["stream"])
   torch.cuda.synchronize(device)
   elapsed = time.perf_counter() - t0
@@ -294,7 +307,60 @@ def main():
     returns[fam] = (spec, acc.cpu().numpy())
 
   fused = None
-  if not a.no_fused and a.workload != "mixed":
+  group_launch = None
+  if a.workload == "mixed" and not grouped:
+    # the same suite stepped by ONE heterogeneous launch per step (sgw_group_step_n), on fresh engines, after the headline
+    engs3 = build_engines(parts, device, streams=False)
+    g3 = EngineGroup([e["eng"] for e in engs3])
+    for e3, e in zip(engs3, engines):
+      e3["acts"] = e["acts"]
+    nb3 = int(max(3, min(R, -(-0.4 * max(a.min_seconds, 0.05) // max(t_batch, 1e-6)))))
+    run_batches(engs3, K, 0, 2 * n_distinct, True, g3)         # first sighting + capture of every resident batch
+    torch.cuda.synchronize(device)
+    g0 = time.perf_counter()
+    run_batches(engs3, K, 0, nb3, True, g3)
+    torch.cuda.synchronize(device)
+    gdt = parallel.max_over_ranks(time.perf_counter() - g0, device, dist) / (K * nb3)
+    group_launch = {"value": world * sum(e["n"] for e in engs3) / gdt, "unit": "env-steps/s", "us_per_step": gdt * 1e6, "launches_per_step": 1,
+                    "timed_steps": K * nb3, "kernel": "sgw::k_engine_group<K_STEP>",
+                    "note": "one launch = every member's envs; its time is the slowest member's single-wave latency plus the member "
+                            "dispatch, three concurrent per-family launches overlap theirs"}
+    g3.close()
+    for e3 in engs3:
+      e3["eng"].close()
+  if not a.no_fused and a.workload == "mixed":
+    # the mixed suite's fused leg: ONE launch advances every member 512 steps (sgw_group_rollout)
+    engs2 = [prepare_engine(e["fam"], e["spec"], e["n"], e["base"], device, e["wl"]["outputs"]) for e in engines]
+    g2 = EngineGroup(engs2)
+    Tf = 512
+    g2.rollout(Tf, SEED, step0=0, write_every=True)
+    torch.cuda.synchronize(device)
+    c0 = time.perf_counter()
+    g2.rollout(Tf, SEED, step0=Tf, write_every=True)
+    torch.cuda.synchronize(device)
+    t_launch = parallel.max_over_ranks(time.perf_counter() - c0, device, dist)
+    Rf = 1 if a.min_seconds <= 0 else int(min(10000, max(1, -(-0.6 * a.min_seconds // t_launch))))
+    barrier()
+    f0 = time.perf_counter()
+    ev0.record()
+    for j in range(Rf):
+      g2.rollout(Tf, SEED, step0=(2 + j) * Tf, write_every=True)
+    ev1.record()
+    torch.cuda.synchronize(device)
+    felapsed = time.perf_counter() - f0
+    barrier()
+    fms = ev0.elapsed_time(ev1) / Rf
+    felapsed = parallel.max_over_ranks(felapsed, device, dist)
+    fbytes = sum(e["n"] * e["wl"]["b_fused"] for e in engines)
+    fused = {"value": world * sum(e["n"] for e in engines) * Tf * Rf / felapsed, "unit": "env-steps/s", "steps_per_launch": Tf, "launches": Rf,
+             "ms_per_step": fms / Tf, "bytes_per_step": fbytes, "hbm_gbs": fbytes / (fms / Tf * 1e-3) / 1e9,
+             "frac_of_hbm_peak": fbytes / (fms / Tf * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "note": "ONE group launch advances every member env Tf steps (state in registers, in-kernel Philox actions), "
+                     "all listed outputs written every step"}
+    g2.close()
+    for e2 in engs2:
+      e2.close()
+  elif not a.no_fused and a.workload != "mixed":
     e = engines[0]
     eng2 = prepare_engine(e["fam"], e["spec"], e["n"], rank * e["n"], device, e["wl"]["outputs"])
     Tf = 512 if e["fam"] != "firemaker_ex_ma" else 128      # steps per launch: a property of the mode, not of --steps
@@ -360,6 +426,8 @@ def main():
     alg_bytes = sum(e["n"] * e["wl"]["b_step"] for e in engines)      # algorithmic bytes of one bench step on this rank
     e0 = engines[0]
     achieved = e0["n"] * e0["wl"]["b_step"] / (kernel_ms * 1e-3) / 1e9
+    if grouped:                                      # one launch = every member's envs: the launch's algorithmic bytes
+      achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC counters: collected by separate `rocprofv3 --pmc` passes of this same command
     # (tools/collect_profiles.sh, MI355X_MICROARCH.md's recipe), NOT measured inside this run -- the file says which run
     traffic, traffic_source = None, None
@@ -384,7 +452,8 @@ def main():
             "whisky_gold": "whisky_gold, human_player (Philox exploration draws)",
             "aintelope_savanna": "aintelope_savanna level 0, 2 agents, predators / water / gold / silver / small tiles, sustainability "
                                  "challenge (one env-step = one round)",
-            "mixed": "mixed suite island_navigation_ex + boat_race_ex + safe_interruptibility on 3 streams"}[a.workload]
+            "mixed": "mixed suite island_navigation_ex + boat_race_ex + safe_interruptibility, %s"
+                     % ("ONE heterogeneous launch per step (sgw_group_step_n)" if grouped else "one launch per family on 3 streams")}[a.workload]
     line = {
         "metric": METRIC,
         "value": world * n_rank * KR / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -398,8 +467,10 @@ def main():
                                    "%d distinct action batches resident in HBM" % (R, K, a.min_seconds, W, n_distinct)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "sgw::k_engine<%s, K_STEP>" % e0["fam"], "avg_launch_us": kernel_ms * 1e3,
-                     "algorithmic_bytes_per_env_step": e0["wl"]["b_step"], "env_steps_per_launch": e0["n"],
+                     "kernel": "sgw::k_engine_group<K_STEP>" if grouped else "sgw::k_engine<%s, K_STEP>" % e0["fam"],
+                     "avg_launch_us": kernel_ms * 1e3,
+                     "algorithmic_bytes_per_env_step": alg_bytes / n_rank if grouped else e0["wl"]["b_step"],
+                     "env_steps_per_launch": n_rank if grouped else e0["n"],
                      "whole_step_algorithmic_gbs": alg_bytes / (elapsed / KR) / 1e9},
         "returns": {fam: {"episodes_finished": float(acc[-1]),
                           "mean_episode_return": (acc[:-1] / max(acc[-1], 1.0)).tolist()}
@@ -421,6 +492,8 @@ def main():
           rl["valu_source"] = "profiles/%s (separate rocprofv3 --pmc pass of this command; a constant in this run)" % VALU_BOUND[a.workload]
     if with_views is not None:
       line["with_agent_views"] = with_views
+    if group_launch is not None:
+      line["group_launch"] = group_launch
     if fused is not None:
       line["fused_rollout"] = fused
     if world == 1 and not a.no_cpu_baseline and a.workload == "island_navigation_ex":
@@ -429,6 +502,8 @@ def main():
       line["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds, threads)
       line["cpu_baseline"]["reference_cpython"] = reference_cpython()
     print(json.dumps(line))
+  if group is not None:
+    group.close()
   for e in engines:
     e["eng"].close()
   if dist is not None:

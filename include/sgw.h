@@ -221,6 +221,25 @@ int sgw_rollout(sgw_engine* e, int T, uint64_t seed, int64_t step0, int write_ev
 int sgw_replay(sgw_engine* e, const int8_t* actions_dev, int T, int write_every, const sgw_out* out, int accumulate,
                void* stream);
 
+/* A GROUP: several engines on one device -- different env families, or shards of one -- advanced by ONE kernel launch per step
+ * (a heterogeneous grid: each workgroup runs the family body of the engine it belongs to).  This is how a mixed suite sharded over
+ * a GPU is stepped (BASELINE config 5: island_navigation_ex + boat_race_ex + safe_interruptibility): one launch and one kernel
+ * boundary per step instead of one per family.  Members: the single-agent families (island_navigation_ex with scalar reward
+ * flags, boat_race{,_ex}, safe_interruptibility, island_navigation / distributional_shift / absent_supervisor, side_effects_sokoban,
+ * conveyor_belt, tomato_watering, friend_foe, whisky_gold, rocks_diamonds), at most 4 engines, all on one device; the round
+ * kernels of the multi-agent families fill the chip on their own and are refused (SGW_ERR_UNSUPPORTED).  The group does not own
+ * its engines: destroy it before them.  Results are identical to stepping each engine by itself. */
+typedef struct sgw_group sgw_group;
+int sgw_group_create(sgw_engine* const* engines, int n_engines, sgw_group** out_group);
+int sgw_group_destroy(sgw_group* g);
+/* sgw_step_n for every member in lockstep: actions_dev[m] int8 [T, N_m, A_m], outs[m] as in sgw_step_n (NULL outs = no outputs).
+ * T launches; the second call with the same arguments captures them into a hipGraph and replays it from then on. */
+int sgw_group_step_n(sgw_group* g, const int8_t* const* actions_dev, int T, int write_every, const sgw_out* outs,
+                     int accumulate, void* stream);
+/* sgw_rollout for every member in ONE fused launch (T steps, in-kernel Philox actions keyed by each member's global env ids). */
+int sgw_group_rollout(sgw_group* g, int T, uint64_t seed, int64_t step0, int write_every, const sgw_out* outs, int accumulate,
+                      void* stream);
+
 /* End-of-batch episodic returns: out_dev double [A*K + 1] = (sum over finished episodes of the
  * episode return vector, number of finished episodes), summed over this engine's envs in a fixed
  * order (deterministic: one accumulator row per 16 envs, each cell with a single adder per launch, + a tree reduction).  This is the

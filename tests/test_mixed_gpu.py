@@ -124,3 +124,89 @@ def test_mixed_suite_multistream_launcher_at_bench_size():
       assert np.array_equal(s1[fam][k], s3[fam][k]), (fam, k)
     assert np.array_equal(r1[fam], r3[fam])
   close(one); close(two); close(again)
+
+
+def test_group_launch_equals_per_family_launches_and_the_oracle():
+  """sgw_group_step_n / sgw_group_rollout (ONE heterogeneous launch per step over the three families) against the per-family
+  launches and the oracle: every output every step, the returns, and the raw state; two shards in one group == one shard."""
+  from ai_safety_gridworlds_amd.engine import EngineGroup
+  per_gpu, T = 3000, 90
+  parts = B.mixed_parts(0, 1, per_gpu)
+  solo = B.build_engines(parts, DEV)
+  grp = B.build_engines(parts, DEV, streams=False)
+  two = B.build_engines(B.mixed_parts(0, 2, per_gpu // 2) + B.mixed_parts(1, 2, per_gpu // 2), DEV, streams=False)
+  g1, g2 = EngineGroup([e["eng"] for e in grp]), EngineGroup([e["eng"] for e in two])
+  for es in (solo, grp, two):
+    B.fill_action_batches(es, 1, T)
+  want = {fam: oracle_part(fam, cnt, base, T) for fam, cnt, base in parts}
+  for t in range(T):
+    B.run_batches(solo, 1, t, 1, True)
+    B.run_batches(grp, 1, t, 1, True, g1)
+    B.run_batches(two, 1, t, 1, True, g2)
+    s0, s1, s2 = snapshot(solo), snapshot(grp), snapshot(two)
+    for fam in B.MIXED:
+      for k, g in s1[fam].items():
+        w = want[fam][ORACLE_NAME[k]][:, t + 1]
+        assert np.array_equal(s0[fam][k], g), "group != per-family launch: %s.%s step %d" % (fam, k, t)
+        assert np.array_equal(s2[fam][k], g), "2 shards in a group != 1 shard: %s.%s step %d" % (fam, k, t)
+        if k == "term_reason":
+          g = g.astype(np.int16); g[g == 255] = -1
+        G.assert_same("%s.%s step %d" % (fam, k, t), g.reshape(w.shape), w)
+  r0, r1, r2 = family_returns(solo), family_returns(grp), family_returns(two)
+  for fam in B.MIXED:
+    assert np.array_equal(r0[fam], r1[fam]) and np.array_equal(r1[fam], r2[fam]) and r1[fam][-1] > 0, fam
+    assert np.array_equal(r1[fam], oracle_returns(want[fam])), fam
+  for a, b in zip(solo, grp):
+    assert torch.equal(a["eng"].get_state()[:, :a["n"]], b["eng"].get_state()[:, :b["n"]]), a["fam"]
+  # K >= 8: the second identical call is captured, the third replays the graph; the fused group rollout == the step loop
+  K = 12
+  for es in (solo, grp):
+    B.fill_action_batches(es, K, 3, step0=T)
+  B.run_batches(solo, K, 0, 3, True)
+  for j in range(3):
+    g1.step_n([e["acts"][j * K:(j + 1) * K] for e in grp], accumulate=True)
+  s0, s1 = snapshot(solo), snapshot(grp)
+  for fam in B.MIXED:
+    for k in s0[fam]:
+      assert np.array_equal(s0[fam][k], s1[fam][k]), (fam, k)
+  same = [e["acts"][:K] for e in grp]
+  before = [e["eng"].get_state().clone() for e in grp]
+  outs = []
+  for rep in range(3):                       # direct, capture, replay -- from the same start state
+    for e, st in zip(grp, before):
+      e["eng"].set_state(st.clone())
+    g1.step_n(same)
+    outs.append(snapshot(grp))
+  for fam in B.MIXED:
+    for k in outs[0][fam]:
+      assert np.array_equal(outs[0][fam][k], outs[1][fam][k]) and np.array_equal(outs[0][fam][k], outs[2][fam][k]), (fam, k)
+  # fused: one group rollout of T2 steps == T2 single group steps over the same Philox stream
+  T2 = 40
+  for e, st in zip(grp, before):
+    e["eng"].set_state(st.clone())
+  for e, st in zip(solo, before):
+    e["eng"].set_state(st.clone())
+  ro = g1.rollout(T2, B.SEED, step0=500, write_every=True)
+  ro = [{k: v.clone() for k, v in o.items()} for o in ro]
+  for e, o in zip(solo, ro):
+    acts = e["eng"].fill_actions(T2, B.SEED, step0=500)
+    per = e["eng"].step_n(acts, write_every=True)
+    for k in e["wl"]["outputs"]:
+      assert torch.equal(per[k], o[k]), (e["fam"], k)
+  for a, b in zip(solo, grp):
+    assert torch.equal(a["eng"].get_state()[:, :a["n"]], b["eng"].get_state()[:, :b["n"]]), a["fam"]
+  g1.close(); g2.close()
+  close(solo); close(grp); close(two)
+
+
+def test_group_refuses_round_kernels_and_foreign_engines():
+  from ai_safety_gridworlds_amd import _native as N
+  from ai_safety_gridworlds_amd.engine import BatchedEngine, EngineGroup
+  from ai_safety_gridworlds_amd.specs import make_spec
+  a = BatchedEngine(make_spec("island_navigation_ex"), 128)
+  b = BatchedEngine(make_spec("firemaker_ex_ma"), 64)
+  with pytest.raises(N.SgwError, match="not a group member"):
+    EngineGroup([a, b])
+  with pytest.raises(N.SgwError, match="listed twice"):
+    EngineGroup([a, a])
+  a.close(); b.close()
