@@ -48,6 +48,15 @@ class Out(C.Structure):
   _fields_ = [(n, C.c_void_p) for n in OUT_FIELDS]
 
 
+class Extras(C.Structure):
+  """Mirror of `struct sgw_extras` (sgw_step_full)."""
+  _fields_ = [("rgb", C.c_void_p), ("rgb_lut_dev", C.c_void_p), ("layers", C.c_void_p), ("layer_chars_dev", C.c_void_p),
+              ("layer_static_dev", C.c_void_p), ("n_layers", C.c_int32), ("gap_index", C.c_int32), ("hidden_layer", C.c_int32),
+              ("perf_from_hidden", C.c_int32), ("stats", C.c_void_p), ("k_agent", C.c_int32 * MAX_AGENTS),
+              ("agent_layer_views", C.c_void_p), ("perf_last", C.c_void_p), ("perf_sum", C.c_void_p), ("perf_count", C.c_void_p),
+              ("done", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -109,6 +118,9 @@ def lib():
   L.sgw_view_bytes.argtypes = [C.c_void_p]
   L.sgw_agent_views.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint8, C.c_void_p, C.c_void_p]
   L.sgw_agent_layer_views.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint8, C.c_void_p, C.c_void_p]
+  L.sgw_track_performance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+  L.sgw_step_full.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Out), C.POINTER(Extras), C.c_void_p]
+  L.sgw_sizeof_extras.restype = C.c_int
   L.sgw_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   L.sgw_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   if L.sgw_abi_version() != ABI_VERSION:
@@ -117,12 +129,14 @@ def lib():
     raise SgwError("struct layout mismatch between libsgw.so and the ctypes mirror "
                    "(spec %d vs %d, out %d vs %d)" % (L.sgw_sizeof_spec(), C.sizeof(Spec),
                                                       L.sgw_sizeof_out(), C.sizeof(Out)))
+  if L.sgw_sizeof_extras() != C.sizeof(Extras):
+    raise SgwError("struct layout mismatch: sgw_extras %d vs %d" % (L.sgw_sizeof_extras(), C.sizeof(Extras)))
   _lib = L
   return L
 
 
 EXPORTS = [
-    "sgw_abi_version", "sgw_last_error", "sgw_sizeof_spec", "sgw_sizeof_out", "sgw_create",
+    "sgw_abi_version", "sgw_last_error", "sgw_sizeof_spec", "sgw_sizeof_out", "sgw_sizeof_extras", "sgw_create", "sgw_track_performance", "sgw_step_full",
     "sgw_destroy", "sgw_n_envs", "sgw_n_pad", "sgw_state_bytes", "sgw_set_episode_bits",
     "sgw_set_rng_state", "sgw_set_random_stream", "sgw_set_family_table", "sgw_pow_f64", "sgw_pow_selfcheck", "sgw_reset", "sgw_step", "sgw_step_n", "sgw_rollout", "sgw_replay", "sgw_group_create", "sgw_group_destroy", "sgw_group_step_n", "sgw_group_rollout", "sgw_read_returns", "sgw_fill_actions",
     "sgw_accumulate_returns", "sgw_observe", "sgw_derived_stats", "sgw_observe_layers", "sgw_state_layers", "sgw_view_bytes", "sgw_agent_views", "sgw_agent_layer_views", "sgw_state_words", "sgw_get_state", "sgw_set_state"]

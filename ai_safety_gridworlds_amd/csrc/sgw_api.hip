@@ -72,11 +72,16 @@ struct sgw_engine {
   std::vector<StepGraph> graphs;
   hipStream_t capture_stream;
   unsigned lds_cap_raised; // bit KIND: this engine's k_engine<F, KIND> may use more than 64 KiB of dynamic LDS (set once)
+  // sgw_step_full: one captured graph per (actions, out, extras) triple
+  struct FullGraph { const int8_t* actions; sgw_out out; sgw_extras ex; long long last_use; hipGraphExec_t exec; };
+  std::vector<FullGraph> full_graphs;
 };
 
 static void drop_graphs(sgw_engine* e) {      // any setter that changes what a launch's arguments hold invalidates the captures
   for (auto& g : e->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   e->graphs.clear();
+  for (auto& g : e->full_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  e->full_graphs.clear();
 }
 
 // island_navigation_ex: the packed (i16) state when the spec proves it exact (sgw_island.hpp); SGW_ISLAND_PLAIN_STATE in the
@@ -133,6 +138,7 @@ int sgw_abi_version(void) { return SGW_ABI_VERSION; }
 const char* sgw_last_error(void) { return g_err; }
 int sgw_sizeof_spec(void) { return (int)sizeof(sgw_spec); }
 int sgw_sizeof_out(void) { return (int)sizeof(sgw_out); }
+int sgw_sizeof_extras(void) { return (int)sizeof(sgw_extras); }
 int64_t sgw_pow_selfcheck(void) { return (int64_t)pow_selfcheck(); }
 
 int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int device, sgw_engine** out_engine) {
@@ -797,16 +803,46 @@ int sgw_accumulate_returns(sgw_engine* e, const double* cumulative_dev, const ui
   return SGW_OK;
 }
 
+// ceil(2^32 / x) for div_recip (sgw_kernels.hpp): exact for every f <= f_max, or 0xffffffff... refused by the caller
+static bool plane_geom(int HW, int P, PlaneGeom& g) {
+  auto recip = [](uint64_t x, uint64_t f_max, uint32_t& out) {
+    if (x <= 1) { out = 0; return true; }
+    const uint64_t r = ((1ull << 32) + x - 1) / x, err = r * x - (1ull << 32);
+    out = (uint32_t)r;
+    return f_max * err < (1ull << 32);
+  };
+  g.HW = HW; g.P = P;
+  uint32_t a = 0, b = 0;
+  const uint64_t total = (uint64_t)PLANES_ENVS * P * HW;
+  const bool ok = recip((uint64_t)P * HW, total, a) && recip((uint64_t)HW, total, b);
+  g.recip_PHW = (int)a; g.recip_HW = (int)b;
+  return ok;
+}
+static int raise_lds_cap(sgw_engine* e, const void* fn, size_t lds, unsigned bit) {
+  if (lds > 160 * 1024) return fail(SGW_ERR_UNSUPPORTED, "observe: the board is too large for the plane kernels' LDS staging");
+  if (lds > 65536 && !(e->lds_cap_raised & bit)) {
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    e->lds_cap_raised |= bit;
+  }
+  return SGW_OK;
+}
+
 int sgw_observe(sgw_engine* e, const uint8_t* board_dev, const uint8_t* rgb_lut_dev, uint8_t* rgb_dev,
                 const uint8_t* layer_chars_dev, int n_layers, uint8_t* layers_dev, void* stream) {
   if (!e || !board_dev) return fail(SGW_ERR_ARG, "sgw_observe: null argument");
   if (rgb_dev && !rgb_lut_dev) return fail(SGW_ERR_ARG, "sgw_observe: rgb requested without a LUT");
-  if (layers_dev && (!layer_chars_dev || n_layers < 1)) return fail(SGW_ERR_ARG, "sgw_observe: bad layer list");
+  if (layers_dev && (!layer_chars_dev || n_layers < 1 || n_layers > 128)) return fail(SGW_ERR_ARG, "sgw_observe: bad layer list");
+  if (!rgb_dev && !layers_dev) return SGW_OK;
   HIP_TRY(hipSetDevice(e->device));
-  long long total = e->n_envs * e->ks.HW;
-  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(k_observe, dim3(blocks), dim3(256), 0, (hipStream_t)stream, board_dev, e->n_envs, e->ks.HW,
-                     rgb_lut_dev, rgb_dev, layer_chars_dev, n_layers, layers_dev);
+  PlaneGeom g_rgb, g_lay;
+  if (!plane_geom(e->ks.HW, 3, g_rgb) || !plane_geom(e->ks.HW, layers_dev ? n_layers : 1, g_lay))
+    return fail(SGW_ERR_UNSUPPORTED, "sgw_observe: board / layer count outside the plane kernels' index arithmetic");
+  const size_t lds = (((size_t)PLANES_ENVS * e->ks.HW + 15) & ~(size_t)15) + 3 * 128;
+  int rc = raise_lds_cap(e, reinterpret_cast<const void*>(&k_observe), lds, 16u);
+  if (rc) return rc;
+  const unsigned blocks = (unsigned)((e->n_envs + PLANES_ENVS - 1) / PLANES_ENVS);
+  hipLaunchKernelGGL(k_observe, dim3(blocks), dim3(PLANES_THREADS), lds, (hipStream_t)stream, board_dev, (long long)e->n_envs, g_rgb,
+                     rgb_lut_dev, rgb_dev, g_lay, layer_chars_dev, layers_dev);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }
@@ -815,15 +851,22 @@ int sgw_derived_stats(sgw_engine* e, const double* reward_dev, const double* cum
                       const int32_t* k_agent, double* stats_dev, void* stream) {
   if (!e || !reward_dev || !cumulative_dev || !frame_dev || !k_agent || !stats_dev)
     return fail(SGW_ERR_ARG, "sgw_derived_stats: null argument");
+  if (((uintptr_t)reward_dev | (uintptr_t)cumulative_dev | (uintptr_t)stats_dev) & 15)
+    return fail(SGW_ERR_ARG, "sgw_derived_stats: reward / cumulative / stats must be 16-byte aligned (rows move as 16-byte accesses)");
   AgentK ak; memset(&ak, 0, sizeof(ak));
   for (int a = 0; a < e->spec.A; ++a) {
     if (k_agent[a] < 0 || k_agent[a] > e->spec.K) return fail(SGW_ERR_ARG, "sgw_derived_stats: k_agent out of range");
     ak.k[a] = k_agent[a];
   }
   HIP_TRY(hipSetDevice(e->device));
-  const long long total = e->n_envs * e->spec.A;
-  hipLaunchKernelGGL(k_derived_stats, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)stream, reward_dev,
-                     cumulative_dev, frame_dev, e->n_envs, e->spec.A, e->spec.K, ak, stats_dev);
+  const int A = e->spec.A, K = e->spec.K;
+  const size_t lds = (size_t)(2 * A * K + A * (5 + K)) * WAVE * 8;           // R | C | O (sgw_kernels.hpp k_derived_stats)
+  if (lds > 65536 && !(e->lds_cap_raised & 8u)) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_derived_stats), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    e->lds_cap_raised |= 8u;
+  }
+  hipLaunchKernelGGL(k_derived_stats, dim3((unsigned)((e->n_envs + WAVE - 1) / WAVE)), dim3(WAVE), lds, (hipStream_t)stream, reward_dev,
+                     cumulative_dev, frame_dev, e->n_envs, A, K, ak, ((1 << 18) + A * K - 1) / (A * K), stats_dev);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }
@@ -835,12 +878,19 @@ int sgw_observe_layers(sgw_engine* e, const uint8_t* board_dev, const uint8_t* l
     return fail(SGW_ERR_ARG, "sgw_observe_layers: agent_pos/agent_flags/hidden_layer mismatch");
   if (!e || !board_dev || !layer_chars_dev || !layer_static_dev || !layers_dev || n_layers < 1 || gap_index >= n_layers)
     return fail(SGW_ERR_ARG, "sgw_observe_layers: bad argument");
+  if (n_layers > 32) return fail(SGW_ERR_UNSUPPORTED, "sgw_observe_layers: at most 32 layers (a cell's layers are one 32-bit mask)");
   HIP_TRY(hipSetDevice(e->device));
-  long long total = e->n_envs * e->ks.HW;
-  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(k_observe_layers, dim3(blocks), dim3(256), 0, (hipStream_t)stream, board_dev, e->n_envs, e->ks.HW,
-                     e->ks.W, layer_chars_dev, layer_static_dev, n_layers, gap_index, agent_pos_dev, agent_flags_dev,
-                     e->spec.A, agent_pos_dev ? hidden_layer : -1, layers_dev);
+  PlaneGeom g;
+  if (!plane_geom(e->ks.HW, n_layers, g))
+    return fail(SGW_ERR_UNSUPPORTED, "sgw_observe_layers: board / layer count outside the plane kernels' index arithmetic");
+  const size_t HW = (size_t)e->ks.HW;
+  const size_t lds = ((PLANES_ENVS * HW + 15) & ~(size_t)15) + PLANES_ENVS * HW * 4 + HW * 8 + 512;   // boards | masks | dyn, on | per-char
+  int rc = raise_lds_cap(e, reinterpret_cast<const void*>(&k_observe_layers), lds, 32u);
+  if (rc) return rc;
+  const unsigned blocks = (unsigned)((e->n_envs + PLANES_ENVS - 1) / PLANES_ENVS);
+  hipLaunchKernelGGL(k_observe_layers, dim3(blocks), dim3(PLANES_THREADS), lds, (hipStream_t)stream, board_dev, (long long)e->n_envs, g,
+                     e->ks.W, layer_chars_dev, layer_static_dev, gap_index, agent_pos_dev, agent_flags_dev, e->spec.A,
+                     agent_pos_dev ? hidden_layer : -1, layers_dev);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }
@@ -943,6 +993,102 @@ int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_
   hipLaunchKernelGGL(k_agent_layer_views, dim3(blocks), dim3(256), 4 * lds_per_wave, (hipStream_t)stream, layers_dev, agent_pos_dev,
                      agent_flags_dev, e->n_envs, v, layer_chars_dev, n_layers, outside_chr, out_dev, lds_per_wave);
   HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
+int sgw_track_performance(sgw_engine* e, const double* perf_dev, int n_cols, const uint8_t* step_type_dev, double* last_dev,
+                          double* sum_dev, int64_t* count_dev, uint8_t* done_dev, void* stream) {
+  if (!e || !perf_dev || !step_type_dev || n_cols < 1) return fail(SGW_ERR_ARG, "sgw_track_performance: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  const long long total = e->n_envs * n_cols;
+  const int per_agent = (e->spec.family == SGW_ISLAND_NAVIGATION_EX_MA || e->spec.family == SGW_AINTELOPE_SAVANNA) ? 1 : 0;
+  hipLaunchKernelGGL(k_track_performance, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, perf_dev, n_cols,
+                     step_type_dev, e->spec.A, per_agent, (long long)e->n_envs, last_dev, sum_dev, reinterpret_cast<long long*>(count_dev), done_dev);
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
+static int step_full_launches(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, const sgw_extras* x, void* stream) {
+  int rc = sgw_step(e, actions_dev, out, stream);
+  if (rc || !x) return rc;
+  if (x->rgb) { rc = sgw_observe(e, out->board, x->rgb_lut_dev, x->rgb, nullptr, 0, nullptr, stream); if (rc) return rc; }
+  if (x->layers) {
+    if (e->spec.family == SGW_AINTELOPE_SAVANNA) rc = sgw_state_layers(e, x->layer_chars_dev, x->n_layers, 1, x->layers, stream);
+    else rc = sgw_observe_layers(e, out->board, x->layer_chars_dev, x->layer_static_dev, x->n_layers, x->gap_index,
+                                 x->hidden_layer >= 0 ? out->agent_pos : nullptr, x->hidden_layer >= 0 ? out->agent_flags : nullptr,
+                                 x->hidden_layer, x->layers, stream);
+    if (rc) return rc;
+  }
+  if (x->agent_layer_views) {
+    const bool rot = e->spec.family != SGW_FIREMAKER_EX_MA;      // the families with observation directions rotate by agent_flags (UP = none)
+    rc = sgw_agent_layer_views(e, x->layers, out->agent_pos, rot ? out->agent_flags : nullptr, x->layer_chars_dev, x->n_layers,
+                               (uint8_t)(e->ks.view_pad), x->agent_layer_views, stream);
+    if (rc) return rc;
+  }
+  if (x->stats) { rc = sgw_derived_stats(e, out->reward, out->cumulative, out->frame, x->k_agent, x->stats, stream); if (rc) return rc; }
+  if (x->perf_last || x->perf_sum || x->perf_count || x->done) {
+    const double* src = x->perf_from_hidden ? out->hidden : out->cumulative;
+    rc = sgw_track_performance(e, src, x->perf_from_hidden ? 1 : e->spec.A * e->spec.K, out->step_type, x->perf_last, x->perf_sum, x->perf_count,
+                               x->done, stream);
+    if (rc) return rc;
+  }
+  return SGW_OK;
+}
+
+int sgw_step_full(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, const sgw_extras* x, void* stream) {
+  if (!e || !actions_dev || !out) return fail(SGW_ERR_ARG, "sgw_step_full: null argument");
+  if (x) {
+    if ((x->rgb || (x->layers && e->spec.family != SGW_AINTELOPE_SAVANNA)) && !out->board)
+      return fail(SGW_ERR_ARG, "sgw_step_full: rgb / layers need the board output");
+    if (x->rgb && !x->rgb_lut_dev) return fail(SGW_ERR_ARG, "sgw_step_full: rgb requested without a LUT");
+    if (x->layers && (!x->layer_chars_dev || x->n_layers < 1)) return fail(SGW_ERR_ARG, "sgw_step_full: bad layer list");
+    if (x->layers && x->hidden_layer >= 0 && (!out->agent_pos || !out->agent_flags))
+      return fail(SGW_ERR_ARG, "sgw_step_full: a hidden drape layer needs the agent_pos and agent_flags outputs");
+    if (x->agent_layer_views && (!x->layers || !out->agent_pos || !out->agent_flags))
+      return fail(SGW_ERR_ARG, "sgw_step_full: agent layer cubes need `layers` and the agent_pos / agent_flags outputs");
+    if (x->stats && (!out->reward || !out->cumulative || !out->frame))
+      return fail(SGW_ERR_ARG, "sgw_step_full: stats need the reward, cumulative and frame outputs");
+    if ((x->perf_last || x->perf_sum || x->perf_count || x->done) && (!out->step_type || !(x->perf_from_hidden ? (const void*)out->hidden : (const void*)out->cumulative)))
+      return fail(SGW_ERR_ARG, "sgw_step_full: performance bookkeeping needs step_type and the cumulative (or hidden) output");
+  }
+  const hipStream_t st = (hipStream_t)stream;
+  sgw_extras key_x; memset(&key_x, 0, sizeof(key_x));
+  if (x) key_x = *x;
+  if (step_graphs_min_T() > 8) return step_full_launches(e, actions_dev, out, x, stream);     // SGW_STEP_GRAPHS=0
+  sgw_engine::FullGraph* hit = nullptr;
+  for (auto& g : e->full_graphs)
+    if (g.actions == actions_dev && memcmp(&g.out, out, sizeof(sgw_out)) == 0 && memcmp(&g.ex, &key_x, sizeof(key_x)) == 0) { hit = &g; break; }
+  if (!hit) {
+    while (e->full_graphs.size() >= 16) {
+      size_t worst = 0;
+      for (size_t i = 1; i < e->full_graphs.size(); ++i) if (e->full_graphs[i].last_use < e->full_graphs[worst].last_use) worst = i;
+      if (e->full_graphs[worst].exec) (void)hipGraphExecDestroy(e->full_graphs[worst].exec);
+      e->full_graphs.erase(e->full_graphs.begin() + worst);
+    }
+    sgw_engine::FullGraph g; memset(&g, 0, sizeof(g));
+    g.actions = actions_dev; g.out = *out; g.ex = key_x; g.last_use = ++e->graph_tick; g.exec = nullptr;
+    e->full_graphs.push_back(g);
+    return step_full_launches(e, actions_dev, out, x, stream);
+  }
+  hit->last_use = ++e->graph_tick;
+  if (!hit->exec) {
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->capture_stream) HIP_TRY(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = step_full_launches(e, actions_dev, out, x, e->capture_stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(e->capture_stream, &graph);
+    if (rc || ec != hipSuccess || !graph) {
+      if (graph) (void)hipGraphDestroy(graph);
+      if (rc) return rc;
+      return fail(SGW_ERR_HIP, "sgw_step_full: stream capture failed");
+    }
+    const hipError_t ei = hipGraphInstantiate(&hit->exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { hit->exec = nullptr; return fail(SGW_ERR_HIP, "sgw_step_full: hipGraphInstantiate failed"); }
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipGraphLaunch(hit->exec, st));
   return SGW_OK;
 }
 

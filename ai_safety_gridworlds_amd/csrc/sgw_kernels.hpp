@@ -883,6 +883,23 @@ __global__ void k_accumulate_returns(const double* cumulative, const uint8_t* st
   if ((threadIdx.x & (WAVE - 1)) == 0 && c != 0.0) atomicAdd(&accum[AK], c);
 }
 
+// _episodic_performances bookkeeping per env (safety_game.py:194-263): at a LAST timestep the episode's performance becomes the
+// env's last performance and joins its running sum and count
+__global__ void k_track_performance(const double* perf, int C, const uint8_t* step_type, int A, int per_agent, long long n, double* last,
+                                    double* sum, long long* count, uint8_t* done_out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * C) return;
+  const long long e = i / C;
+  bool done = step_type[e * A] == ST_LAST;
+  if (per_agent) { done = true; for (int ag = 0; ag < A; ++ag) done = done && step_type[e * A + ag] >= ST_LAST; }
+  if (done_out && i == e * C) done_out[e] = done ? 1 : 0;
+  if (!done) return;
+  const double v = perf[i];
+  if (last) last[i] = v;
+  if (sum) sum[i] += v;
+  if (count && i == e * C) count[e] += 1;
+}
+
 __global__ void k_pow(const double* x, double y, double* out, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = sgw_glibc_pow(x[i], y);
@@ -924,77 +941,290 @@ __global__ void k_state_init(uint64_t* state, long long n_pad, int words) {
 }
 
 // ---- derived statistics (safety_game_mo.py:1027-1084) in numpy's summation order -----------------------------
-// numpy pairwise_sum for a contiguous double array (umath loops): n < 8 sequential; n <= 128 eight accumulators
-// over blocks of 8, tree-combined, remainder added sequentially; larger n split recursively (n2 = n/2 rounded
-// down to a multiple of 8).  Here n <= 256 (K <= 16, K*K outer differences).
-__device__ inline double np_pairwise_block(const double* a, int n) {
-  if (n < 8) { double r = 0.0; for (int i = 0; i < n; ++i) r += a[i]; return r; }
-  double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
-  int i = 8;
-  for (; i < n - (n % 8); i += 8) { r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3]; r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7]; }
-  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-  for (; i < n; ++i) res += a[i];
-  return res;
+// numpy pairwise_sum for a contiguous double array (umath loops): n < 8 sequential from 0.0; n <= 128 eight accumulators
+// over blocks of 8, tree-combined, remainder added sequentially; larger n split once (n2 = n/2 rounded down to a
+// multiple of 8: both halves <= 128 for n <= 256 = K * K outer differences, K <= 16).  Everything is unrolled at compile time
+// for the agent's number of dimensions K (a switch over 1..16): the element index is a constant, so the vectors stay in
+// registers and a sum over |d_i - d_j| needs no array of the K * K differences (round 2 kept one per thread: 2.6 KB of scratch
+// per lane; a version that streamed the vectors from LDS at run-time indices was bound by serial LDS round trips, 23 us).
+template <int T0, int N, class Get> __device__ __forceinline__ double np_block_c(Get& get) {
+  if constexpr (N < 8) {
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r += get(T0 + i);
+    return r;
+  } else {
+    double r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = get(T0 + u);
+#pragma unroll
+    for (int i = 8; i < N - (N % 8); i += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] += get(T0 + i + u);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+    for (int i = N - (N % 8); i < N; ++i) res += get(T0 + i);
+    return res;
+  }
 }
-__device__ inline double np_sum(const double* a, int n) {
-  if (n <= 128) return np_pairwise_block(a, n);
-  int n2 = n / 2; n2 -= n2 % 8;
-  return np_sum(a, n2) + np_sum(a + n2, n - n2);
+template <int N, class Get> __device__ __forceinline__ double np_sum_c(Get get) {
+  if constexpr (N <= 128) return np_block_c<0, N>(get);
+  else {
+    constexpr int n2 = (N / 2) - ((N / 2) % 8);
+    const double lo = np_block_c<0, n2>(get);
+    return lo + np_block_c<n2, N - n2>(get);
+  }
 }
-__device__ inline double np_gini100(const double* v, int k, double* scratch) {   // gini_coefficient(...) * 100
-  if (k == 0) return 0.0;
+template <int K> __device__ __forceinline__ double np_gini100_c(const double (&v)[K]) {      // gini_coefficient(...) * 100 (1645-1681)
   double mn = v[0];
-  for (int i = 1; i < k; ++i) mn = v[i] < mn ? v[i] : mn;                         // python min()
-  double d[SGW_MAX_K];
-  for (int i = 0; i < k; ++i) d[i] = v[i] - mn;
-  for (int i = 0; i < k; ++i) for (int j = 0; j < k; ++j) scratch[i * k + j] = fabs(d[i] - d[j]);
-  const double mad = np_sum(scratch, k * k) / (double)(k * k);
-  const double rel = mad / (np_sum(d, k) / (double)k + 2.220446049250313e-16);
+#pragma unroll
+  for (int i = 1; i < K; ++i) mn = v[i] < mn ? v[i] : mn;                                   // python min()
+  double d[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) d[i] = v[i] - mn;
+  const double mad = np_sum_c<K * K>([&](int t) { return fabs(d[t / K] - d[t % K]); }) / (double)(K * K);
+  const double rel = mad / (np_sum_c<K>([&](int i) { return d[i]; }) / (double)K + 2.220446049250313e-16);
   return 0.5 * rel * 100.0;
 }
-__device__ inline double np_var(const double* v, int k, double* scratch) {        // np.var(list, ddof=0)
-  const double mean = np_sum(v, k) / (double)k;
-  for (int i = 0; i < k; ++i) { const double x = v[i] - mean; scratch[i] = x * x; }
-  return np_sum(scratch, k) / (double)k;
+template <int K> __device__ __forceinline__ double np_var_c(const double (&v)[K]) {          // np.var(list, ddof=0)
+  const double mean = np_sum_c<K>([&](int i) { return v[i]; }) / (double)K;
+  double x[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) { const double y = v[i] - mean; x[i] = y * y; }
+  return np_sum_c<K>([&](int i) { return x[i]; }) / (double)K;
 }
 struct AgentK { int k[SGW_MAX_AGENTS]; };
-__global__ void k_derived_stats(const double* reward, const double* cumulative, const int* frame, long long n, int A, int K,
-                                AgentK ak, double* stats) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * A) return;
-  const long long e = i / A;
-  const int ag = (int)(i % A), k = ak.k[ag];
-  double r[SGW_MAX_K], c[SGW_MAX_K], avg[SGW_MAX_K], scratch[SGW_MAX_K * SGW_MAX_K];
-  const double denom = (double)(frame[e] + 1);
-  for (int j = 0; j < k; ++j) { r[j] = reward[i * K + j]; c[j] = cumulative[i * K + j]; avg[j] = c[j] / denom; }
-  double* o = stats + i * (5 + K);
-  o[0] = np_gini100(r, k, scratch);
-  o[1] = np_gini100(c, k, scratch);
-  o[2] = np_var(r, k, scratch);
-  o[3] = np_var(c, k, scratch);
-  o[4] = np_var(avg, k, scratch);
-  for (int j = 0; j < K; ++j) o[5 + j] = j < k ? avg[j] : 0.0;
+// one agent's statistics for this lane's env: vectors from the transposed LDS rows into registers, results into the lane's
+// output row in LDS
+template <int K> __device__ __noinline__ void derived_agent(const double* Rv, const double* Cv, double denom, double* o, int Kout, int lane) {
+  double r[K], c[K], avg[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) { r[i] = Rv[i * WAVE + lane]; c[i] = Cv[i * WAVE + lane]; }
+#pragma unroll
+  for (int i = 0; i < K; ++i) avg[i] = c[i] / denom;
+  o[0] = np_gini100_c<K>(r);
+  o[1] = np_gini100_c<K>(c);
+  o[2] = np_var_c<K>(r);
+  o[3] = np_var_c<K>(c);
+  o[4] = np_var_c<K>(avg);
+#pragma unroll
+  for (int j = 0; j < K; ++j) o[5 + j] = avg[j];
+  for (int j = K; j < Kout; ++j) o[5 + j] = 0.0;
+}
+// One wave per 64 envs.  The wave's 64 x A rows of `reward` and `cumulative` are contiguous in global memory: they come in as
+// 16-byte loads and are transposed through LDS as [agent][dimension][lane] (a lane then reads its own vector conflict-free);
+// the wave's 64 x A x (5 + K) results are staged in LDS and leave as 16-byte stores.
+// LDS (dynamic): R [A][K][64] | C [A][K][64] | O [64 * A * (5 + K)] doubles.
+__global__ __launch_bounds__(WAVE) void k_derived_stats(const double* reward, const double* cumulative, const int* frame, long long n, int A, int K,
+                                                        AgentK ak, int recip_K, double* stats) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t ds_lds[];
+  const int lane = threadIdx.x;
+  const long long env0 = (long long)blockIdx.x * WAVE, env = env0 + lane;
+  const int AK = A * K, S = 5 + K;
+  double* R = reinterpret_cast<double*>(ds_lds);
+  double* Cm = R + AK * WAVE;
+  double* O = Cm + AK * WAVE;
+  // ---- rows in: element e of the wave's block (row-major [64][A][K]) -> [agent * K + dim][lane]
+  const long long rows_left = n - env0;
+  const int nrow = rows_left < WAVE ? (int)rows_left : WAVE;        // a ragged last wave reads only its own rows
+  const int nel = nrow * AK;
+  const double* gr = reward + env0 * AK;
+  const double* gc = cumulative + env0 * AK;
+  for (int e0 = 2 * lane; e0 < WAVE * AK; e0 += 2 * WAVE) {
+    double r0 = 0.0, r1 = 0.0, c0 = 0.0, c1 = 0.0;
+    if (e0 + 1 < nel) {
+      const double2 rv = *reinterpret_cast<const double2*>(gr + e0), cv = *reinterpret_cast<const double2*>(gc + e0);
+      r0 = rv.x; r1 = rv.y; c0 = cv.x; c1 = cv.y;
+    } else if (e0 < nel) { r0 = gr[e0]; c0 = gc[e0]; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = e0 + h;
+      const int row = (e * recip_K) >> 18;                          // e / (A * K): exact for e < 64 * 64 (host-computed ceil(2^18 / (A K)))
+      const int col = e - row * AK;
+      R[col * WAVE + row] = h ? r1 : r0;
+      Cm[col * WAVE + row] = h ? c1 : c0;
+    }
+  }
+  const double denom = (double)((env < n ? frame[env] : 0) + 1);
+  lds_wave_sync();
+  for (int ag = 0; ag < A; ++ag) {
+    const double* Rv = R + ag * K * WAVE;
+    const double* Cv = Cm + ag * K * WAVE;
+    double* o = O + (lane * A + ag) * S;
+    switch (ak.k[ag]) {                                             // uniform
+#define SGW_DS_CASE(KK) case KK: derived_agent<KK>(Rv, Cv, denom, o, K, lane); break;
+      SGW_DS_CASE(1) SGW_DS_CASE(2) SGW_DS_CASE(3) SGW_DS_CASE(4) SGW_DS_CASE(5) SGW_DS_CASE(6) SGW_DS_CASE(7) SGW_DS_CASE(8)
+      SGW_DS_CASE(9) SGW_DS_CASE(10) SGW_DS_CASE(11) SGW_DS_CASE(12) SGW_DS_CASE(13) SGW_DS_CASE(14) SGW_DS_CASE(15) SGW_DS_CASE(16)
+#undef SGW_DS_CASE
+      default: {                                                    // an agent without reward dimensions (an absent slot)
+        const double nan = __longlong_as_double(0x7ff8000000000000LL);
+        o[0] = 0.0; o[1] = 0.0; o[2] = nan; o[3] = nan; o[4] = nan;
+        for (int j = 0; j < K; ++j) o[5 + j] = 0.0;
+      }
+    }
+  }
+  lds_wave_sync();
+  // ---- results out: the wave's nrow * A * S doubles are contiguous
+  const int nout = nrow * A * S;
+  double* g = stats + env0 * A * S;
+  for (int e0 = 2 * lane; e0 < nout; e0 += 2 * WAVE) {
+    if (e0 + 1 < nout) *reinterpret_cast<double2*>(g + e0) = *reinterpret_cast<const double2*>(O + e0);
+    else g[e0] = O[e0];
+  }
 }
 
-// unoccluded layers + gap correction (rendering.py:188-302, observation_distiller_ex.py:164-178); thread per cell
-__global__ void k_observe_layers(const uint8_t* board, long long n, int HW, int W, const uint8_t* chars, const uint8_t* stat,
-                                 int L, int gap, const uint8_t* pos, const uint8_t* flags, int A, int hidden, uint8_t* layers) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = n * HW;
-  for (; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long e = i / HW;
-    const int c = (int)(i % HW);
-    const uint8_t ch = board[i] & 0x7f;
-    bool any_other = false;
-    for (int k = 0; k < L; ++k) {
-      const uint8_t st = stat[k * HW + c];
-      bool on = st == 2 ? (ch == chars[k]) : (st != 0);
-      if (k == hidden && pos)
-        for (int ag = 0; ag < A; ++ag)
-          on |= (flags[e * A + ag] & 1) && ((int)pos[(e * A + ag) * 2] * W + (int)pos[(e * A + ag) * 2 + 1] == c);
-      if (k != gap) { any_other |= on; layers[(e * L + k) * HW + c] = (uint8_t)on; }
+// ---- per-character planes of a rendered board: RGB, occluded layers, unoccluded layers ---------------------------------------
+// Every one of these outputs is [N][P planes][H*W] bytes with byte (e, p, c) a function of plane p and of what is at cell c of
+// env e.  A workgroup takes 64 envs: their board rows (contiguous) come in as 16-byte loads into LDS, phase 1 reduces a cell to
+// a CODE (the ascii code, or the bit mask of the layers that are on there), and phase 2 writes the block's 64 * P * HW
+// contiguous output bytes 16 at a time -- a lane walks (env, plane, cell) forward by one from the chunk's first byte, whose
+// coordinates come from two reciprocal multiplies, instead of dividing per byte.  (Round 2: one thread per cell, an integer
+// division each, P one-byte stores at a stride of HW.)
+constexpr int PLANES_THREADS = 256, PLANES_ENVS = 64;
+struct PlaneGeom { int HW, P, recip_PHW, recip_HW; };                // recip_x = ceil(2^32 / x) as uint32: (f * recip) >> 32 == f / x for f < 2^20
+__device__ inline uint32_t div_recip(uint32_t f, uint32_t recip) { return recip ? (uint32_t)(((uint64_t)f * recip) >> 32) : f; }   // recip 0: x == 1
+// phase 2.  value(p, code) -> output byte
+template <class Value>
+__device__ inline void planes_expand(uint8_t* out_block, const PlaneGeom& g, int n_env, Value value) {
+  const uint32_t per_env = (uint32_t)(g.P * g.HW), total = (uint32_t)n_env * per_env;
+  for (uint32_t f0 = 16u * threadIdx.x; f0 < total; f0 += 16u * PLANES_THREADS) {
+    uint32_t e = div_recip(f0, (uint32_t)g.recip_PHW), rem = f0 - e * per_env;
+    uint32_t p = div_recip(rem, (uint32_t)g.recip_HW), c = rem - p * (uint32_t)g.HW;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const uint32_t v = f0 + b < total ? (uint32_t)value((int)p, (int)e, (int)c) & 0xffu : 0u;
+      w[b >> 2] |= v << (8 * (b & 3));
+      if (++c == (uint32_t)g.HW) { c = 0; if (++p == (uint32_t)g.P) { p = 0; ++e; } }
     }
-    if (gap >= 0) layers[(e * L + gap) * HW + c] = (uint8_t)((stat[gap * HW + c] != 0) && !any_other);
+    if (f0 + 16u <= total) *reinterpret_cast<uint4*>(out_block + f0) = make_uint4(w[0], w[1], w[2], w[3]);
+    else for (uint32_t b = 0; f0 + b < total; ++b) out_block[f0 + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+  }
+}
+// phase 2 when H*W is a multiple of 4: every output row (env, plane) starts on a dword, so a lane takes FOUR consecutive cells of
+// an env, fetches their codes once and writes one aligned dword per plane -- consecutive lanes write consecutive dwords of a
+// row.  dword(p, codes of the 4 cells) -> the 4 output bytes
+template <class Dword4>
+__device__ inline void planes_expand4(uint8_t* out_block, const PlaneGeom& g, int n_env, Dword4 dword4) {
+  const int HW = g.HW, q = HW >> 2, items = n_env * q;
+  for (int i = threadIdx.x; i < items; i += PLANES_THREADS) {
+    const int e = (int)div_recip((uint32_t)(4 * i), (uint32_t)g.recip_HW), c = 4 * i - e * HW;
+    uint32_t* row = reinterpret_cast<uint32_t*>(out_block + (size_t)e * g.P * HW + c);
+    dword4(e, c, [&](int p, uint32_t v) { row[p * q] = v; });
+  }
+}
+// the block's board rows -> LDS (16-byte loads; 64 * HW is a multiple of 16 and the block starts on one)
+__device__ inline void planes_load_boards(const uint8_t* board, long long env0, int n_env, int HW, uint8_t* lds_board) {
+  const uint4* src = reinterpret_cast<const uint4*>(board + env0 * HW);
+  const int bytes = n_env * HW, n16 = (reinterpret_cast<uintptr_t>(board) & 15) ? 0 : bytes >> 4;      // a caller's unaligned slice: bytes
+  for (int j = threadIdx.x; j < n16; j += PLANES_THREADS) reinterpret_cast<uint4*>(lds_board)[j] = src[j];
+  for (int j = (n16 << 4) + threadIdx.x; j < bytes; j += PLANES_THREADS) lds_board[j] = board[env0 * HW + j];     // ragged last block
+}
+
+// observation distiller extras from an ascii board (observation_distiller.py:30-91, rendering.py:69-185): RGB planes via the
+// colour LUT and OCCLUDED per-character layers (board == char).  LDS: boards [64 * HW] | table [P][128]
+__global__ __launch_bounds__(PLANES_THREADS) void k_observe(const uint8_t* board, long long n, PlaneGeom g_rgb, const uint8_t* rgb_lut, uint8_t* rgb,
+                                                            PlaneGeom g_lay, const uint8_t* layer_chars, uint8_t* layers) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t pl_lds[];
+  const int HW = g_rgb.HW;
+  const long long env0 = (long long)blockIdx.x * PLANES_ENVS;
+  const int n_env = n - env0 < PLANES_ENVS ? (int)(n - env0) : PLANES_ENVS;
+  uint8_t* bl = pl_lds;
+  uint8_t* tab = pl_lds + ((PLANES_ENVS * HW + 15) & ~15);
+  planes_load_boards(board, env0, n_env, HW, bl);
+  if (rgb) {
+    for (int i = threadIdx.x; i < 3 * 128; i += PLANES_THREADS) tab[i] = rgb_lut[(i & 127) * 3 + (i >> 7)];        // [plane][char]
+    __syncthreads();
+    if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(rgb) & 3) == 0) {
+      planes_expand4(rgb + env0 * 3 * HW, g_rgb, n_env, [&](int e, int c, auto put) {
+        const uint32_t b4 = *reinterpret_cast<const uint32_t*>(bl + e * HW + c);
+        const uint32_t c0 = b4 & 0x7f, c1 = (b4 >> 8) & 0x7f, c2 = (b4 >> 16) & 0x7f, c3 = (b4 >> 24) & 0x7f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const uint8_t* t = tab + p * 128;
+          put(p, (uint32_t)t[c0] | ((uint32_t)t[c1] << 8) | ((uint32_t)t[c2] << 16) | ((uint32_t)t[c3] << 24));
+        }
+      });
+    } else {
+      planes_expand(rgb + env0 * 3 * HW, g_rgb, n_env, [&](int p, int e, int c) { return tab[p * 128 + (bl[e * HW + c] & 0x7f)]; });
+    }
+  }
+  if (layers) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < g_lay.P; i += PLANES_THREADS) tab[i] = layer_chars[i];
+    __syncthreads();
+    if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(layers) & 3) == 0) {
+      planes_expand4(layers + env0 * g_lay.P * HW, g_lay, n_env, [&](int e, int c, auto put) {
+        const uint32_t b4 = *reinterpret_cast<const uint32_t*>(bl + e * HW + c) & 0x7f7f7f7fu;
+        for (int p = 0; p < g_lay.P; ++p) put(p, bytes_equal_mask(b4, 0x01010101u * tab[p]) & 0x01010101u);
+      });
+    } else {
+      planes_expand(layers + env0 * g_lay.P * HW, g_lay, n_env, [&](int p, int e, int c) { return (uint8_t)((bl[e * HW + c] & 0x7f) == tab[p]); });
+    }
+  }
+}
+
+// unoccluded layers + gap correction (rendering.py:188-302, observation_distiller_ex.py:164-178).  Phase 1 reduces cell (e, c)
+// to the bit mask of the layers that are on there: a dynamic layer (stat 2: sprite / moving drape) where the board shows its
+// character, a static curtain (stat 1) always, the hidden drape under an agent that covers it (firemaker's fire), and the
+// what_lies_beneath layer only where every other layer is blank.  LDS: boards [64 * HW] | masks u32 [64 * HW] | per-cell tables
+// dyn u32 [HW], on u32 [HW] | per-char table u32 [128]
+__global__ __launch_bounds__(PLANES_THREADS) void k_observe_layers(const uint8_t* board, long long n, PlaneGeom g, int W, const uint8_t* chars,
+                                                                   const uint8_t* stat, int gap, const uint8_t* pos, const uint8_t* flags, int A,
+                                                                   int hidden, uint8_t* layers) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t pl_lds[];
+  const int HW = g.HW, L = g.P;
+  const long long env0 = (long long)blockIdx.x * PLANES_ENVS;
+  const int n_env = n - env0 < PLANES_ENVS ? (int)(n - env0) : PLANES_ENVS;
+  uint8_t* bl = pl_lds;
+  uint32_t* mask = reinterpret_cast<uint32_t*>(pl_lds + ((PLANES_ENVS * HW + 15) & ~15));
+  uint32_t* dyn = mask + PLANES_ENVS * HW;
+  uint32_t* on = dyn + HW;
+  uint32_t* chm = on + HW;
+  planes_load_boards(board, env0, n_env, HW, bl);
+  for (int c = threadIdx.x; c < HW; c += PLANES_THREADS) {
+    uint32_t d = 0u, o = 0u;
+    for (int k = 0; k < L; ++k) { const uint8_t st = stat[k * HW + c]; d |= (st == 2 ? 1u : 0u) << k; o |= ((st != 0 && st != 2) ? 1u : 0u) << k; }
+    dyn[c] = d; on[c] = o;
+  }
+  for (int ch = threadIdx.x; ch < 128; ch += PLANES_THREADS) {
+    uint32_t m = 0u;
+    for (int k = 0; k < L; ++k) m |= (chars[k] == ch ? 1u : 0u) << k;
+    chm[ch] = m;
+  }
+  __syncthreads();
+  const uint32_t gapbit = gap >= 0 ? 1u << gap : 0u;
+  for (int i = threadIdx.x; i < n_env * HW; i += PLANES_THREADS) {
+    const int e = (int)div_recip((uint32_t)i, (uint32_t)g.recip_HW), c = i - e * HW;
+    mask[i] = ((chm[bl[i] & 0x7f] & dyn[c]) | on[c]) & ~gapbit;      // the gap layer is decided below
+  }
+  __syncthreads();
+  if (pos && hidden >= 0) {                                           // the hidden drape under an agent's sprite
+    for (int i = threadIdx.x; i < n_env * A; i += PLANES_THREADS) {
+      const long long ea = env0 * A + i;
+      const int e = i / A;
+      if (flags[ea] & 1) atomicOr(&mask[e * HW + (int)pos[ea * 2] * W + (int)pos[ea * 2 + 1]], 1u << hidden);
+    }
+    __syncthreads();
+  }
+  if (gap >= 0) {
+    for (int i = threadIdx.x; i < n_env * HW; i += PLANES_THREADS) {
+      const int e = (int)div_recip((uint32_t)i, (uint32_t)g.recip_HW), c = i - e * HW;
+      const uint32_t m = mask[i];
+      const bool gap_static = ((on[c] | dyn[c]) & gapbit) != 0u;              // the layer's curtain entry is not 0
+      if (gap_static && (m & ~gapbit) == 0u) mask[i] = m | gapbit;
+    }
+    __syncthreads();
+  }
+  if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(layers) & 3) == 0) {
+    planes_expand4(layers + env0 * L * HW, g, n_env, [&](int e, int c, auto put) {
+      const uint4 m = *reinterpret_cast<const uint4*>(mask + e * HW + c);            // the four cells' layer masks: one 16-byte LDS read
+      for (int p = 0; p < L; ++p)
+        put(p, ((m.x >> p) & 1u) | (((m.y >> p) & 1u) << 8) | (((m.z >> p) & 1u) << 16) | (((m.w >> p) & 1u) << 24));
+    });
+  } else {
+    planes_expand(layers + env0 * L * HW, g, n_env, [&](int p, int e, int c) { return (uint8_t)((mask[e * HW + c] >> p) & 1u); });
   }
 }
 
@@ -1155,24 +1385,6 @@ __global__ void k_agent_layer_views(const uint8_t* layers, const uint8_t* pos, c
     const int cells = v.vh[ag] * v.vw[ag];
     view_wave(layers + (e * L + li) * (long long)(v.H * v.W), out + e * ((long long)v.total * L) + (long long)v.off[ag] * L + (long long)li * cells,
               lds, v.H, v.W, v.vh[ag], v.vw[ag], pr, pc, dir, flags != nullptr, (uint8_t)(chars[li] == outside), lane);
-  }
-}
-
-// observation distiller extras from an ascii board: RGB planes and occluded per-char layers
-__global__ void k_observe(const uint8_t* board, long long n, int HW, const uint8_t* rgb_lut, uint8_t* rgb,
-                          const uint8_t* layer_chars, int L, uint8_t* layers) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long total = n * HW;
-  for (; i < total; i += (long long)gridDim.x * blockDim.x) {
-    long long e = i / HW;
-    int c = (int)(i % HW);
-    uint8_t ch = board[i] & 0x7f;
-    if (rgb) {
-      rgb[(e * 3 + 0) * HW + c] = rgb_lut[ch * 3 + 0];
-      rgb[(e * 3 + 1) * HW + c] = rgb_lut[ch * 3 + 1];
-      rgb[(e * 3 + 2) * HW + c] = rgb_lut[ch * 3 + 2];
-    }
-    if (layers) for (int k = 0; k < L; ++k) layers[(e * L + k) * HW + c] = (uint8_t)(ch == layer_chars[k]);
   }
 }
 

@@ -15,6 +15,8 @@ import torch
 
 from . import _native as N
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
 DEFAULT_OUTPUTS = ("board", "reward", "step_type", "term_reason")
 # every family's outputs; "safety2": aintelope_savanna only; "views" / "obs_views": the families with agent windows
 ALL_OUTPUTS = tuple(f for f in N.OUT_FIELDS if f not in ("safety2", "views", "obs_views"))
@@ -106,7 +108,8 @@ class BatchedEngine(object):
     return dict(out)
 
   def _stream(self):
-    return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+    # the raw handle of torch's current stream on this device (torch.cuda.current_stream() builds a Stream object: 2 us per call)
+    return C.c_void_p(_raw_stream(self.device.index))
 
   # -- API --------------------------------------------------------------------------------------
   def reset(self, mask=None):
@@ -133,6 +136,90 @@ class BatchedEngine(object):
                          "not compatible with what the pycolab game expects.")   # pycolab_interface.py:160-163
     N.check(self._lib.sgw_step(self._h, actions.data_ptr(), C.byref(self._out), self._stream()), "sgw_step")
     return self._views()
+
+  def _agent_ks(self):
+    sp = self.spec
+    if sp.A > 1:
+      slots = getattr(sp, "agent_slots", list(range(len(sp.agent_chars))))
+      ks = [0] * sp.A                                  # by column of the library's layout; an absent agent has no dimensions
+      for c, q in zip(sp.agent_chars, slots):
+        ks[q] = len(sp.agent_dim_names[c])
+      return ks
+    return [sp.K]
+
+  def step_full(self, actions, rgb=False, layers=False, stats=False, agent_layer_views=False, performance=False):
+    """One env.step() per env AND the derived observations of that step from ONE library call (sgw_step_full: the launches are
+    chained in C and replayed as one hipGraph from the third call on): dict of the engine's outputs plus "RGB" uint8
+    [N, 3, H, W], "layers" uint8 [N, L, H, W] (unoccluded, gap-corrected), the derived statistics (gini_index, ...,
+    average_reward), "agent_layer_views" (list over agents of [N, L, h, w]) and, with `performance`, "last_performance" /
+    "performance_sum" float64 [N, C] and "episodes" int64 [N] (get_last_performance / get_overall_performance bookkeeping).
+    The extra tensors are persistent buffers, rewritten by every call, like the engine's outputs."""
+    sp = self.spec
+    if self._T != 1:
+      self._alloc_outputs(1)
+    if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
+      actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
+    if actions.numel() != self.n_envs * sp.A:
+      raise RuntimeError("A pycolab Environment adapter's step method was called with actions that were "
+                         "not compatible with what the pycolab game expects.")
+    key = (bool(rgb), bool(layers or agent_layer_views), bool(stats), bool(agent_layer_views), bool(performance))
+    fx = getattr(self, "_full", None)
+    if fx is None or fx["key"] != key or fx["for"] is not self._bufs.get("step_type", self._bufs.get("board")):
+      n, dev = self.n_envs, self.device
+      x, t, res = N.Extras(), {}, {}
+      if key[0]:
+        t["lut"] = torch.from_numpy(sp.rgb_lut().reshape(-1)).to(dev)
+        res["RGB"] = torch.empty((n, 3, sp.H, sp.W), dtype=torch.uint8, device=dev)
+        x.rgb, x.rgb_lut_dev = res["RGB"].data_ptr(), t["lut"].data_ptr()
+      if key[1]:
+        L = len(sp.layer_chars)
+        t["chars"] = torch.tensor([ord(c) for c in sp.layer_chars], dtype=torch.uint8, device=dev)
+        res["layers"] = torch.empty((n, L, sp.H, sp.W), dtype=torch.uint8, device=dev)
+        x.layers, x.layer_chars_dev, x.n_layers = res["layers"].data_ptr(), t["chars"].data_ptr(), L
+        x.gap_index = sp.layer_chars.index(sp.what_lies_beneath) if sp.what_lies_beneath in sp.layer_chars else -1
+        hidden = getattr(sp, "hidden_layer_char", None)
+        x.hidden_layer = sp.layer_chars.index(hidden) if hidden is not None else -1
+        if not getattr(sp, "layers_from_state", False):
+          t["stat"] = torch.from_numpy(sp.layer_static()).to(dev)
+          x.layer_static_dev = t["stat"].data_ptr()
+      else:
+        x.hidden_layer, x.gap_index = -1, -1
+      if key[2]:
+        t["stats"] = torch.empty((n, sp.A, 5 + sp.K), dtype=torch.float64, device=dev)
+        x.stats = t["stats"].data_ptr()
+        for i, k in enumerate(self._agent_ks()):
+          x.k_agent[i] = k
+        st = t["stats"][:, 0] if sp.A == 1 else t["stats"]
+        for i, nm in enumerate(("gini_index", "cumulative_gini_index", "mo_variance", "cumulative_mo_variance", "average_mo_variance")):
+          res[nm] = st[..., i]
+        res["average_reward"] = st[..., 5:]
+      if key[3]:
+        vb = int(self._lib.sgw_view_bytes(self._h))
+        L = len(sp.layer_chars)
+        t["cubes"] = torch.empty((n, vb * L), dtype=torch.uint8, device=dev)
+        x.agent_layer_views = t["cubes"].data_ptr()
+        cubes, off = [], 0
+        for (h, w) in sp.view_shapes:
+          cubes.append(t["cubes"][:, off:off + L * h * w].reshape(n, L, h, w))
+          off += L * h * w
+        res["agent_layer_views"] = cubes
+      if key[4]:
+        use_hidden = sp.scalar and getattr(sp, "performance", "hidden") == "hidden"
+        C_ = 1 if use_hidden else sp.A * sp.K
+        res["last_performance"] = torch.full((n, C_), float("nan"), dtype=torch.float64, device=dev)
+        res["performance_sum"] = torch.zeros((n, C_), dtype=torch.float64, device=dev)
+        res["episodes"] = torch.zeros(n, dtype=torch.int64, device=dev)
+        t["done"] = torch.zeros(n, dtype=torch.uint8, device=dev)
+        res["done"] = t["done"].view(torch.bool)                     # the episode ended with this step (the wrapper's `terminated`)
+        x.perf_from_hidden = 1 if use_hidden else 0
+        x.perf_last, x.perf_sum, x.perf_count = res["last_performance"].data_ptr(), res["performance_sum"].data_ptr(), res["episodes"].data_ptr()
+        x.done = t["done"].data_ptr()
+      fx = self._full = {"key": key, "for": self._bufs.get("step_type", self._bufs.get("board")), "x": x, "keep": t, "res": res}
+    N.check(self._lib.sgw_step_full(self._h, actions.data_ptr(), C.byref(self._out), C.byref(fx["x"]), self._stream()), "sgw_step_full")
+    if fx.get("all") is None:
+      fx["all"] = self._views()
+      fx["all"].update(fx["res"])
+    return dict(fx["all"])
 
   def step_ptr(self, actions_ptr):
     """Launch-only variant for tight loops: raw device pointer, no tensor checks, no views."""
@@ -322,13 +409,7 @@ class BatchedEngine(object):
     for k in ("reward", "cumulative", "frame"):
       if k not in self._bufs or self._T != 1:
         raise N.SgwError("derived_stats needs the 'reward', 'cumulative' and 'frame' outputs of a single step")
-    if sp.A > 1:
-      slots = getattr(sp, "agent_slots", list(range(len(sp.agent_chars))))
-      ks = [0] * sp.A                                  # by column of the library's layout; an absent agent has no dimensions
-      for c, q in zip(sp.agent_chars, slots):
-        ks[q] = len(sp.agent_dim_names[c])
-    else:
-      ks = [sp.K]
+    ks = self._agent_ks()
     karr = (C.c_int32 * N.MAX_AGENTS)(*(ks + [0] * (N.MAX_AGENTS - len(ks))))
     stats = torch.empty((self.n_envs, sp.A, 5 + sp.K), dtype=torch.float64, device=self.device)
     N.check(self._lib.sgw_derived_stats(self._h, self._bufs["reward"].data_ptr(), self._bufs["cumulative"].data_ptr(),

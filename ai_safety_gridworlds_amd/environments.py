@@ -52,6 +52,8 @@ class BatchedSafetyEnvironment(object):
     self.device = self.engine.device
     self._last = None
     self._last_performance = None     # [N, K] of the most recently finished episode per env (NaN = none yet)
+    self._performance_sum = None      # [N, K] running sum over the env's finished episodes; _episodes int64 [N] their number
+    self._episodes = None
 
   # ---- specs ----------------------------------------------------------------------------------
   def action_spec(self):
@@ -73,15 +75,28 @@ class BatchedSafetyEnvironment(object):
     else:
       st = st[:, 0]                                           # all agents of an env share the step type
     if self._track_performance and ("cumulative" in o or "hidden" in o):      # _calculate_episode_performance (safety_game.py:253-263)
-      use_hidden = self.spec.scalar and getattr(self.spec, "performance", "hidden") == "hidden"   # distributional_shift keeps the default: episode return
-      perf = o["hidden"].reshape(self.num_envs, 1) if use_hidden and "hidden" in o else o.get("cumulative")
-      if perf is not None:
-        perf = perf.reshape(self.num_envs, -1)
-        if self._last_performance is None:
-          self._last_performance = torch.full_like(perf, float("nan"))
-        done = (st == N.LAST)
-        self._last_performance = torch.where(done[:, None], perf, self._last_performance)
+      self._track(o)
     return TimeStep(step_type=st, reward=o.get("reward"), discount=o.get("discount"), observation=o)
+
+  def _perf_source(self, o):
+    use_hidden = self.spec.scalar and getattr(self.spec, "performance", "hidden") == "hidden"   # distributional_shift keeps the default: episode return
+    return ("hidden", 1) if use_hidden and "hidden" in o else ("cumulative", self.spec.A * self.spec.K)
+
+  def _track(self, o):
+    """Device-side _episodic_performances bookkeeping (sgw_track_performance): last performance, running sum and episode count
+    per env, updated where the step that just ran was LAST."""
+    import ctypes as C
+    name, cols = self._perf_source(o)
+    if o.get(name) is None or "step_type" not in o:
+      return
+    if self._last_performance is None:
+      self._last_performance = torch.full((self.num_envs, cols), float("nan"), dtype=torch.float64, device=self.device)
+      self._performance_sum = torch.zeros((self.num_envs, cols), dtype=torch.float64, device=self.device)
+      self._episodes = torch.zeros(self.num_envs, dtype=torch.int64, device=self.device)
+    eng = self.engine
+    N.check(eng._lib.sgw_track_performance(eng._h, eng._bufs[name].data_ptr(), cols, eng._bufs["step_type"].data_ptr(),
+                                           self._last_performance.data_ptr(), self._performance_sum.data_ptr(),
+                                           self._episodes.data_ptr(), None, eng._stream()), "sgw_track_performance")
 
   def reset(self, mask=None):
     return self._timestep(self.engine.reset(mask))
@@ -94,6 +109,17 @@ class BatchedSafetyEnvironment(object):
   def get_last_performance(self, default=None):
     """Per env: performance of the last finished episode (safety_game.py:229-251); NaN rows = none yet."""
     return default if self._last_performance is None else self._last_performance
+
+  def get_overall_performance(self, default=None):
+    """Per env: the mean of the performances of its finished episodes, sum(_episodic_performances) / len(...) in the reference's
+    left-to-right order (safety_game.py:194-208, 234-244; safety_game_mo.py:917-938); NaN rows = no episode finished yet.
+    `episodes_finished()` gives the counts."""
+    if self._last_performance is None:
+      return default
+    return self._performance_sum / self._episodes.to(torch.float64)[:, None]      # 0 / 0 = NaN where none finished
+
+  def episodes_finished(self):
+    return None if self._last_performance is None else self._episodes
 
   def set_episode_bits(self, bits, seed=0):
     self.engine.set_episode_bits(bits, seed)

@@ -374,16 +374,32 @@ class GridworldVectorEnv(object):
   """N envs at once; observations/rewards/dones stay on the device as torch tensors.
 
   reset() -> (obs [N,1,H,W] float32, info);  step(actions int8/int64 [N]) ->
-  (obs, reward [N,K] float64 (or [N] for scalar envs), terminated bool [N], truncated bool [N], info)."""
+  (obs, reward [N,K] float64 (or [N] for scalar envs), terminated bool [N], truncated bool [N], info).
+
+  full_info=True: info carries everything the reference's env.step() computes per step (gridworld_gym_env.py:455-585,
+  safety_game_mo.py:971-1107, observation_distiller_ex.py:147-187) as device tensors -- "RGB" uint8 [N, 3, H, W], "layers"
+  uint8 [N, L, H, W] (unoccluded, `layers_order`), "cumulative_reward", "average_reward", "gini_index",
+  "cumulative_gini_index", "mo_variance", "cumulative_mo_variance", "average_mo_variance", "metrics", "safety",
+  "last_performance" / "performance_sum" / "episodes" -- produced by ONE library call per step (sgw_step_full: step kernel +
+  RGB + layers + derived statistics + performance bookkeeping chained in C, replayed as one hipGraph)."""
+
+  FULL_OUTPUTS = ("board", "obs_board", "reward", "cumulative", "step_type", "term_reason", "hidden", "frame", "metrics", "safety",
+                  "discount", "actual_action")
 
   def __init__(self, env_name, num_envs, device="cuda:0", env_id_base=0,
-               outputs=("board", "obs_board", "reward", "cumulative", "step_type", "term_reason", "hidden"),
+               outputs=("board", "obs_board", "reward", "cumulative", "step_type", "term_reason", "hidden"), full_info=False,
                **kwargs):
+    self._full = bool(full_info)
+    if self._full:
+      outputs = tuple(dict.fromkeys(tuple(outputs) + self.FULL_OUTPUTS))
     self._env = BatchedSafetyEnvironment(env_name, num_envs=num_envs, device=device, env_id_base=env_id_base,
                                          outputs=outputs, track_performance=False, **kwargs)
     self.spec_ = self._env.spec
     self.num_envs = num_envs
+    self.layers_order = list(self.spec_.layer_chars)
     self._never = torch.zeros(num_envs, dtype=torch.bool, device=self._env.device)      # truncated: always False (gym_env.py:563-578)
+    self._done = torch.zeros(num_envs, dtype=torch.bool, device=self._env.device)
+    self._info = None
 
   def _pack(self, ts):
     o = ts.observation
@@ -396,11 +412,42 @@ class GridworldVectorEnv(object):
     return self._pack(self._env.reset(mask))
 
   def step(self, actions):
-    ts = self._env.step(actions if actions.dtype == torch.int8 else actions.to(torch.int8))
+    if actions.dtype != torch.int8:
+      actions = actions.to(torch.int8)
+    if self._full:
+      return self._step_full(actions)
+    ts = self._env.step(actions)
     obs, info = self._pack(ts)
     reward = ts.reward if not self.spec_.scalar else ts.reward.reshape(-1)
     terminated = ts.step_type == N.LAST
     return obs, reward, terminated, self._never, info
+
+  def _step_full(self, actions):
+    """A step from Python is host-bound: the outputs live in persistent buffers, so the info dict of views is built once
+    and a step is one library call plus one comparison."""
+    o = self._env.engine.step_full(actions, rgb=True, layers=True, stats=not self.spec_.scalar, performance=True)
+    self._env._last = o
+    if self._info is None or self._info["_for"] is not o["step_type"]:
+      st = o["step_type"].reshape(self.num_envs, -1)[:, 0]
+      info = {"step_type": st, "term_reason": o["term_reason"], "board": o["board"], "cumulative": o["cumulative"], "hidden": o["hidden"],
+              "cumulative_reward": o["cumulative"], "RGB": o["RGB"], "layers": o["layers"], "layers_order": self.layers_order,
+              "metrics": o["metrics"][:, :self.spec_.M], "safety": o["safety"], "frame": o["frame"], "discount": o["discount"],
+              "actual_action": o["actual_action"], "last_performance": o["last_performance"], "performance_sum": o["performance_sum"],
+              "episodes": o["episodes"]}
+      for k in ("gini_index", "cumulative_gini_index", "mo_variance", "cumulative_mo_variance", "average_mo_variance", "average_reward"):
+        if k in o:
+          info[k] = o[k]
+      self._info = {"_for": o["step_type"], "info": info, "done": o["done"], "obs": o["obs_board"].unsqueeze(1),
+                    "reward": o["reward"] if not self.spec_.scalar else o["reward"].reshape(-1)}
+    c = self._info
+    return c["obs"], c["reward"], c["done"], self._never, dict(c["info"])
+
+  def get_overall_performance(self):
+    """[N, C] mean performance over each env's finished episodes (NaN = none yet); needs full_info=True (safety_game.py:194-208)."""
+    o = self._env._last
+    if o is None or "performance_sum" not in o:
+      return None
+    return o["performance_sum"] / o["episodes"].to(torch.float64)[:, None]
 
   def close(self):
     self._env.close()

@@ -421,6 +421,39 @@ def main():
                   "note": "ONE sgw_step launch per round writes the round's outputs AND the agents' windows (sgw_out.views)"}
     engv.close()
 
+  # everything env.step() returns: the step with every output + RGB + unoccluded layers + derived
+  # statistics + performance bookkeeping, ONE sgw_step_full call per step (its launches replayed as one hipGraph), actions
+  # refilled in place in a persistent buffer as an RL loop does
+  full_obs = None
+  if a.workload != "mixed" and world == 1 and engines[0]["spec"].A == 1:
+    from ai_safety_gridworlds_amd.helpers.gridworld_gym_env import GridworldVectorEnv
+    e = engines[0]
+    engf = prepare_engine(e["fam"], e["spec"], e["n"], rank * e["n"], device,
+                          tuple(dict.fromkeys(tuple(e["wl"]["outputs"]) + GridworldVectorEnv.FULL_OUTPUTS)))
+    acts = e["acts"]
+    nf = int(min(acts.shape[0], 400))
+    buf = torch.empty_like(acts[0])
+    kw = dict(rgb=True, layers=True, stats=not e["spec"].scalar, performance=True)
+    for t in range(min(nf, 30)):
+      buf.copy_(acts[t]); engf.step_full(buf, **kw)
+    torch.cuda.synchronize(device)
+    f0 = time.perf_counter()
+    ev0.record()
+    for t in range(nf):
+      buf.copy_(acts[t]); engf.step_full(buf, **kw)
+    ev1.record()
+    fhost = time.perf_counter() - f0
+    torch.cuda.synchronize(device)
+    fdt = (time.perf_counter() - f0) / nf
+    sp = e["spec"]
+    HWc, Lc = sp.H * sp.W, len(sp.layer_chars)
+    full_obs = {"value": e["n"] / fdt, "unit": "env-steps/s", "us_per_step": ev0.elapsed_time(ev1) * 1e3 / nf, "us_per_step_wall": fdt * 1e6,
+                "host_us_per_call": fhost / nf * 1e6, "steps": nf,
+                "outputs_bytes_per_env_step": int(HWc * (1 + 4 + 3 + Lc) + sp.K * 8 * 3 + (5 + sp.K) * 8 + max(sp.M, 0) * 8 + 40),
+                "note": "sgw_step_full: step kernel (board, float board, reward, cumulative, metrics, ...) + RGB + unoccluded layers + "
+                        "gini / variances / average reward + per-env performance bookkeeping, one library call per step"}
+    engf.close()
+
   if rank == 0:
     n_rank = sum(e["n"] for e in engines)
     alg_bytes = sum(e["n"] * e["wl"]["b_step"] for e in engines)      # algorithmic bytes of one bench step on this rank
@@ -490,6 +523,8 @@ def main():
           rl["frac"] = rl["achieved"] / VALU_PEAK_GINST
           rl["valu_insts_per_launch"] = valu
           rl["valu_source"] = "profiles/%s (separate rocprofv3 --pmc pass of this command; a constant in this run)" % VALU_BOUND[a.workload]
+    if full_obs is not None:
+      line["full_observation"] = full_obs
     if with_views is not None:
       line["with_agent_views"] = with_views
     if group_launch is not None:

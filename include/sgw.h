@@ -132,6 +132,7 @@ const char* sgw_last_error(void);
 /* Bytes of one sgw_spec / sgw_out as compiled (lets a binding verify its struct mirror). */
 int sgw_sizeof_spec(void);
 int sgw_sizeof_out(void);
+int sgw_sizeof_extras(void);
 
 /* Create an engine for n_envs instances on HIP device `device`.  env_id_base is the global id
  * of env 0 (keys the counter-based RNG so results do not depend on the GPU count).
@@ -267,6 +268,42 @@ int sgw_observe(sgw_engine* e, const uint8_t* board_dev, const uint8_t* rgb_lut_
  * average_mo_variance, average_reward[K]).  k_agent[A] = number of reward dimensions of each agent (<= K). */
 int sgw_derived_stats(sgw_engine* e, const double* reward_dev, const double* cumulative_dev, const int32_t* frame_dev,
                       const int32_t* k_agent, double* stats_dev, void* stream);
+
+/* Per-env performance bookkeeping of SafetyEnvironment{,Mo}: _episodic_performances.append(...) at every LAST timestep
+ * (safety_game.py:253-263, 301-302; safety_game_mo.py:1015-1016), get_last_performance (229-251) and get_overall_performance =
+ * sum(performances) / len(performances) (194-208, 234-244; safety_game_mo.py:917-938).  perf_dev double [N, C] is the step's
+ * performance source (the `cumulative` output, C = A*K, or the `hidden` output, C = 1); where step_type_dev[n, 0..A) is LAST
+ * (every agent LAST or DEAD for the families whose agents finish one by one): last_dev[n] = perf[n], sum_dev[n] += perf[n]
+ * (the reference's left-to-right sum), count_dev[n] += 1; done_dev[n] = 1 there and 0 elsewhere (the wrapper's `terminated`,
+ * gridworld_gym_env.py:563-578).  Any of last / sum / count / done may be NULL. */
+int sgw_track_performance(sgw_engine* e, const double* perf_dev, int n_cols, const uint8_t* step_type_dev, double* last_dev,
+                          double* sum_dev, int64_t* count_dev, uint8_t* done_dev, void* stream);
+
+/* Everything env.step() returns from ONE host call: sgw_step, then -- on the same stream, chained in C -- whatever of the
+ * observation distiller's and _process_timestep's derived outputs `extras` asks for, computed from that step's outputs:
+ * RGB (sgw_observe), unoccluded layers (sgw_observe_layers; aintelope_savanna: sgw_state_layers), derived statistics
+ * (sgw_derived_stats), per-agent layer cubes (sgw_agent_layer_views), performance bookkeeping (sgw_track_performance).  The second
+ * call with the same (actions_dev, out, extras) pointers captures the launches into a hipGraph and replays it from then on (one
+ * graph launch per step instead of up to six kernel launches; refill the action buffer in place).  `out` must carry what the
+ * requested extras read: board (rgb, layers), agent_pos + agent_flags (hidden drape, layer cubes), reward + cumulative + frame
+ * (stats), cumulative or hidden + step_type (performance).  Reference: gridworld_gym_env.py:455-585, safety_game_mo.py:971-1107,
+ * observation_distiller_ex.py:147-187. */
+typedef struct sgw_extras {
+  uint8_t* rgb;                       /* [N, 3, H*W] or NULL */
+  const uint8_t* rgb_lut_dev;         /* uint8 [128*3] */
+  uint8_t* layers;                    /* unoccluded [N, L, H*W] or NULL */
+  const uint8_t* layer_chars_dev;     /* uint8 [L] */
+  const uint8_t* layer_static_dev;    /* uint8 [L, H*W] (unused by aintelope_savanna) */
+  int32_t n_layers, gap_index, hidden_layer, perf_from_hidden;
+  double* stats;                      /* [N, A, 5 + K] or NULL */
+  int32_t k_agent[SGW_MAX_AGENTS];
+  uint8_t* agent_layer_views;         /* [N, L * view_bytes] or NULL (needs `layers`) */
+  double* perf_last;                  /* [N, C] / [N, C] / int64 [N] / uint8 [N]; all NULL = no bookkeeping */
+  double* perf_sum;
+  int64_t* perf_count;
+  uint8_t* done;
+} sgw_extras;
+int sgw_step_full(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, const sgw_extras* extras, void* stream);
 
 /* Unoccluded observation layers (BaseUnoccludedObservationRenderer, rendering.py:188-302, which the multi-objective
  * and multi-agent envs use: safety_game_mo_base.py:1157) with the "gap only where every other layer is blank"
