@@ -83,6 +83,7 @@ def lib():
       path = LIB_PATH
   L = C.CDLL(path)
   L.sgw_last_error.restype = C.c_char_p
+  L.sgw_build_info.restype = C.c_char_p
   L.sgw_create.argtypes = [C.POINTER(Spec), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
   L.sgw_destroy.argtypes = [C.c_void_p]
   for f in ("sgw_n_envs", "sgw_n_pad", "sgw_state_bytes"):
@@ -136,7 +137,7 @@ def lib():
 
 
 EXPORTS = [
-    "sgw_abi_version", "sgw_last_error", "sgw_sizeof_spec", "sgw_sizeof_out", "sgw_sizeof_extras", "sgw_create", "sgw_track_performance", "sgw_step_full",
+    "sgw_abi_version", "sgw_last_error", "sgw_build_info", "sgw_sizeof_spec", "sgw_sizeof_out", "sgw_sizeof_extras", "sgw_create", "sgw_track_performance", "sgw_step_full",
     "sgw_destroy", "sgw_n_envs", "sgw_n_pad", "sgw_state_bytes", "sgw_set_episode_bits",
     "sgw_set_rng_state", "sgw_set_random_stream", "sgw_set_family_table", "sgw_pow_f64", "sgw_pow_selfcheck", "sgw_reset", "sgw_step", "sgw_step_n", "sgw_rollout", "sgw_replay", "sgw_group_create", "sgw_group_destroy", "sgw_group_step_n", "sgw_group_rollout", "sgw_read_returns", "sgw_fill_actions",
     "sgw_accumulate_returns", "sgw_observe", "sgw_derived_stats", "sgw_observe_layers", "sgw_state_layers", "sgw_view_bytes", "sgw_agent_views", "sgw_agent_layer_views", "sgw_state_words", "sgw_get_state", "sgw_set_state"]

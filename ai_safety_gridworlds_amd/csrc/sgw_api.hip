@@ -136,6 +136,10 @@ extern "C" {
 
 int sgw_abi_version(void) { return SGW_ABI_VERSION; }
 const char* sgw_last_error(void) { return g_err; }
+#ifndef SGW_BUILD_COMPILER
+#define SGW_BUILD_COMPILER "unknown (built outside ai_safety_gridworlds_amd/build.py: not linted)"
+#endif
+const char* sgw_build_info(void) { return SGW_BUILD_COMPILER; }
 int sgw_sizeof_spec(void) { return (int)sizeof(sgw_spec); }
 int sgw_sizeof_out(void) { return (int)sizeof(sgw_out); }
 int sgw_sizeof_extras(void) { return (int)sizeof(sgw_extras); }

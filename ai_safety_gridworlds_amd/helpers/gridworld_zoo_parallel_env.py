@@ -305,8 +305,8 @@ class GridworldZooParallelEnv(_Base):
     self._test_deads = {a: False for a in self.possible_agents}
     o, states = self._observe(ts, True)
     result = (states, self._infos(o, states))
-    if self._post_reset_callback is not None:
-      self._post_reset_callback(*result, seed, *args, **kwargs)
+    if self._post_reset_callback is not None:                   # zoo.py:699-700: exactly (obs, infos)
+      self._post_reset_callback(*result)
     return result
 
   def step(self, actions, *args, **kwargs):

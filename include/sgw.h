@@ -128,6 +128,9 @@ typedef struct sgw_engine sgw_engine;
 
 int sgw_abi_version(void);
 const char* sgw_last_error(void);
+/* The compiler this library was built with ("HIP <version>; <clang version>"): every build is checked for the gfx950
+ * register-allocator defect of DESIGN.md §8 before it is installed, so the string names the compiler the lint passed on. */
+const char* sgw_build_info(void);
 
 /* Bytes of one sgw_spec / sgw_out as compiled (lets a binding verify its struct mirror). */
 int sgw_sizeof_spec(void);

@@ -39,9 +39,37 @@ def test_lint_recognises_the_round1_pattern():
 
 @pytest.fixture(scope="module")
 def asm():
+  """The assembly of the INSTALLED build (build.build() keeps it as libsgw.s and refuses to install a flagged build)."""
   if not os.path.exists("/opt/rocm/bin/hipcc"):
     pytest.skip("hipcc not present")
-  return open(isa_lint.build_asm()).read()
+  from ai_safety_gridworlds_amd import build as B
+  B.build()
+  if not os.path.exists(B.ASM) or os.path.getmtime(B.ASM) < max(os.path.getmtime(d) for d in B._deps()):
+    B.build(force=True)
+  return open(B.ASM).read()
+
+
+def test_build_refuses_to_install_a_flagged_library(tmp_path, monkeypatch):
+  """build.build() lints the assembly of the compile it is about to install: with a lint that reports a finding the library
+  on disk is left as it was and the build raises (a rebuild on another compiler cannot ship the round-1 pattern silently)."""
+  if not os.path.exists("/opt/rocm/bin/hipcc"):
+    pytest.skip("hipcc not present")
+  from ai_safety_gridworlds_amd import build as B, isa_lint as pkg_lint
+  B.build()
+  before = os.path.getmtime(B.LIB)
+  small = tmp_path / "k.hip"
+  small.write_text("#include <hip/hip_runtime.h>\n__global__ void k(int* p) { p[threadIdx.x] = 1; }\n")
+  monkeypatch.setattr(B, "SOURCES", [str(small)])
+  monkeypatch.setattr(pkg_lint, "lint_text", lambda text: [("k", 1, "v_mov_b32 v0, v1", "s_or_b64 exec, exec, s[0:1]")])
+  with pytest.raises(RuntimeError, match="NOT installed"):
+    B.build(force=True)
+  assert os.path.getmtime(B.LIB) == before
+
+
+def test_library_names_its_compiler():
+  from ai_safety_gridworlds_amd import _native as N, build as B
+  info = N.lib().sgw_build_info().decode()
+  assert info.startswith("HIP ") and "clang" in info and info == B.compiler_version()
 
 
 def test_no_kernel_saves_registers_ahead_of_an_exec_restore(asm):
@@ -58,6 +86,9 @@ def test_register_budget(asm):
   heavy = ("Savanna", "IslandTILb1", "IslandMa", "Firemaker")
   for k, d in stats.items():
     if "k_engine" not in k:
+      continue
+    if "k_engine_group" in k:                            # eleven family bodies in one kernel: the counts are sums over them
+      assert d.get("vgpr_spill_count", 0) == 0 and d.get("private_segment_fixed_size", 0) == 0 and d.get("sgpr_spill_count", 0) < 11 * 64, (k, d)
       continue
     if "Li1E" not in k and "Savanna" not in k:           # step and reset kernels: nothing spilled to scratch
       assert d.get("vgpr_spill_count", 0) == 0, k

@@ -87,6 +87,36 @@ def test_zoo_parallel_callbacks_and_custom_orders():
   env.close()
 
 
+def test_callbacks_with_the_reference_signatures():
+  """The four hooks written exactly as a caller of the reference would write them: pre_reset(seed, *args, **kwargs) ->
+  (allow, seed, args, kwargs), post_reset(obs, infos), pre_step(actions) -> actions, post_step(actions, obs, rewards,
+  terminateds, truncateds, infos)  (gridworld_zoo_parallel_env.py:445-446, 612-613, 619-622, 699-700; gridworld_gym_env.py
+  has the same four with the Gym tuple)."""
+  seen = {}
+  def pre_reset(seed, *args, **kwargs): seen["pre_reset"] = seed; return (True, seed, args, kwargs)
+  def post_reset(obs, infos): seen["post_reset"] = (sorted(obs), sorted(infos))
+  def pre_step(actions): seen["pre_step"] = dict(actions); return actions
+  def post_step(actions, obs, rewards, terminateds, truncateds, infos): seen["post_step"] = (sorted(rewards), sorted(truncateds))
+  env = Z.GridworldZooParallelEnv("island_navigation_ex_ma", level=9, seed=3, pre_reset_callback=pre_reset, post_reset_callback=post_reset,
+                                  pre_step_callback=pre_step, post_step_callback=post_step)
+  env.reset(seed=5)
+  env.step({"agent_1": 1, "agent_2": 2})
+  assert seen["pre_reset"] == 5 and seen["post_reset"] == (["agent_1", "agent_2"], ["agent_1", "agent_2"])
+  assert seen["pre_step"] == {"agent_1": 1, "agent_2": 2} and seen["post_step"] == (["agent_1", "agent_2"], ["agent_1", "agent_2"])
+  env.close()
+  from ai_safety_gridworlds_amd.helpers.gridworld_gym_env import GridworldGymEnv
+  seen.clear()
+  def g_post_reset(state, info): seen["post_reset"] = state.shape
+  def g_pre_step(action): seen["pre_step"] = action; return action
+  def g_post_step(action, state, reward, terminated, truncated, info): seen["post_step"] = (action, terminated, truncated)
+  g = GridworldGymEnv("island_navigation_ex", level=9, pre_reset_callback=pre_reset, post_reset_callback=g_post_reset,
+                      pre_step_callback=g_pre_step, post_step_callback=g_post_step)
+  g.reset(seed=9)
+  g.step(2)
+  assert seen["pre_reset"] == 9 and seen["post_reset"] == (1, 6, 8) and seen["pre_step"] == 2 and seen["post_step"] == (2, False, False)
+  g.close()
+
+
 def test_zoo_vector_layer_cubes_equal_the_single_env_facade():
   """The batched facade's cubes (device tensors) == the one-env facade's, env by env, over a few rounds."""
   import torch
