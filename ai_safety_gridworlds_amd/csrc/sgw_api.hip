@@ -84,6 +84,10 @@ static void drop_graphs(sgw_engine* e) {      // any setter that changes what a 
   e->full_graphs.clear();
 }
 
+static size_t acc_bytes(const sgw_engine* e) {              // [env-waves * parts][A*K+1] doubles
+  return (size_t)(e->spec.A * e->spec.K + 1) * (size_t)(e->n_pad / WAVE) * SGW_ACC_PARTS * 8;
+}
+
 // island_navigation_ex: the packed (i16) state when the spec proves it exact (sgw_island.hpp); SGW_ISLAND_PLAIN_STATE in the
 // environment forces the plain f64 state (tests run every fixture through both).
 static bool island_packable(const sgw_spec& sp) { return !getenv("SGW_ISLAND_PLAIN_STATE") && Island::packable(sp); }
@@ -112,9 +116,7 @@ static int family_words(const sgw_spec& sp) {
 // the reference's math.pow is the RUNNING host's libm pow.  When the two differ (another glibc, a non-FMA dispatch) parity
 // of resource regrowth would fail later and quietly, so the families that regrow resources refuse to construct instead.
 // Probe: the regrowth domain (halves and pseudo-random x in [1, 61]) at three exponents.  Returns the mismatch count.
-static long pow_selfcheck() {
-  static long cached = -1;
-  if (cached >= 0) return cached;
+static long pow_selfcheck_run() {
   long bad = 0;
   unsigned long long s = 88172645463325252ULL;
   const double ys[3] = {1.1, 1.05, 1.5};
@@ -128,8 +130,11 @@ static long pow_selfcheck() {
                                           sgw_host_pow::SGW_POW_LOG_TAB, sgw_host_pow::SGW_POW_EXP_TAB);
     if (memcmp(&want, &got, 8) != 0) ++bad;
   }
-  cached = bad;
   return bad;
+}
+static long pow_selfcheck() {
+  static const long cached = pow_selfcheck_run();           // C++11: initialised once, thread-safe
+  return cached;
 }
 
 extern "C" {
@@ -198,6 +203,8 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   memcpy(k.start_cell, spec->start_cell, sizeof(k.start_cell));
   kspec_derive(k);
   kspec_views(k, *spec);
+  if (spec->family == SGW_ISLAND_NAVIGATION_EX_MA) k.view_rotates = (spec->flags & (IslandMa::F_ODIR | IslandMa::F_ODIR_TURN)) ? 1 : 0;
+  if (spec->family == SGW_AINTELOPE_SAVANNA) k.view_rotates = (spec->flags & (Savanna::F_ODIR | Savanna::F_ODIR_TURN)) ? 1 : 0;
   memcpy(k.dim_slot, spec->dim_slot, sizeof(k.dim_slot));
   memcpy(k.metric_slot, spec->metric_slot, sizeof(k.metric_slot));
 
@@ -214,10 +221,15 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   if (err == hipSuccess) err = hipMemcpy(e->tables_dev, host_tables, tbytes, hipMemcpyHostToDevice);
   const size_t sbytes = (size_t)state_alloc_words(words, e->n_pad) * 8;      // pair layout (sgw_common.hpp): ceil(words / 2) KiB per env-wave
   if (err == hipSuccess) err = hipMalloc((void**)&e->state_dev, sbytes);
+  // the episodic-return accumulators (sgw_read_returns): part of the engine from the start, zeroed here with the state --
+  // sgw_create ends with a device synchronisation, so no stream of the caller can run ahead of the zeroing
+  if (err == hipSuccess) err = hipMalloc((void**)&e->acc_dev, acc_bytes(e));
+  if (err == hipSuccess) err = hipMemset(e->acc_dev, 0, acc_bytes(e));
   if (err != hipSuccess) {
     snprintf(g_err, sizeof(g_err), "sgw_create: device allocation failed: %s", hipGetErrorString(err));
     if (e->tables_dev) (void)hipFree(e->tables_dev);
     if (e->state_dev) (void)hipFree(e->state_dev);
+    if (e->acc_dev) (void)hipFree(e->acc_dev);
     delete e;
     return SGW_ERR_HIP;
   }
@@ -337,15 +349,9 @@ int sgw_pow_f64(const double* x_dev, double y, double* out_dev, int64_t n, int d
   return SGW_OK;
 }
 
-// The accumulators are zeroed ON THE CALLER'S STREAM: a hipMemset on the null stream is not ordered against a non-blocking
-// stream (torch side streams are), so the first accumulating launches could run before it and lose their sums.
-static int ensure_acc(sgw_engine* e, hipStream_t st) {
-  if (e->acc_dev) return SGW_OK;
-  HIP_TRY(hipSetDevice(e->device));
-  const size_t bytes = (size_t)(e->spec.A * e->spec.K + 1) * (size_t)(e->n_pad / WAVE) * SGW_ACC_PARTS * 8;   // [waves * parts][A*K+1]
-  HIP_TRY(hipMalloc((void**)&e->acc_dev, bytes));
-  HIP_TRY(hipMemsetAsync(e->acc_dev, 0, bytes, st));
-  return SGW_OK;
+// (the accumulators are allocated and zeroed by sgw_create: nothing is allocated on the step path)
+static int ensure_acc(sgw_engine* e, hipStream_t) {
+  return e->acc_dev ? SGW_OK : fail(SGW_ERR_ARG, "the engine's return accumulators are missing");
 }
 
 }  // extern "C"
@@ -409,7 +415,10 @@ template <class F, int KIND> static int plan_launch(const sgw_engine* e, KArgs& 
   const long long n_waves = e->n_pad / WAVE;
   const int need = lds_need(a, F::LDS_SCRATCH_M), pa = F::PER_AGENT ? F::NA : 1;
   if ((need & (LN_VIEWS | LN_OBSVIEWS)) && (!has_views<F>::value || a.sp.view_total <= 0))
-    return fail(SGW_ERR_UNSUPPORTED, "launch: the views / obs_views outputs exist for families with agent windows only (firemaker_ex_ma)");
+    return fail(SGW_ERR_UNSUPPORTED, "launch: the views / obs_views outputs exist for the families with agent windows only");
+  if ((need & (LN_VIEWS | LN_OBSVIEWS)) && F::WAVES == 1 && a.sp.view_prefill)
+    return fail(SGW_ERR_UNSUPPORTED, "launch: a window larger than the board is not assembled inside this family's round kernel (one "
+                                     "wavefront per 64 envs would walk them env by env): use sgw_agent_views");
   const int vb = a.sp.view_total > 0 ? a.sp.view_total : 0;
   a.lp = lds_plan(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, vb); a.need = need;
   p.lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, vb, F::LDS_EXTRA, EW, NB);

@@ -31,6 +31,7 @@ struct KSpec {
   uint8_t view_up[SGW_MAX_AGENTS], view_left[SGW_MAX_AGENTS], view_h[SGW_MAX_AGENTS], view_w[SGW_MAX_AGENTS];
   uint16_t view_off[SGW_MAX_AGENTS], view_recip[SGW_MAX_AGENTS];     // recip = ceil(65536 / view_w): (k * recip) >> 16 == k / view_w for k < 320
   int view_total, view_pad, view_prefill, recip_W;                   // pad character; any window larger than the board; ceil(65536 / W)
+  int view_rotates;                                                  // the env has observation directions (windows are rot90-ed by them)
 };
 
 // byte offsets of one env-wave staging buffer's regions, computed ONCE per launch on the host (lds_plan) and read from the
@@ -114,7 +115,7 @@ __host__ __device__ inline void kspec_derive(KSpec& k) {
 // window geometry from the spec's radii (up, down, left, right; < 0 = the agent has no window)
 __host__ inline void kspec_views(KSpec& k, const sgw_spec& sp) {
   int off = 0;
-  k.view_prefill = 0;
+  k.view_prefill = 0; k.view_rotates = 0;
   for (int ag = 0; ag < SGW_MAX_AGENTS; ++ag) {
     const int32_t* rad = sp.view_radius[ag];
     k.view_off[ag] = (uint16_t)off; k.view_up[ag] = k.view_left[ag] = k.view_h[ag] = k.view_w[ag] = 0; k.view_recip[ag] = 0;

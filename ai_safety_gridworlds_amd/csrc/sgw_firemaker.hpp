@@ -178,9 +178,15 @@ struct Firemaker {
   }
 
   // The step after LAST still shuffles the (discarded) actions before it resets (PM:177-180, 211-221)
-  static __device__ void pre_autoreset(State& s, const KArgs& a, const int (&)[NA]) {
+  // the agents in the submitted dict: an action < 0 = "not in the dict" (EnvironmentMa.step plays exactly the agents it is given,
+  // PM:173-246; the Gym wrapper with agent_character steps one agent, gridworld_gym_env.py:476-479)
+  static __device__ bool submitted(const KSpec& sp, const int (&actions)[NA], int ag) { return present(sp, ag) && actions[ag] >= 0; }
+  static __device__ int n_submitted(const KSpec& sp, const int (&actions)[NA]) {
+    return (submitted(sp, actions, 0) ? 1 : 0) + (submitted(sp, actions, 1) ? 1 : 0) + (submitted(sp, actions, 2) ? 1 : 0);
+  }
+  static __device__ void pre_autoreset(State& s, const KArgs& a, const int (&actions)[NA]) {
     if ((a.sp.flags & F_SHUFFLE) && s.step_type == ST_LAST) {        // Generator.shuffle of the n submitted actions, n > 1
-      const int n = n_present(a.sp);
+      const int n = n_submitted(a.sp, actions);
       if (n == 3) interval(s, 2);
       if (n >= 2) interval(s, 1);
     }
@@ -475,8 +481,10 @@ struct Firemaker {
     const double* p = l.params;
     const int lane = cx.lane;
     FM_T(0);                                                    // everything outside fire_update
+    if (live) {
 #pragma unroll
-    for (int ag = 0; ag < 3; ++ag) set_bit(s.fire, s.row[ag] * W + s.col[ag], false);     // FM:540-542
+      for (int ag = 0; ag < 3; ++ag) set_bit(s.fire, s.row[ag] * W + s.col[ag], false);   // FM:540-542
+    }
     const M5 old = s.fire;
     M5 src = old;                                              // + workers on an active workshop (FM:550-554)
     const bool ws_active = (s.countdown == 0);
@@ -499,7 +507,8 @@ struct Firemaker {
     // ---- cooperative phase: this wave's 16 envs, one at a time; envs with nothing burning and nothing to ignite are skipped
     M5 res = old;
     uint64_t res_hi = s.rs_hi, res_lo = s.rs_lo;
-    const bool has_work = ((old.a | old.b | old.c | old.d | old.e | cand.a | cand.b | cand.c | cand.d | cand.e) != 0ull);
+    // (a lane whose play slot is empty -- it resets this step, or fewer agents were submitted than the round has slots -- has none)
+    const bool has_work = live && ((old.a | old.b | old.c | old.d | old.e | cand.a | cand.b | cand.c | cand.d | cand.e) != 0ull);
     // burning envs are handed out dynamically: every wave pulls tickets from one LDS counter until it draws one past
     // the end (the counter only grows; all waves track the same base), so a wave that gets cheap envs takes more of them
     const uint64_t work = __ballot(has_work);                                                // scalar
@@ -659,10 +668,16 @@ struct Firemaker {
   // firemaker has no terminating entity; the episode ends through max_iterations).
   static __device__ double play(State& s, const int (&actions)[3], const KArgs& a, const Lds& l, double (&r)[NU],
                                 long long env, bool live, Ctx& cx) {
-    // the agents that exist, in update-schedule order ('1', '2', 'S'); Generator.shuffle(list of n): i = n - 1 .. 1
+    // the SUBMITTED agents, in update-schedule order ('1', '2', 'S'), compacted per lane; Generator.shuffle(list of n): i = n - 1 .. 1.
+    // The round has as many play slots as the spec has agents (uniform: the cooperative fire update is called by every lane of
+    // every wave); a lane with fewer submitted agents leaves its last slots empty (live = false there: nothing changes).
     const KSpec& sp = a.sp;
-    const int n = n_present(sp);
-    int o0 = 0, o1 = (sp.flags & F_NO_AGENT2) ? 2 : 1, o2 = 2;
+    const int n_slots = n_present(sp);
+    const bool s0 = submitted(sp, actions, 0), s1 = submitted(sp, actions, 1), s2 = submitted(sp, actions, 2);
+    const int n = (s0 ? 1 : 0) + (s1 ? 1 : 0) + (s2 ? 1 : 0);
+    int o0 = s0 ? 0 : (s1 ? 1 : 2);
+    int o1 = s0 ? (s1 ? 1 : 2) : 2;
+    int o2 = 2;
     if (live && (sp.flags & F_SHUFFLE)) {
       if (n == 3) {
         const int j = interval(s, 2);
@@ -676,10 +691,10 @@ struct Firemaker {
       }
     }
 #pragma nounroll
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n_slots; ++i) {
       const int ag = i == 0 ? o0 : (i == 1 ? o1 : o2);
       const int act = ag == 0 ? actions[0] : (ag == 1 ? actions[1] : actions[2]);
-      play_one(s, ag, act, sp, l, r, live, cx);
+      play_one(s, ag, act, sp, l, r, live && i < n, cx);
     }
     return 1.0;
   }

@@ -66,6 +66,7 @@ struct IslandMa {
   static constexpr bool STEP_REREADS_ARGS = false;   // measured: 39 instead of 88 SGPR spills but 296 instead of 240 registers = one wave per SIMD: 23.9 vs 24.2 us at 65 536 envs, 84.9 vs 70.6 us at 262 144
   static constexpr int ENV_WAVES_MAX = 2;    // env-waves per workgroup (LDS: every output staged must fit 160 KiB)
   static constexpr bool PER_AGENT = true;   // step_type / term_reason / safety are [N, A]
+  static constexpr bool VIEWS = true;       // sgw_out.views: the agents' windows leave with the round's launch
   struct Ctx {};
   static __device__ void init_ctx(Ctx&, const Lds&) {}
 
@@ -468,6 +469,7 @@ struct IslandMa {
   static __device__ int actual(const State&, int) { return -1; }
   static __device__ void agent_pos(const State& s, int ag, int& r, int& c) { r = s.row[ag]; c = s.col[ag]; }
   static __device__ int agent_flags(const State& s, int ag) { return (s.adir[ag] << 1) | (s.odir[ag] << 3); }
+  static __device__ int view_dir(const State& s, int ag) { return s.odir[ag]; }
   // per-agent outputs
   static __device__ int agent_step_type(const State& s, int ag) { return s.step_type == ST_NONE ? (int)ST_NONE : s.ast[ag]; }
   static __device__ int agent_term(const State& s, int ag) {

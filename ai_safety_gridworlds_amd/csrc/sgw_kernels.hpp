@@ -366,6 +366,48 @@ __device__ inline void views_stage_wave_per_env(const typename F::State& s, cons
   }
 }
 
+// Families whose env-waves are single wavefronts (island_navigation_ex_ma, aintelope_savanna): a LANE assembles its own env's
+// windows -- 64 envs x 2 small windows would be 128 serial wave passes the other way.  The window cell index is uniform over
+// the wave (scalar row / column); only the agent's position and, where the env has observation directions, the rot90 are per
+// lane.  Windows no larger than the board only (a larger one takes the wave-per-env path).
+template <class F>
+__device__ inline void views_stage_lane_per_env(const typename F::State& s, const KSpec& sp, const Lds& l, int lane) {
+  const int VB = sp.view_total, HW = sp.HW, W = sp.W, H = sp.H;
+  const uint32_t pad = (uint32_t)sp.view_pad & 0xffu;
+  const uint8_t* src = reinterpret_cast<const uint8_t*>(l.board) + lane * HW;
+  uint8_t* row = l.views + lane * VB;
+#pragma unroll
+  for (int ag = 0; ag < F::NA; ++ag) {
+    const int vh = sp.view_h[ag], vw = sp.view_w[ag], len = vh * vw;
+    if (len == 0) continue;
+    int prow, pcol, dir = 2;
+    F::agent_pos(s, ag, prow, pcol);
+    if constexpr (has_view_dir<F>::value) dir = F::view_dir(s, ag);
+    const int pr = prow - (int)sp.view_up[ag], pc = pcol - (int)sp.view_left[ag], n1 = vw - 1;
+    uint8_t* dst = row + sp.view_off[ag];
+    const bool rot = sp.view_rotates != 0;                    // scalar: the env has observation directions at all
+    int vr = 0, vc = 0;                                       // scalar window coordinates of cell k
+    constexpr int NB = 8;                                     // cells per batch: eight independent LDS reads in flight, then the eight writes
+    for (int k = 0; k < len; k += NB) {
+      uint32_t got[NB]; bool inside[NB];
+#pragma unroll
+      for (int h = 0; h < NB; ++h) {
+        int cr = vr, cc = vc;                                 // crop coordinates of output cell (vr, vc): view_unrotate per lane
+        if (rot) {
+          cr = dir == 2 ? vr : (dir == 3 ? n1 - vr : (dir == 0 ? n1 - vc : vc));
+          cc = dir == 2 ? vc : (dir == 3 ? n1 - vc : (dir == 0 ? vr : n1 - vr));
+        }
+        const int r = cr + pr, c = cc + pc;
+        inside[h] = r >= 0 && r < H && c >= 0 && c < W;
+        got[h] = src[inside[h] ? r * W + c : 0];
+        if (++vc == vw) { vc = 0; ++vr; }                     // (past the window's end the coordinates run on harmlessly: reads are clamped)
+      }
+#pragma unroll
+      for (int h = 0; h < NB; ++h) if (k + h < len) dst[k + h] = (uint8_t)(inside[h] ? got[h] : pad);
+    }
+  }
+}
+
 // LDS view image -> global: `nthr` threads (thread `tid` of them) copy the env-wave's 64 contiguous rows, 16 bytes per lane and
 // instruction; the float variant maps four window bytes to four floats per store (value_mapping LUT, rendering.py:491-549)
 __device__ inline void views_drain(const KArgs& a, const Lds& l, long long env0, long long toff, int tid, int nthr) {
@@ -458,7 +500,8 @@ __device__ inline void views_phase(const typename F::State& s, const KArgs& a_in
   // BOARD_DRAIN: the board rows also leave by the whole workgroup (their stores are in flight while the windows are assembled)
   if constexpr (BOARD_DRAIN) board_drain_wg(a, l, env0, toff, (int)threadIdx.x, NW * WAVE);
   if (!(a.need & (LN_VIEWS | LN_OBSVIEWS))) return;
-  views_stage_wave_per_env<F>(s, a.sp, l, w * EPW, (w + 1) * EPW, lane);
+  if (NW == 1 && !a.sp.view_prefill) views_stage_lane_per_env<F>(s, a.sp, l, lane);
+  else views_stage_wave_per_env<F>(s, a.sp, l, w * EPW, (w + 1) * EPW, lane);
   if (!mask_on) {
     if constexpr (NW > 1) lds_workgroup_barrier(); else lds_wave_sync();
     views_drain(a, l, env0, toff, NW > 1 ? (int)threadIdx.x : lane, NW * WAVE);

@@ -123,6 +123,7 @@ struct Savanna {
   static constexpr bool STEP_REREADS_ARGS = true;    // the one-step kernel re-reads the arguments for its output phase (sgw_kernels.hpp step_rereads)
   static constexpr int ENV_WAVES_MAX = 1;    // env-waves per workgroup (LDS: every output staged must fit 160 KiB)
   static constexpr bool PER_AGENT = true;
+  static constexpr bool VIEWS = true;       // sgw_out.views: the agents' windows leave with the round's launch
   struct Ctx {};
   static __device__ __forceinline__ void init_ctx(Ctx&, const Lds&) {}
 
@@ -813,6 +814,7 @@ struct Savanna {
   static __device__ __forceinline__ int actual(const State&, int) { return -1; }
   static __device__ __forceinline__ void agent_pos(const State& s, int ag, int& r, int& c) { r = s.row[ag]; c = s.col[ag]; }
   static __device__ __forceinline__ int agent_flags(const State& s, int ag) { return (s.adir[ag] << 1) | (s.odir[ag] << 3); }
+  static __device__ __forceinline__ int view_dir(const State& s, int ag) { return s.odir[ag]; }
   static __device__ __forceinline__ int agent_step_type(const State& s, int) { return s.step_type == ST_NONE ? (int)ST_NONE : s.ast; }
   static __device__ __forceinline__ int agent_term(const State& s, int) {
     return (s.step_type != ST_NONE && s.ast >= AST_LAST) ? (int)SGW_MAX_STEPS : (int)SGW_TERM_NONE;

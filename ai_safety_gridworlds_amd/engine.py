@@ -23,7 +23,15 @@ ALL_OUTPUTS = tuple(f for f in N.OUT_FIELDS if f not in ("safety2", "views", "ob
 
 
 # families whose step launch can write the agent windows itself (sgw_out.views / obs_views)
-FUSED_VIEW_FAMILIES = (N.FIREMAKER_EX_MA,)
+FUSED_VIEW_FAMILIES = (N.FIREMAKER_EX_MA, N.ISLAND_NAVIGATION_EX_MA, N.AINTELOPE_SAVANNA)
+
+
+def fused_views(spec):
+  """Can this spec's step launch write the agent windows itself (sgw_out.views / obs_views)?  firemaker_ex_ma always (its
+  workgroup's eight waves share the work); island_navigation_ex_ma / aintelope_savanna when no window is larger than the board."""
+  if spec.family not in FUSED_VIEW_FAMILIES or not getattr(spec, "view_shapes", None):
+    return False
+  return spec.family == N.FIREMAKER_EX_MA or all(h * w <= spec.H * spec.W for (h, w) in spec.view_shapes)
 
 
 def _dtype_shape(spec, name):

@@ -52,6 +52,26 @@ class DiscreteActionSpace(object):
   __contains__ = contains
 
 
+class MultiDiscreteActionSpace(object):
+  """MultiDiscrete(nvec=[n], start=[lo]) stand-in (use_multi_discrete_action_space=True: gym_env.py:220-221, 753-830): one
+  component, so an action is an int32 array of shape (1,); sample() draws as gymnasium's MultiDiscrete does,
+  (random(nvec.shape) * nvec).astype(dtype) + start."""
+
+  def __init__(self, lo, n, np_random):
+    self.start, self.nvec, self._rng = np.array([int(lo)], np.int32), np.array([int(n)], np.int32), np_random
+    self.n, self.min_action, self.max_action = int(n), int(lo), int(lo) + int(n) - 1
+    self.shape, self.dtype = (1,), np.int32
+
+  def sample(self, mask=None):
+    return (self._rng.random(self.nvec.shape) * self.nvec).astype(self.dtype) + self.start
+
+  def contains(self, x):
+    x = np.asarray(x)
+    return x.shape == self.shape and bool(((x >= self.start) & (x < self.start + self.nvec)).all())
+
+  __contains__ = contains
+
+
 class BoxObservationSpace(object):
   def __init__(self, shape, low, high, dtype=np.float32):
     self.shape, self.low, self.high, self.dtype = tuple(shape), low, high, dtype
@@ -75,8 +95,6 @@ class GridworldGymEnv(_Base):
                observable_attribute_value_mapping=None, use_multi_discrete_action_space=False, agent_character=None,
                np_random=None, seed=None, pre_reset_callback=None, post_reset_callback=None, pre_step_callback=None,
                post_step_callback=None, render_mode=None, device="cuda:0", **kwargs):
-    if use_multi_discrete_action_space:
-      raise NotImplementedError("use_multi_discrete_action_space (gym_env.py:152): one Discrete action per step is implemented")
     self.render_mode = render_mode
     self._env_name = env_name
     # experiment bookkeeping of SafetyEnvironmentMo.__init__ (safety_game_mo.py:181-186, 338-385): per wrapper instance here
@@ -90,12 +108,15 @@ class GridworldGymEnv(_Base):
     self.spec_ = self._env.spec
     # multi-agent env behind the single-agent wrapper (gym_env.py:182-189, 476-479): ONE agent is controlled -- the given
     # `agent_character` or the first player -- and stepped alone ({agent: action}); the state is that agent's window
-    self._ma = bool(getattr(self.spec_, "per_agent", False))
+    self._ma = bool(getattr(self.spec_, "per_agent", False)) or self.spec_.family == N.FIREMAKER_EX_MA
+    self._fixed_directions = self.spec_.family == N.FIREMAKER_EX_MA      # no observation / action directions in its state (mode 0)
     if self.spec_.A > 1 and not self._ma:
       raise NotImplementedError("%s: the batched engine plays whole rounds of this env (use GridworldZooParallelEnv)" % env_name)
     if self._ma:
       chars = list(self.spec_.agent_chars)
-      self._agent_index = chars.index(agent_character) if agent_character is not None else 0
+      slots = list(getattr(self.spec_, "agent_slots", range(len(chars))))     # the library's column of each agent character
+      self._agent_chr = agent_character if agent_character is not None else chars[0]
+      self._agent_index = slots[chars.index(self._agent_chr)]
       self._ma_ascii = bool(ascii_observation_format)
       self._vm = np.array([self.spec_.native.value_map[i] for i in range(128)], np.float32)
       self._seed_env(seed)
@@ -116,7 +137,8 @@ class GridworldGymEnv(_Base):
     self._internal_np_random = np_random if np_random is not None else np.random.Generator(
         np.random.PCG64(np.random.SeedSequence(seed)))
     sp = self.spec_
-    self._action_space = DiscreteActionSpace(sp.action_lo, sp.n_actions, self._internal_np_random)
+    self._action_space = (MultiDiscreteActionSpace if use_multi_discrete_action_space else DiscreteActionSpace)(
+        sp.action_lo, sp.n_actions, self._internal_np_random)
     vals = list(sp.value_mapping.values())
     shape = (2 if use_transitions else 1, sp.H, sp.W)
     if flatten_observations:
@@ -139,7 +161,7 @@ class GridworldGymEnv(_Base):
       self._seed_env(seed)
 
   def _seed_env(self, seed):                     # environment_data[NP_RANDOM] = seeding.np_random(seed)[0]
-    if getattr(self.spec_, "needs_rng", False):
+    if getattr(self.spec_, "needs_rng", False) or self.spec_.family == N.FIREMAKER_EX_MA:
       st = np.random.PCG64(np.random.SeedSequence(seed)).state["state"]
       m = (1 << 64) - 1
       self._env.engine.set_rng_state(np.array([[st["state"] >> 64, st["state"] & m, st["inc"] >> 64, st["inc"] & m]],
@@ -193,26 +215,35 @@ class GridworldGymEnv(_Base):
     o = {k: v[0].detach().cpu().numpy() for k, v in ts.observation.items()}
     return o
 
+  def _dim_names(self):
+    """The controlled agent's reward dimensions (firemaker's workers and supervisor have different ones)."""
+    sp = self.spec_
+    if self._ma and getattr(sp, "agent_dim_names", None):
+      return list(sp.agent_dim_names[self._agent_chr])
+    return list(sp.dim_names)
+
   def _compute_info(self, o, first):
     sp = self.spec_
     K = sp.K
     ai = self._agent_index if self._ma else 0
-    reward = o["reward"].reshape(-1)[ai * K:(ai + 1) * K]
-    cum = o["cumulative"].reshape(-1)[ai * K:(ai + 1) * K]
+    names = self._dim_names()
+    reward = o["reward"].reshape(-1)[ai * K:ai * K + len(names)]
+    cum = o["cumulative"].reshape(-1)[ai * K:ai * K + len(names)]
     frame = int(o["frame"])
+    tri = ai if o["term_reason"].size > 1 else 0                # per agent only where agents finish one by one
     extra = {}
     if int(o["actual_action"].reshape(-1)[0]) >= 0:
       extra["actual_actions"] = int(o["actual_action"].reshape(-1)[0])
     if int(o["step_type"].reshape(-1)[ai]) == N.LAST:
-      extra["termination_reason"] = TerminationReason(int(o["term_reason"].reshape(-1)[ai]))
+      extra["termination_reason"] = TerminationReason(int(o["term_reason"].reshape(-1)[tri]))
     info = {
         "observation_direction": None, "action_direction": DIRECTION_UP,
         "board": o["obs_board"].copy(), "ascii_codes": o["board"].copy(),
         "ascii": np.vectorize(chr)(o["board"]), "extra_observations": extra,
     }
     if not sp.scalar:                           # safety_game_mo.py:1012-1084
-      info["reward_dict"] = dict(zip(sp.dim_names, reward.tolist()))
-      info["cumulative_reward_dict"] = dict(zip(sp.dim_names, cum.tolist()))
+      info["reward_dict"] = dict(zip(names, reward.tolist()))
+      info["cumulative_reward_dict"] = dict(zip(names, cum.tolist()))
       metrics = o["metrics"].reshape(-1)[:sp.M]
       info["metrics_dict"] = dict(zip(sp.metric_names, metrics.tolist()))
       mm = np.empty([sp.M, 2], object)
@@ -224,7 +255,7 @@ class GridworldGymEnv(_Base):
       ds = self._env.engine.derived_stats()
       pick = (lambda t: t[0, ai] if self._ma else t[0])
       info["cumulative_reward"] = cum.copy()
-      info["average_reward"] = pick(ds["average_reward"]).cpu().numpy()[:len(sp.dim_names)].astype(np.float64)
+      info["average_reward"] = pick(ds["average_reward"]).cpu().numpy()[:len(names)].astype(np.float64)
       for key in ("gini_index", "cumulative_gini_index", "mo_variance", "cumulative_mo_variance", "average_mo_variance"):
         info[key] = np.float64(pick(ds[key]).item())
       lay = None
@@ -250,9 +281,10 @@ class GridworldGymEnv(_Base):
         else:
           info["info_observation_layers_cube"] = np.stack([ascii_board == c for c in order], axis=0)
       if self._ma:                                                # gym_env.py:373-384, 428-439: the controlled agent's own window
-        ch = sp.agent_chars[self._agent_index]
+        ch = self._agent_chr
         flags = int(o["agent_flags"].reshape(-1)[ai])
-        info["observation_direction"], info["action_direction"] = (flags >> 3) & 3, (flags >> 1) & 3
+        if not self._fixed_directions:
+          info["observation_direction"], info["action_direction"] = (flags >> 3) & 3, (flags >> 1) & 3
         view = self._env.engine.agent_views()[ai][0].cpu().numpy()
         info["info_agent_observations"] = np.vectorize(chr)(view) if self._ma_ascii else self._vm[view]
         if lay is not None:
@@ -341,7 +373,7 @@ class GridworldGymEnv(_Base):
       r = float(o["reward"].reshape(-1)[0])
       reward = int(r) if r == int(r) else r
     else:
-      reward = o["reward"].reshape(-1)[ai * sp.K:(ai + 1) * sp.K].astype(np.float64).copy()
+      reward = o["reward"].reshape(-1)[ai * sp.K:ai * sp.K + len(self._dim_names())].astype(np.float64).copy()
     if sp.scalar:                                # gym_env.py:498-505
       cumulative_hidden = float(o["hidden"])
       hidden_reward = cumulative_hidden - self._last_hidden_reward

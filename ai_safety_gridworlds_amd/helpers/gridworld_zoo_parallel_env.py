@@ -24,7 +24,7 @@ try:
 except Exception:                       # pragma: no cover - pettingzoo absent in this image
   _Base = object
 
-from .gridworld_gym_env import DiscreteActionSpace, BoxObservationSpace
+from .gridworld_gym_env import DiscreteActionSpace, MultiDiscreteActionSpace, BoxObservationSpace
 
 OUTS = ("board", "obs_board", "reward", "cumulative", "step_type", "term_reason", "discount", "metrics", "frame",
         "agent_pos", "agent_flags", "hidden", "actual_action")
@@ -57,10 +57,7 @@ class GridworldZooParallelEnv(_Base):
                pre_reset_callback=None, post_reset_callback=None, pre_step_callback=None, post_step_callback=None,
                render_mode=None, device="cuda:0", **kwargs):
     """Same parameters as the reference wrapper (gridworld_zoo_parallel_env.py:100-135).  The observable-attribute parameters are
-    accepted and unused (no environment of the reference defines observable attributes); `use_multi_discrete_action_space` is
-    refused."""
-    if use_multi_discrete_action_space:
-      raise NotImplementedError("use_multi_discrete_action_space is not implemented")
+    accepted and unused (no environment of the reference defines observable attributes)."""
     if occlusion_in_layers:
       raise NotImplementedError("occlusion_in_layers=True: the reference's branch (safety_game_moma.py:607-618) raises NameError "
                                 "at this snapshot")
@@ -94,7 +91,8 @@ class GridworldZooParallelEnv(_Base):
     self._last_hidden_reward = {a: 0.0 for a in self.possible_agents}
     self._state = None
     self._vm = np.array([sp.native.value_map[i] for i in range(128)], np.float32)
-    self._action_spaces = {a: DiscreteActionSpace(sp.action_lo, sp.n_actions, self._np_random) for a in self.possible_agents}
+    space = MultiDiscreteActionSpace if use_multi_discrete_action_space else DiscreteActionSpace       # zoo.py:225-228
+    self._action_spaces = {a: space(sp.action_lo, sp.n_actions, self._np_random) for a in self.possible_agents}
     vals = list(sp.value_mapping.values())
     self._observation_spaces = {}
     for i, a in enumerate(self.possible_agents):
@@ -320,7 +318,7 @@ class GridworldZooParallelEnv(_Base):
         if a in actions:
           raise ValueError("Agent %s is done" % self.agent_name_mapping[a])      # pycolab_interface_ma.py:218
         continue
-      if a not in actions and getattr(sp, "per_agent", False):
+      if a not in actions and (getattr(sp, "per_agent", False) or sp.family == N.FIREMAKER_EX_MA):
         acts[q] = -1                       # not in the submitted dict: the agent does not play this round (PM:173-246)
         continue
       v = actions.get(a, 0)

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from .. import _native as N
-from ..engine import FUSED_VIEW_FAMILIES
+from ..engine import fused_views
 from ..environments import BatchedSafetyEnvironment
 from ..specs import make_spec
 
@@ -38,7 +38,7 @@ class GridworldZooVectorEnv(object):
 
   def __init__(self, env_name, num_envs, ascii_observation_format=True, layers_in_observation=False, seed=None, device="cuda:0",
                env_id_base=0, **kwargs):
-    self._fused = make_spec(env_name, **kwargs).family in FUSED_VIEW_FAMILIES
+    self._fused = fused_views(make_spec(env_name, **kwargs))
     self._ascii = bool(ascii_observation_format)
     outs = OUTS + ((("views",) if self._ascii else ("obs_views",)) if self._fused else ())
     self._env = BatchedSafetyEnvironment(env_name, num_envs=num_envs, device=device, env_id_base=env_id_base, outputs=outs,
@@ -144,8 +144,8 @@ class GridworldZooVectorEnv(object):
     return obs, infos
 
   def step(self, actions):
-    """actions: {agent: int8 / int64 tensor [N] on the device (or a python int for every env)}; a missing agent plays NOOP
-    (per-agent families: does not play this round).  Or ONE int8 tensor [N, A] already in the library's column order
+    """actions: {agent: int8 / int64 tensor [N] on the device (or a python int for every env)}; a missing agent does not play
+    this round (EnvironmentMa.step plays exactly the agents in the dict).  Or ONE int8 tensor [N, A] already in the library's column order
     (`agent_slots`): no per-agent copy."""
     sp = self.spec_
     if torch.is_tensor(actions):                                 # already the library's layout: int8 [N, A] by column (no copy)
@@ -154,8 +154,8 @@ class GridworldZooVectorEnv(object):
       for i, a in enumerate(self.possible_agents):
         col = self._acts[:, self._slots[i]]
         v = actions.get(a)
-        if v is None:
-          col.fill_(-1 if self._per_agent else 0)
+        if v is None:                                            # not in the dict: the agent does not play this round (PM:173-246)
+          col.fill_(-1)
         elif torch.is_tensor(v):
           col.copy_(v.reshape(-1))
         else:

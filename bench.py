@@ -38,7 +38,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from ai_safety_gridworlds_amd import parallel                   # noqa: E402
-from ai_safety_gridworlds_amd.engine import BatchedEngine, EngineGroup, FUSED_VIEW_FAMILIES      # noqa: E402
+from ai_safety_gridworlds_amd.engine import BatchedEngine, EngineGroup, fused_views      # noqa: E402
 from ai_safety_gridworlds_amd.specs import make_spec            # noqa: E402
 
 SEED = 0x5AFE
@@ -394,7 +394,7 @@ def main():
   # what the Zoo wrapper hands to the agents as observations -- written by the SAME launch (sgw_out.views: the
   # round kernel assembles them from the board rows it holds in LDS); after the main measurement so that it cannot disturb it
   with_views = None
-  if a.workload != "mixed" and world == 1 and engines[0]["spec"].family in FUSED_VIEW_FAMILIES:
+  if a.workload != "mixed" and world == 1 and fused_views(engines[0]["spec"]):
     e = engines[0]
     engv = prepare_engine(e["fam"], e["spec"], e["n"], rank * e["n"], device, tuple(e["wl"]["outputs"]) + ("views",))
     vb = int(engv._lib.sgw_view_bytes(engv._h))

@@ -362,15 +362,17 @@ int or_ma_reset(or_ma_env* e, or_ma_timestep* out) {           /* safety_game_mo
 }
 
 int or_ma_step(or_ma_env* e, const int8_t* actions, or_ma_timestep* out) {   /* pycolab_interface_ma.py:173-246 */
-  int order[FM_MAXA];
-  for (int a = 0; a < e->A; ++a) order[a] = a;
-  if (e->cfg.randomize_agent_actions_order && e->A > 1)          /* Generator.shuffle(list): Fisher-Yates from the top */
-    for (int i = e->A - 1; i >= 1; --i) {
+  /* the submitted dict: an action < 0 = that agent is not in it (pycolab_interface_ma.py:173-246 plays exactly the agents it is
+   * given, in dict = update-schedule order; the Gym wrapper with agent_character submits one, gridworld_gym_env.py:476-479) */
+  int order[FM_MAXA], n = 0;
+  for (int a = 0; a < e->A; ++a) if (actions[e->slot[a]] >= 0) order[n++] = a;
+  if (e->cfg.randomize_agent_actions_order && n > 1)             /* Generator.shuffle(list): Fisher-Yates from the top */
+    for (int i = n - 1; i >= 1; --i) {
       int j = (int)random_interval(&e->rng, (uint64_t)i);
       int t = order[i]; order[i] = order[j]; order[j] = t;
     }
   memset(e->last_reward, 0, sizeof(e->last_reward));
-  for (int i = 0; i < e->A; ++i) {
+  for (int i = 0; i < n; ++i) {
     int a = order[i];
     if (e->state[a] == 2 || e->state[a] == 3) {
       int all = 1;

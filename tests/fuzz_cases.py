@@ -78,12 +78,19 @@ def ma_case(rnd, which, E=800, T=150, nthreads=16, strict=False):
     want = Or.run_streams(Or.make_config(**kw), actions, rng, nthreads=nthreads)
   except ValueError as ex:
     return (which, kw, "oracle refused: %s" % ex)
-  outs = ("board", "reward", "cumulative", "step_type", "frame", "metrics")
+  from ai_safety_gridworlds_amd.engine import fused_views
+  fused = fused_views(spec)
+  outs = ("board", "reward", "cumulative", "step_type", "frame", "metrics", "agent_pos", "agent_flags") + (("views",) if fused else ())
   eng = BatchedEngine(spec, E, outputs=outs); eng.set_rng_state(rng)
   a = torch.from_numpy(np.ascontiguousarray(np.transpose(actions, (1, 0, 2)))).to("cuda:0")
   rec = {k: [] for k in outs}
+  views_ok = [True]
   def grab(o):
     for k in outs: rec[k].append(o[k].clone())
+    # the windows written by the round's launch == the separate window kernel on the same board (rot90-ed by the observation direction)
+    if fused:
+      for f, w in zip(eng.split_views(o["views"]), eng.agent_views()):
+        views_ok[0] &= bool(torch.equal(f, w))
   grab(eng.reset()); grab(eng.reset())
   for t in range(T):
     grab(eng.reset() if actions[0, t, 0] == -128 else eng.step(a[t]))
@@ -99,7 +106,7 @@ def ma_case(rnd, which, E=800, T=150, nthreads=16, strict=False):
   partial = (actions[:, :, :A] == -1).any(axis=2)
   valid = ~(done_before & partial).any(axis=1) if strict else np.ones(E, bool)
   v = valid
-  ok = bool((got["board"][v, 1:].reshape(want["board"][v, 1:].shape) == want["board"][v, 1:]).all())
+  ok = views_ok[0] and bool((got["board"][v, 1:].reshape(want["board"][v, 1:].shape) == want["board"][v, 1:]).all())
   ok &= bool((got["step_type"][v, 1:, :A] == want["step_type"][v, 1:]).all())
   g = got["reward"][v, 1:].reshape(int(v.sum()), S - 1, 2, spec.K)[:, :, :A]; ok &= bool((g == want["reward"][v, 1:]).all())
   g = got["cumulative"][v, 1:].reshape(int(v.sum()), S - 1, 2, spec.K)[:, :, :A]; ok &= bool((g == want["cumulative"][v, 1:]).all())

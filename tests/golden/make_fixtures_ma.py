@@ -31,6 +31,9 @@ CONFIGS = {
     # three-column ('1','2','S') layout, absent agents' columns stay zero; metrics sit at their METRICS_LABELS_TEMPLATE rows.
     "firemaker_L0_a2": (dict(amount_agents=2, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.03, max_iterations=120), 16, 200),
     "firemaker_L0_a1": (dict(amount_agents=1, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.03, max_iterations=120), 16, 200),
+    # rounds with a SUBSET of the agents in the submitted dict (EnvironmentMa.step plays exactly those, pycolab_interface_ma.py:
+    # 173-246; what the Gym wrapper with agent_character does every step): actions < 0 in the recorded array = not submitted
+    "firemaker_L0_subset": (dict(amount_agents=3, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.04, max_iterations=90), 16, 200),
     # randomize_agent_actions_order=False cannot be configured through the reference constructor: it passes the
     # flag explicitly AND leaves it in **kwargs (firemaker_ex_ma.py:816-847) -> TypeError "multiple values".
 }
@@ -66,6 +69,16 @@ def main():
     SLOT = {'1': 0, '2': 1, 'S': 2}
     TEMPLATE = list(m.METRICS_LABELS_TEMPLATE)
     acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(A)], axis=-1)  # [T,E,A]
+    if name.endswith("_subset"):        # two ticks out of three: one or two agents only (which ones varies with the tick and the stream)
+      acts = acts.astype(np.int8)
+      for t in range(T):
+        for e in range(E):
+          if t % 3 == 1:
+            keep = (t // 3 + e) % 3
+            for q in range(3):
+              if q != keep: acts[t, e, q] = -1
+          elif t % 3 == 2:
+            acts[t, e, (t // 3 + 2 * e) % 3] = -1
     rec = dict(
         actions=np.transpose(acts, (1, 0, 2)).copy(),          # [E, T, A]
         seeds=np.zeros(E, np.int64), rng_init=np.zeros((E, 4), np.uint64),
@@ -102,8 +115,11 @@ def main():
           if ts.reward is not None and ts.reward.get(ch) is not None:
             r = np.asarray(ts.reward[ch], dtype=np.float64)
             rec["reward"][e, t, ai, :len(r)] = r
-          c = np.asarray(ts.observation["cumulative_reward"][ch], dtype=np.float64)
-          rec["cumulative"][e, t, ai, :len(c)] = c
+          cr = ts.observation["cumulative_reward"]
+          if ch in cr:                # (an agent outside the submitted dict may have no observation entry)
+            c = np.asarray(cr[ch], dtype=np.float64)
+            rec["cumulative"][e, t, ai, :len(c)] = c
+            rec.setdefault("cumulative_present", np.zeros((E, S, A), bool))[e, t, ai] = True
           sp = env.environment_data['agent_sprite'][ch]
           rec["pos"][e, t, ai] = [sp.position.row, sp.position.col]
           tr = ts.observation["extra_observations"].get("termination_reason")
@@ -149,7 +165,7 @@ def main():
       record(0, ts)
       for t in range(T):
         a = acts[t, e]
-        ts = env.step({ch: {'step': int(a[SLOT[ch]])} for ch in agents})
+        ts = env.step({ch: {'step': int(a[SLOT[ch]])} for ch in agents if a[SLOT[ch]] >= 0})
         record(t + 1, ts)
     dt = time.time() - t0
     meta = dict(name=name, family="firemaker_ex_ma", kwargs=repr(sorted(kw.items())), E=E, T=T, seed=SEED,

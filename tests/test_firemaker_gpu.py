@@ -192,3 +192,34 @@ def test_firemaker_views_of_a_masked_reset_and_of_step_n():
     assert torch.equal(got[i][m], want[i][m]), i
   assert torch.equal(o["views"][~m], before[~m])                    # the other envs' rows were left alone
   eng.close()
+
+
+@pytest.mark.parametrize("agent", ["1", "S"])
+def test_firemaker_through_the_gym_facade_with_agent_character(agent):
+  """GridworldGymEnv("firemaker_ex_ma", agent_character=...) steps ONE agent per step ({agent: action}: gridworld_gym_env.py:
+  182-189, 476-479; EnvironmentMa.step plays exactly the submitted agents, pycolab_interface_ma.py:173-246) -- against the
+  multi-agent oracle fed the same single-agent rounds (pinned on the reference run firemaker_L0_subset)."""
+  from oracle import oracle_ma as OM
+  from ai_safety_gridworlds_amd.helpers.gridworld_gym_env import GridworldGymEnv
+  kw = dict(amount_agents=3, max_iterations=50, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.05)
+  T, seed, q = 120, 31, {"1": 0, "2": 1, "S": 2}[agent]
+  own = philox.actions(seed, np.arange(1), np.arange(T), 0, 5, agent=q)[:, 0]
+  actions = np.full((1, T, 3), -1, np.int8); actions[0, :, q] = own
+  want = OM.run_streams(OM.make_config(**kw), actions, OM.rng_state_words(seed)[None])
+  env = GridworldGymEnv("firemaker_ex_ma", agent_character=agent, seed=seed, **kw)
+  state, info = env.reset()
+  view = want["view_worker"][0, :, q] if q < 2 else want["view_supervisor"][0]
+  assert np.array_equal(state[0], np.vectorize(chr)(view[0]))
+  k = 2 if q < 2 else 3
+  for t in range(T):
+    state, reward, terminated, truncated, info = env.step(int(own[t]))
+    st = int(want["step_type"][0, t + 1, q])
+    assert np.array_equal(state[-1] if state.ndim == 3 else state, np.vectorize(chr)(view[t + 1])), t
+    assert terminated == (st == 2) and truncated is False, t
+    if st == 0:
+      assert np.all(np.asarray(reward) == 0.0), t
+    else:
+      assert np.array_equal(reward, want["reward"][0, t + 1, q, :k]), t
+      assert list(info["reward_dict"]) == (["ENERGY", "WORKSHOP"] if q < 2 else ["ENERGY", "EXTERNAL_FIRE", "TRESPASSING"])
+      assert np.array_equal(info["cumulative_reward"], want["cumulative"][0, t + 1, q, :k]), t
+  env.close()

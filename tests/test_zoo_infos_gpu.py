@@ -117,6 +117,29 @@ def test_callbacks_with_the_reference_signatures():
   g.close()
 
 
+def test_multi_discrete_action_spaces():
+  """use_multi_discrete_action_space=True (gridworld_gym_env.py:220-221, 753-830; gridworld_zoo_parallel_env.py:225-228): the
+  action space is MultiDiscrete([n], start=[min]) with shape (1,), and step() takes its samples."""
+  from ai_safety_gridworlds_amd.helpers.gridworld_gym_env import GridworldGymEnv
+  g = GridworldGymEnv("boat_race_ex", level=3, use_multi_discrete_action_space=True, seed=1)
+  sp = g.action_space
+  assert sp.shape == (1,) and sp.nvec.tolist() == [5] and sp.start.tolist() == [0] and sp.min_action == 0 and sp.max_action == 4
+  g.reset()
+  for _ in range(20):
+    a = sp.sample()
+    assert a.shape == (1,) and a.dtype == np.int32 and a in sp
+    state, reward, terminated, truncated, info = g.step(a)
+  assert np.array([7], np.int32) not in sp
+  g.close()
+  z = Z.GridworldZooParallelEnv("island_navigation_ex_ma", level=9, seed=3, use_multi_discrete_action_space=True)
+  z.reset()
+  acts = {a: z.action_space(a).sample() for a in z.possible_agents}
+  assert all(v.shape == (1,) for v in acts.values())
+  obs, rewards, terms, truncs, infos = z.step(acts)
+  assert set(rewards) == set(z.possible_agents)
+  z.close()
+
+
 def test_zoo_vector_layer_cubes_equal_the_single_env_facade():
   """The batched facade's cubes (device tensors) == the one-env facade's, env by env, over a few rounds."""
   import torch

@@ -3,7 +3,8 @@ sys.path.insert(0, "/root/repo")
 import torch
 from ai_safety_gridworlds_amd.helpers.gridworld_zoo_vector_env import GridworldZooVectorEnv
 for name, n, kw, layers in (("island_navigation_ex_ma", 65536, {}, False), ("island_navigation_ex_ma", 65536, {}, True),
-                            ("aintelope_savanna", 65536, dict(amount_agents=2), False), ("firemaker_ex_ma", 16384, dict(amount_agents=3), True)):
+                            ("aintelope_savanna", 65536, dict(amount_agents=2), False), ("firemaker_ex_ma", 16384, dict(amount_agents=3), False),
+                            ("firemaker_ex_ma", 16384, dict(amount_agents=3), True)):
   z = GridworldZooVectorEnv(name, num_envs=n, seed=0, layers_in_observation=layers, **kw)
   z.reset()
   A = z.spec_.A
