@@ -420,8 +420,9 @@ template <class F, int KIND> static int plan_launch(const sgw_engine* e, KArgs& 
     return fail(SGW_ERR_UNSUPPORTED, "launch: a window larger than the board is not assembled inside this family's round kernel (one "
                                      "wavefront per 64 envs would walk them env by env): use sgw_agent_views");
   const int vb = a.sp.view_total > 0 ? a.sp.view_total : 0;
-  a.lp = lds_plan(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, vb); a.need = need;
-  p.lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, vb, F::LDS_EXTRA, EW, NB);
+  const int CS = cum_stash_rows<F>(a.sp.A, a.sp.K);
+  a.lp = lds_plan(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, vb, CS); a.need = need;
+  p.lds_bytes = lds_total_bytes(a.sp.HW, a.sp.A, a.sp.K, a.sp.M, pa, need, vb, F::LDS_EXTRA, EW, NB, CS);
   p.blocks = (unsigned)((n_waves + EW - 1) / EW);
   p.threads = (unsigned)wg_threads<F, KIND>();
   // the bytes requested == the bytes the plan hands out (checked on every launch)

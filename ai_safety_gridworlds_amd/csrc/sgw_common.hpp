@@ -36,7 +36,7 @@ struct KSpec {
 
 // byte offsets of one env-wave staging buffer's regions, computed ONCE per launch on the host (lds_plan) and read from the
 // kernarg segment where needed: deriving them on the device cost a ~30-instruction scalar chain per region with spilled terms
-struct LdsPlan { int wave_bytes, vec_r, vec_c, vec_m, vec_a, trash, flag, ain, st, tr, act, pos, flg, disc, hid, saf, frm, views; };
+struct LdsPlan { int wave_bytes, vec_r, vec_c, vec_m, vec_a, trash, flag, ain, st, tr, act, pos, flg, disc, hid, saf, frm, views, cstash; };
 
 struct KArgs {
   KSpec sp;
@@ -157,6 +157,7 @@ struct Lds {
   double *disc, *hid;                // discount [64], hidden [64]
   int32_t *saf, *frm;                // safety [64][PA], frame [64]
   uint8_t* views;          // 64 * view_total bytes: the wave's 64 rows of agent windows, contiguous as in global memory
+  double* cstash;          // [NU][64] doubles: the lanes' cumulative reward vectors parked while the rules run (families with CUM_IN_LDS)
   double* vec_a;           // 64*(A*K+1) doubles: finished-episode returns staged for the per-wave sum
   uint32_t* flag;          // [4] per-step words handed from the computing wave to the draining wave (pipelined rollout)
   int8_t* ain;             // [A][64] synthetic actions handed from the draining wave to the computing wave (pipelined rollout)
@@ -204,18 +205,19 @@ __host__ __device__ inline size_t lds_small_bytes(int A, int pa, int need, int w
   }
 }
 // one staging buffer of one env-wave
-__host__ __device__ inline size_t lds_wave_bytes(int HW, int A, int K, int M, int pa, int need, int vb) {
+__host__ __device__ inline size_t lds_wave_bytes(int HW, int A, int K, int M, int pa, int need, int vb, int cs = 0) {
   const size_t rows = lds_rows(A, K, M, need, LN_REWARD) + lds_rows(A, K, M, need, LN_CUMULATIVE) +
                       lds_rows(A, K, M, need, LN_METRICS) + lds_rows(A, K, M, need, LN_RETURNS) + 1;   // + trash
   size_t small = 16 + (size_t)(64 * A + 15) / 16 * 16;                  // flag words + the synthetic-action inbox (pipelined rollout)
   for (int w = LN_ST; w <= LN_FRM; w <<= 1) small += lds_small_bytes(A, pa, need, w);
-  return lds_board_bytes(HW) + rows * 64 * 8 + small + lds_view_bytes(vb, need);
+  const bool cs_aliased = (need & (LN_REWARD | LN_CUMULATIVE | LN_RETURNS)) != 0;
+  return lds_board_bytes(HW) + rows * 64 * 8 + small + lds_view_bytes(vb, need) + (cs_aliased ? 0 : (size_t)cs * 512);
 }
-__host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M, int pa, int need, int vb, int extra, int env_waves, int buffers) {
-  return TABLE_BYTES + (size_t)extra + (size_t)env_waves * buffers * lds_wave_bytes(HW, A, K, M, pa, need, vb);
+__host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M, int pa, int need, int vb, int extra, int env_waves, int buffers, int cs = 0) {
+  return TABLE_BYTES + (size_t)extra + (size_t)env_waves * buffers * lds_wave_bytes(HW, A, K, M, pa, need, vb, cs);
 }
 
-__host__ __device__ inline LdsPlan lds_plan(int HW, int A, int K, int M, int pa, int need, int vb) {
+__host__ __device__ inline LdsPlan lds_plan(int HW, int A, int K, int M, int pa, int need, int vb, int cs = 0) {
   LdsPlan p;
   int o = (int)lds_board_bytes(HW);
   p.vec_r = o; o += 512 * (int)lds_rows(A, K, M, need, LN_REWARD);
@@ -235,6 +237,14 @@ __host__ __device__ inline LdsPlan lds_plan(int HW, int A, int K, int M, int pa,
   p.saf = o; o += (int)lds_small_bytes(A, pa, need, LN_SAF);
   p.frm = o; o += (int)lds_small_bytes(A, pa, need, LN_FRM);
   p.views = o; o += (int)lds_view_bytes(vb, need);
+  // the parked cumulative vectors (families with CUM_IN_LDS; cs = A * K rows, indexed by output column) live in a staging region
+  // that is only written AFTER the rules -- the reward rows, else the cumulative rows, else the returns rows -- and get rows of
+  // their own only when none of those outputs is requested: an extra 11 KB per workgroup took aintelope_savanna from four
+  // resident workgroups per CU to three, and a quarter of a 65 536-env launch then waits for a second turn (81 instead of 47 us)
+  if (cs > 0 && (need & LN_REWARD)) p.cstash = p.vec_r;
+  else if (cs > 0 && (need & LN_CUMULATIVE)) p.cstash = p.vec_c;
+  else if (cs > 0 && (need & LN_RETURNS)) p.cstash = p.vec_a;
+  else { p.cstash = o; o += cs * 512; }
   p.wave_bytes = o;
   return p;
 }
@@ -260,6 +270,7 @@ __host__ __device__ inline Lds lds_carve(uint8_t* smem, const LdsPlan& p, int ex
   l.disc = reinterpret_cast<double*>(w + p.disc); l.hid = reinterpret_cast<double*>(w + p.hid);
   l.saf = reinterpret_cast<int32_t*>(w + p.saf); l.frm = reinterpret_cast<int32_t*>(w + p.frm);
   l.views = w + p.views;
+  l.cstash = reinterpret_cast<double*>(w + p.cstash);
   return l;
 }
 

@@ -43,6 +43,12 @@ template <class F, class = void> struct step_rereads : std::false_type {};
 template <class F> struct step_rereads<F, std::void_t<decltype(F::STEP_REREADS_ARGS)>> : std::integral_constant<bool, F::STEP_REREADS_ARGS> {};
 template <class F, class = void> struct rollout_rereads : std::true_type {};
 template <class F> struct rollout_rereads<F, std::void_t<decltype(F::ROLLOUT_KEEPS_ARGS)>> : std::integral_constant<bool, !F::ROLLOUT_KEEPS_ARGS> {};
+// families whose cumulative reward vector (NU doubles per lane: 52 VGPRs in aintelope_savanna) is PARKED IN LDS while the rules
+// run: nothing in the rules reads it, so its registers are free for them (`static constexpr bool CUM_IN_LDS = true`)
+template <class F, class = void> struct cum_in_lds : std::false_type {};
+template <class F> struct cum_in_lds<F, std::void_t<decltype(F::CUM_IN_LDS)>> : std::integral_constant<bool, F::CUM_IN_LDS> {};
+// (rows of the stash: one per enabled output column, A * K)
+template <class F> __host__ __device__ inline int cum_stash_rows(int A, int K) { return cum_in_lds<F>::value ? A * K : 0; }
 template <class F, class = void> struct has_init_args : std::false_type {};
 template <class F> struct has_init_args<F, std::void_t<decltype(&F::init_args)>> : std::true_type {};
 // families that write their row of the rendered board into the wave's LDS image themselves
@@ -578,6 +584,7 @@ template <class F> struct family_pipelines<F, std::void_t<decltype(F::ROLLOUT_PI
 // 1 M -- the second wave's start-up and the hand-over barrier cost more than the store issue it takes off the first)
 template <class F, int KIND> constexpr bool pipelined() { return KIND == K_ROLLOUT && !F::COOPERATIVE && family_pipelines<F>::value; }
 // a pipelined workgroup holds at most two env-waves = four wavefronts, one per SIMD, each with the full register file
+static_assert(true, "");
 template <class F, int KIND> constexpr int env_waves() {
   return F::COOPERATIVE ? 1 : (pipelined<F, KIND>() ? (family_env_waves<F>::value < 2 ? family_env_waves<F>::value : 2) : family_env_waves<F>::value);
 }
@@ -735,6 +742,10 @@ __device__ __forceinline__ void engine_body(const KArgs& a, const long long bloc
     for (int u = 0; u < F::NU; ++u) r[u] = 0.0;
     double discount = __longlong_as_double(0x7ff8000000000000LL);   // None at FIRST
     bool over_now = false;
+    if constexpr (cum_in_lds<F>::value) {                           // park the cumulative vector (re-read below, on every path)
+#pragma unroll
+      for (int u = 0; u < F::NU; ++u) { const int q = F::slot(a.sp, u); if (q >= 0) l.cstash[q * WAVE + lane] = s.cum[u]; }   // (a dimension that is not enabled stays 0)
+    }
     if constexpr (!F::COOPERATIVE) {
       int action[F::NA];
 #pragma unroll
@@ -751,6 +762,10 @@ __device__ __forceinline__ void engine_body(const KArgs& a, const long long bloc
         // multi-agent adapter, finished episode, no eligible agent in the submitted dict (PM:173-246: the play loop does not
         // run, so nothing resets): only the per-agent states move on (LAST -> DEAD); rewards are the default zeros
         if constexpr (has_idle_round<F>::value) discount = F::idle_round(s);
+        if constexpr (cum_in_lds<F>::value) {
+#pragma unroll
+          for (int u = 0; u < F::NU; ++u) { const int q = F::slot(a.sp, u); s.cum[u] = q >= 0 ? l.cstash[q * WAVE + lane] : 0.0; }
+        }
       } else if (s.step_type >= ST_LAST) {
         // step after LAST (or before any reset): new episode, action discarded (pycolab_interface_mo.py:175-178); the
         // multi-agent adapters still shuffle the discarded actions when more than one was submitted
@@ -762,7 +777,10 @@ __device__ __forceinline__ void engine_body(const KArgs& a, const long long bloc
         s.step_type = over ? ST_LAST : ST_MID;
         if (over && s.term == TERM_NONE4) s.term = SGW_MAX_STEPS;                   // safety_game.py:294-296
 #pragma unroll
-        for (int u = 0; u < F::NU; ++u) s.cum[u] += r[u];                          // safety_game_mo.py:996-997
+        for (int u = 0; u < F::NU; ++u) {                                          // safety_game_mo.py:996-997
+          if constexpr (cum_in_lds<F>::value) { const int q = F::slot(a.sp, u); s.cum[u] = (q >= 0 ? l.cstash[q * WAVE + lane] : 0.0) + r[u]; }
+          else s.cum[u] += r[u];
+        }
         over_now = over;
       }
     } else {

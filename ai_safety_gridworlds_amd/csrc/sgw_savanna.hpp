@@ -124,6 +124,7 @@ struct Savanna {
   static constexpr int ENV_WAVES_MAX = 1;    // env-waves per workgroup (LDS: every output staged must fit 160 KiB)
   static constexpr bool PER_AGENT = true;
   static constexpr bool VIEWS = true;       // sgw_out.views: the agents' windows leave with the round's launch
+  static constexpr bool CUM_IN_LDS = true;  // the cumulative vectors wait in LDS while the rules run (sgw_kernels.hpp cum_in_lds)
   struct Ctx {};
   static __device__ __forceinline__ void init_ctx(Ctx&, const Lds&) {}
 
