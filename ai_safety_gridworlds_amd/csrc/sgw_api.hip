@@ -85,7 +85,7 @@ static void drop_graphs(sgw_engine* e) {      // any setter that changes what a 
 }
 
 static size_t acc_bytes(const sgw_engine* e) {              // [env-waves * parts][A*K+1] doubles
-  return (size_t)(e->spec.A * e->spec.K + 1) * (size_t)(e->n_pad / WAVE) * SGW_ACC_PARTS * 8;
+  return (size_t)(e->spec.A * e->spec.K + 1) * (size_t)(SGW_ACC_PER_ENV ? e->n_pad : e->n_pad / WAVE * SGW_ACC_PARTS) * 8;
 }
 
 // island_navigation_ex: the packed (i16) state when the spec proves it exact (sgw_island.hpp); SGW_ISLAND_PLAIN_STATE in the
@@ -765,7 +765,7 @@ int sgw_read_returns(sgw_engine* e, double* out_dev, int clear, void* stream) {
   int rc = ensure_acc(e, (hipStream_t)stream);
   if (rc) return rc;
   hipLaunchKernelGGL(k_read_returns, dim3(e->spec.A * e->spec.K + 1), dim3(256), 0, (hipStream_t)stream, e->acc_dev,
-                     e->n_pad / WAVE * SGW_ACC_PARTS, e->spec.A * e->spec.K + 1, out_dev, clear);
+                     SGW_ACC_PER_ENV ? e->n_pad : e->n_pad / WAVE * SGW_ACC_PARTS, e->spec.A * e->spec.K + 1, out_dev, clear);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }

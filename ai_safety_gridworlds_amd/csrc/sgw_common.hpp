@@ -68,7 +68,17 @@ struct KArgs {
 
 // leading scalar kernel arguments of k_engine (preloaded into SGPRs at wave launch): what the prologue's loads need
 #define SGW_HOT_ARGS(a) (a).state, (a).tables, (a).actions, (a).n_pad, (a).n_envs, (a).sp.words
-#define SGW_ACC_PARTS 4          // accumulator rows per env-wave: one per 16 envs (sgw_kernels.hpp accumulate_returns)
+#define SGW_ACC_PARTS 4          // (SGW_ACC_PER_ENV 0) accumulator rows per env-wave: one per 16 envs (sgw_kernels.hpp accumulate_returns)
+// Episodic-return accumulators: 0 = the wave transposes the finished lanes' vectors through LDS and adds 16-env column sums to one
+// row per 16 envs (~90 instructions and three LDS round trips per wave and step: 0.75 of a 6.5 us launch at 65 536 envs, 11 of
+// 58.6 us at 1 M); 1 = experiment of round 3: one cell per (column, env), [A*K+1][n_pad], added to by the lane whose episode just
+// ended (predicated no-return f64 atomics, no LDS, no cross-lane sum).  Measured on one box: island_navigation_ex 7.71 instead of
+// 6.67 us per launch at 65 536 envs, 78 instead of 59 us at 1 M (a random agent ends 13 % of its episodes every step: eleven
+// scattered atomics per wave and step cost more than the transpose); boat_race_ex, whose episodes are long, 7.50 instead of 7.90.
+// Not the default.
+#ifndef SGW_ACC_PER_ENV
+#define SGW_ACC_PER_ENV 0
+#endif
 #define SGW_KARGS_OFFSET 48      // byte offset of the KArgs block in k_engine's kernarg segment: 5 x 8 + 4 (+4 padding)
 
 // In-kernel phase stamps: compiled in ONLY by the diagnostic probe (-DSGW_STAMPS); libsgw.so carries none.
@@ -186,7 +196,7 @@ __host__ __device__ inline size_t lds_rows(int A, int K, int M, int need, int wh
     case LN_REWARD: return (need & LN_REWARD) ? ak : 0;
     case LN_CUMULATIVE: return (need & LN_CUMULATIVE) ? ak : 0;
     case LN_METRICS: return (need & LN_METRICS) ? (M > 6 ? M : 6) : 0;      // firemaker parks six mask words here
-    default: return (need & LN_RETURNS) ? A * K + 1 : 0;
+    default: return ((need & LN_RETURNS) && !SGW_ACC_PER_ENV) ? A * K + 1 : 0;
   }
 }
 // bytes of the per-env scalar outputs of one wave: `pa` = 1, or A for the families whose term_reason / safety are per agent
@@ -210,7 +220,7 @@ __host__ __device__ inline size_t lds_wave_bytes(int HW, int A, int K, int M, in
                       lds_rows(A, K, M, need, LN_METRICS) + lds_rows(A, K, M, need, LN_RETURNS) + 1;   // + trash
   size_t small = 16 + (size_t)(64 * A + 15) / 16 * 16;                  // flag words + the synthetic-action inbox (pipelined rollout)
   for (int w = LN_ST; w <= LN_FRM; w <<= 1) small += lds_small_bytes(A, pa, need, w);
-  const bool cs_aliased = (need & (LN_REWARD | LN_CUMULATIVE | LN_RETURNS)) != 0;
+  const bool cs_aliased = (need & (LN_REWARD | LN_CUMULATIVE | (SGW_ACC_PER_ENV ? 0 : LN_RETURNS))) != 0;
   return lds_board_bytes(HW) + rows * 64 * 8 + small + lds_view_bytes(vb, need) + (cs_aliased ? 0 : (size_t)cs * 512);
 }
 __host__ __device__ inline size_t lds_total_bytes(int HW, int A, int K, int M, int pa, int need, int vb, int extra, int env_waves, int buffers, int cs = 0) {
@@ -243,7 +253,7 @@ __host__ __device__ inline LdsPlan lds_plan(int HW, int A, int K, int M, int pa,
   // resident workgroups per CU to three, and a quarter of a 65 536-env launch then waits for a second turn (81 instead of 47 us)
   if (cs > 0 && (need & LN_REWARD)) p.cstash = p.vec_r;
   else if (cs > 0 && (need & LN_CUMULATIVE)) p.cstash = p.vec_c;
-  else if (cs > 0 && (need & LN_RETURNS)) p.cstash = p.vec_a;
+  else if (cs > 0 && (need & LN_RETURNS) && !SGW_ACC_PER_ENV) p.cstash = p.vec_a;
   else { p.cstash = o; o += cs * 512; }
   p.wave_bytes = o;
   return p;

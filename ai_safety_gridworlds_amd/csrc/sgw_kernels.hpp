@@ -529,6 +529,20 @@ __device__ inline void atomic_add_f64_noret(double* p, double v) {
   *p += v;
 #endif
 }
+// SGW_ACC_PER_ENV: the lanes whose episode just ended add their return vector (and a 1 for the episode count) to their own
+// cells of the [A*K+1][n_pad] accumulators: predicated no-return atomics, one writer per cell (deterministic), nothing to wait for
+template <class F>
+__device__ inline void accumulate_returns_per_env(const typename F::State& s, const KArgs& a, long long env, bool mine) {
+  if (!mine) return;
+  const int C = a.sp.A * a.sp.K + 1;
+#pragma unroll
+  for (int u = 0; u < F::NU; ++u) {
+    const int q = F::slot(a.sp, u);
+    if (q >= 0) atomic_add_f64_noret(&a.ep_acc[(long long)q * a.n_pad + env], s.cum[u]);
+  }
+  atomic_add_f64_noret(&a.ep_acc[(long long)(C - 1) * a.n_pad + env], 1.0);
+}
+
 // Episodic-return accumulators (end-of-batch all-reduce buffer).  Lanes whose episode just ended have staged their return
 // vector in l.vec_a (zeros otherwise).  lane = part * 16 + column: each lane sums one column over its part's 16 rows (reads
 // batched, a fixed add tree) and adds the sum to the part's own accumulator row -- four rows per env-wave, no exchange between
@@ -678,7 +692,7 @@ __device__ __forceinline__ void engine_body(const KArgs& a, const long long bloc
         const Lds lb = lds_carve(smem, a_step.lp, F::LDS_EXTRA, wv * NB + (NB > 1 ? (t & 1) : 0));
         if (a_step.write_every != 0 || t == TT - 1)
           emit_drain<F>(a_step, lb, env0, lane, a_step.write_every != 0 ? (long long)t * a_step.n_pad : 0, true, true);
-        if ((a_step.need & LN_RETURNS) && lb.flag[0] != 0u) accumulate_returns(a_step, lb, wave_id, env0, lane);
+        if (!SGW_ACC_PER_ENV && (a_step.need & LN_RETURNS) && lb.flag[0] != 0u) accumulate_returns(a_step, lb, wave_id, env0, lane);
         if (a_step.actions == nullptr && t + 2 < TT) {      // the computing wave read this inbox before the barrier above
 #pragma unroll
           for (int ag = 0; ag < F::NA; ++ag)
@@ -827,7 +841,9 @@ __device__ __forceinline__ void engine_body(const KArgs& a, const long long bloc
     bool acc_any = false;
     if (leader) {
       if constexpr (!PIPE) lds_wave_sync();                 // the previous step's cooperative reads are done (program order)
-      if (ae.need & LN_RETURNS) {
+      if (SGW_ACC_PER_ENV && (ae.need & LN_RETURNS)) {
+        if (__ballot(over_now && real) != 0ull) accumulate_returns_per_env<F>(s, ae, env, over_now && real);
+      } else if (ae.need & LN_RETURNS) {
         acc_any = __ballot(over_now && real) != 0ull;       // wave-uniform
         if (acc_any) {
           const StageRow row_a(le.vec_a, le.trash, lane, C);
@@ -920,6 +936,18 @@ __global__ __launch_bounds__(256) void k_read_returns(double* acc, long long n_w
   __shared__ double part[256];
   const int c = blockIdx.x;
   double v = 0.0;
+#if SGW_ACC_PER_ENV                                           // [C][rows]: a column is contiguous
+  for (long long w = threadIdx.x; w < n_waves; w += 256) v += acc[(long long)c * n_waves + w];
+  part[threadIdx.x] = v;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = part[0];
+  if (clear) for (long long w = threadIdx.x; w < n_waves; w += 256) acc[(long long)c * n_waves + w] = 0.0;
+  return;
+#endif
   for (long long w = threadIdx.x; w < n_waves; w += 256) v += acc[w * C + c];
   part[threadIdx.x] = v;
   __syncthreads();
