@@ -457,12 +457,12 @@ class GridworldVectorEnv(object):
   def _step_full(self, actions):
     """A step from Python is host-bound: the outputs live in persistent buffers, so the info dict of views is built once
     and a step is one library call plus one comparison."""
-    o = self._env.engine.step_full(actions, rgb=True, layers=True, stats=not self.spec_.scalar, performance=True)
+    o = self._env.engine.step_full(actions, rgb=True, layers=hasattr(self.spec_, "drape_chars"), stats=not self.spec_.scalar, performance=True)
     self._env._last = o
     if self._info is None or self._info["_for"] is not o["step_type"]:
       st = o["step_type"].reshape(self.num_envs, -1)[:, 0]
       info = {"step_type": st, "term_reason": o["term_reason"], "board": o["board"], "cumulative": o["cumulative"], "hidden": o["hidden"],
-              "cumulative_reward": o["cumulative"], "RGB": o["RGB"], "layers": o["layers"], "layers_order": self.layers_order,
+              "cumulative_reward": o["cumulative"], "RGB": o["RGB"], "layers": o.get("layers"), "layers_order": self.layers_order,
               "metrics": o["metrics"][:, :self.spec_.M], "safety": o["safety"], "frame": o["frame"], "discount": o["discount"],
               "actual_action": o["actual_action"], "last_performance": o["last_performance"], "performance_sum": o["performance_sum"],
               "episodes": o["episodes"]}

@@ -13,7 +13,7 @@ included), writing board + reward vector + step_type + term_reason + safety + fr
 action batches are resident in HBM before the timed region starts; the K launches of a batch are
 issued back to back by sgw_step_n (host loop in C).  A K-step batch at this size lasts K x ~9 us, so
 the timed region REPEATS the K-step batch R times (R chosen after warmup so that the region lasts
->= --min-seconds, default 0.5 s; "repeats" / "timed_steps" in the JSON line; --min-seconds 0 times
+>= --min-seconds, default 2 s; "repeats" / "timed_steps" in the JSON line; --min-seconds 0 times
 exactly K steps): with the driver's `--steps 20` alone the region would be 0.2 ms of event / sync
 overhead and clock ramp.  value = envs x K x R x N_gpus / max-over-ranks time.
 Envs are sharded by contiguous global-id ranges; the only collective is one all-reduce (RCCL)
@@ -43,13 +43,15 @@ from ai_safety_gridworlds_amd.specs import make_spec            # noqa: E402
 
 SEED = 0x5AFE
 METRIC = json.load(open(os.path.join(REPO, "BASELINE.json")))["metric"]      # BASELINE.json's metric string, verbatim
-TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")                     # newest first
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")  # newest first
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_MEASURED_COPY_GBS = 6290.0   # MI355X_MICROARCH.md: the guide's measured device-to-device copy rate (reported beside the spec peak)
 # MI355X_MICROARCH.md "SIMD": a wave64 VALU instruction occupies its SIMD for 2 cycles (32 lanes/cycle); 256 CUs x 4 SIMDs at
 # the 2.4 GHz maximum clock -> 1 228.8 G wave-instructions/s (f64 add/mul cost more than one slot: the real ceiling is lower)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 # families whose round kernel is bound by instruction issue, not by HBM: SQ_INSTS_VALU per launch comes from this round's PMC pass
-VALU_BOUND = {"firemaker_ex_ma": "r02_pmc_firemaker_ex_ma.json", "aintelope_savanna": "r02_pmc_aintelope_savanna.json"}
+VALU_BOUND = {"firemaker_ex_ma": ("r03_pmc_firemaker_ex_ma.json", "r02_pmc_firemaker_ex_ma.json"),
+              "aintelope_savanna": ("r03_pmc_aintelope_savanna.json", "r02_pmc_aintelope_savanna.json")}     # newest first
 # algorithmic bytes per env-step, island_navigation_ex L9 (step-per-launch mode):
 # action 1 + state 80 read + 80 write + board 48 + reward 80 + done 1 + term 1 + safety/hidden 8
 # (per-workload figures live in WORKLOADS below; fused rollout: the two state terms drop out)
@@ -216,7 +218,7 @@ def main():
   ap.add_argument("--warmup", type=int, default=200)
   ap.add_argument("--workload", default="island_navigation_ex", choices=sorted(WORKLOADS) + ["mixed"])
   ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's BASELINE size)")
-  ap.add_argument("--min-seconds", type=float, default=0.5,
+  ap.add_argument("--min-seconds", type=float, default=2.0,
                   help="the timed region repeats the K-step batch until it lasts at least this long (0: exactly K steps)")
   ap.add_argument("--cpu-seconds", type=float, default=12.0)
   ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -433,7 +435,8 @@ def main():
     acts = e["acts"]
     nf = int(min(acts.shape[0], 400))
     buf = torch.empty_like(acts[0])
-    kw = dict(rgb=True, layers=True, stats=not e["spec"].scalar, performance=True)
+    # (the original scalar envs observe OCCLUDED layers, safety_game.py: no unoccluded layer tables in their specs)
+    kw = dict(rgb=True, layers=hasattr(e["spec"], "drape_chars"), stats=not e["spec"].scalar, performance=True)
     for t in range(min(nf, 30)):
       buf.copy_(acts[t]); engf.step_full(buf, **kw)
     torch.cuda.synchronize(device)
@@ -449,7 +452,7 @@ def main():
     HWc, Lc = sp.H * sp.W, len(sp.layer_chars)
     full_obs = {"value": e["n"] / fdt, "unit": "env-steps/s", "us_per_step": ev0.elapsed_time(ev1) * 1e3 / nf, "us_per_step_wall": fdt * 1e6,
                 "host_us_per_call": fhost / nf * 1e6, "steps": nf,
-                "outputs_bytes_per_env_step": int(HWc * (1 + 4 + 3 + Lc) + sp.K * 8 * 3 + (5 + sp.K) * 8 + max(sp.M, 0) * 8 + 40),
+                "outputs_bytes_per_env_step": int(HWc * (1 + 4 + 3 + (Lc if kw["layers"] else 0)) + sp.K * 8 * 3 + (5 + sp.K) * 8 + max(sp.M, 0) * 8 + 40),
                 "note": "sgw_step_full: step kernel (board, float board, reward, cumulative, metrics, ...) + RGB + unoccluded layers + "
                         "gini / variances / average reward + per-env performance bookkeeping, one library call per step"}
     engf.close()
@@ -504,7 +507,12 @@ def main():
                      "avg_launch_us": kernel_ms * 1e3,
                      "algorithmic_bytes_per_env_step": alg_bytes / n_rank if grouped else e0["wl"]["b_step"],
                      "env_steps_per_launch": n_rank if grouped else e0["n"],
-                     "whole_step_algorithmic_gbs": alg_bytes / (elapsed / KR) / 1e9},
+                     "whole_step_algorithmic_gbs": alg_bytes / (elapsed / KR) / 1e9,
+                     "frac_of_measured_copy_rate": achieved / HBM_MEASURED_COPY_GBS, "measured_copy_rate_gbs": HBM_MEASURED_COPY_GBS,
+                     "note": ("at this size the launch's working set (%.1f MB of state + outputs) is L2 / Infinity-Cache resident and the "
+                              "launch is one wave per SIMD: the kernel is bound by a single wave's latency chain, the HBM label is nominal "
+                              "(DESIGN.md §4); the HBM-resident point is --envs 1048576" % (alg_bytes / 1e6))
+                             if n_rank <= 131072 else "working set beyond the caches: HBM-resident"},
         "returns": {fam: {"episodes_finished": float(acc[-1]),
                           "mean_episode_return": (acc[:-1] / max(acc[-1], 1.0)).tolist()}
                     for fam, (spec, acc) in returns.items()},
@@ -515,14 +523,15 @@ def main():
       rl.update({"hbm_achieved_gbs": rl["achieved"], "hbm_frac": rl["frac"], "bound": "valu", "unit": "G wave-instr/s",
                  "peak": VALU_PEAK_GINST, "achieved": None, "frac": None,
                  "peak_source": "MI355X_MICROARCH.md: 2 cycles per wave64 VALU instruction per SIMD, 1024 SIMDs, 2.4 GHz"})
-      ppath = os.path.join(REPO, "profiles", VALU_BOUND[a.workload])
+      ppath = next((os.path.join(REPO, "profiles", f) for f in VALU_BOUND[a.workload] if os.path.exists(os.path.join(REPO, "profiles", f))),
+                   os.path.join(REPO, "profiles", VALU_BOUND[a.workload][0]))
       if os.path.exists(ppath):
         valu = json.load(open(ppath)).get("pmc_median_per_launch", {}).get("SQ_INSTS_VALU")
         if valu:
           rl["achieved"] = valu / (kernel_ms * 1e-3) / 1e9
           rl["frac"] = rl["achieved"] / VALU_PEAK_GINST
           rl["valu_insts_per_launch"] = valu
-          rl["valu_source"] = "profiles/%s (separate rocprofv3 --pmc pass of this command; a constant in this run)" % VALU_BOUND[a.workload]
+          rl["valu_source"] = "profiles/%s (separate rocprofv3 --pmc pass of this command; a constant in this run)" % os.path.basename(ppath)
     if full_obs is not None:
       line["full_observation"] = full_obs
     if with_views is not None:

@@ -66,3 +66,56 @@ def test_single_process_helpers_are_noops():
   t = torch.ones(3, dtype=torch.float64)
   assert parallel.allreduce_returns(t, None) is t
   assert parallel.max_over_ranks(1.5, torch.device("cpu"), None) == 1.5
+
+
+def _world8_worker(rank, world, port, out):
+  """One rank of the 8-way rehearsal: bench.mixed_parts for this rank, a stand-in accumulator per family whose value is the
+  sum of the global env ids the rank owns (so the all-reduced total identifies any hole or overlap), parallel.allreduce_returns."""
+  import os
+  import torch
+  os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  import bench as B
+  from ai_safety_gridworlds_amd import parallel
+  dist = parallel.init("gloo")
+  per_gpu = 32768
+  parts = B.mixed_parts(rank, world, per_gpu)
+  res = {}
+  for fam in B.MIXED:
+    acc = torch.zeros(3, dtype=torch.float64)
+    for f, cnt, base in parts:
+      if f == fam:
+        ids = torch.arange(base, base + cnt, dtype=torch.float64)
+        acc += torch.stack([ids.sum(), (ids * ids).sum(), torch.tensor(float(cnt), dtype=torch.float64)])
+    parallel.allreduce_returns(acc, dist)
+    res[fam] = acc.tolist()
+  t = parallel.max_over_ranks(float(rank), torch.device("cpu"), dist)
+  if rank == 0:
+    out.put((res, t, [(f, c, b) for f, c, b in parts]))
+  dist.destroy_process_group()
+
+
+def test_eight_ranks_cover_the_mixed_suite_once_and_allreduce():
+  """CPU tier, world size 8 (gloo): the 262 144-env mixed suite of BASELINE config 5 is cut into per-rank parts by
+  bench.mixed_parts; the all-reduced per-family (sum of ids, sum of squares, count) equals what the three contiguous global id
+  ranges give -- every env id owned exactly once -- and max_over_ranks sees the last rank."""
+  import multiprocessing as mp
+  import socket
+  ctx = mp.get_context("spawn")
+  with socket.socket() as s_:
+    s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+  out = ctx.Queue()
+  procs = [ctx.Process(target=_world8_worker, args=(r, 8, port, out)) for r in range(8)]
+  for p in procs: p.start()
+  res, t, parts0 = out.get(timeout=240)
+  for p in procs:
+    p.join(timeout=120)
+    assert p.exitcode == 0
+  import bench as B
+  from ai_safety_gridworlds_amd import parallel
+  total = 8 * 32768
+  assert t == 7.0
+  for i, fam in enumerate(B.MIXED):
+    lo, hi = parallel.shard_range(total, i, 3)
+    ids = np.arange(lo, hi, dtype=np.float64)
+    assert res[fam] == [ids.sum(), (ids * ids).sum(), float(hi - lo)], fam
+  assert parts0[0][0] == "island_navigation_ex" and parts0[0][2] == 0 and sum(c for _, c, _ in parts0) == 32768

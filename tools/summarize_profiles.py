@@ -56,6 +56,13 @@ for wl, kname in (("firemaker_ex_ma", "Firemaker"), ("aintelope_savanna", "Savan
     body = {"kernel": "sgw::k_engine<sgw::%s, K_STEP> (bench.py --workload %s)" % (kname, wl), "tag": tag, "pmc_median_per_launch": fm}
     json.dump(body, open(os.path.join("profiles", "%s_%s_pmc_%s.json" % (rnd, tag, wl)), "w"), indent=1)
     json.dump(body, open(os.path.join("profiles", "%s_pmc_%s.json" % (rnd, wl)), "w"), indent=1)     # the copy bench.py reads
+for extra in ("side", "firemaker", "mixed"):            # round 3: rocprofv3 kernel stats of the side kernels / firemaker with windows / the group launch
+  st = sorted(glob.glob(os.path.join(src, "stats_" + extra, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+  if st:
+    shutil.copy(st[-1], os.path.join("profiles", "%s_%s_kernel_stats_%s.csv" % (rnd, tag, extra)))
+for f in ("side_probe.json", "side_probe.txt", "vec_probe.txt", "zoo_vector_probe.txt"):
+  if os.path.exists(os.path.join(src, f)):
+    shutil.copy(os.path.join(src, f), os.path.join("profiles", "%s_%s_%s" % (rnd, tag, f)))
 if "hbm_bytes_per_launch" in out:      # the bench ran before this tag's PMC passes were summarised: carry their traffic figure
   line = json.loads(open(bench_dst).read().strip().splitlines()[-1])
   line["roofline"]["traffic"] = out["hbm_bytes_per_launch"]
