@@ -462,8 +462,8 @@ def main():
     alg_bytes = sum(e["n"] * e["wl"]["b_step"] for e in engines)      # algorithmic bytes of one bench step on this rank
     e0 = engines[0]
     achieved = e0["n"] * e0["wl"]["b_step"] / (kernel_ms * 1e-3) / 1e9
-    if grouped:                                      # one launch = every member's envs: the launch's algorithmic bytes
-      achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    if a.workload == "mixed":                        # the suite's step = every family's envs: the whole step's algorithmic bytes over
+      achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9   # the step time on the launch stream (one group launch, or three concurrent ones)
     # HBM bytes per launch from the PMC counters: collected by separate `rocprofv3 --pmc` passes of this same command
     # (tools/collect_profiles.sh, MI355X_MICROARCH.md's recipe), NOT measured inside this run -- the file says which run
     traffic, traffic_source = None, None
@@ -503,10 +503,12 @@ def main():
                                    "%d distinct action batches resident in HBM" % (R, K, a.min_seconds, W, n_distinct)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "sgw::k_engine_group<K_STEP>" if grouped else "sgw::k_engine<%s, K_STEP>" % e0["fam"],
+                     "kernel": ("sgw::k_engine_group<K_STEP>" if grouped else
+                                "sgw::k_engine<island_navigation_ex | boat_race_ex | safe_interruptibility, K_STEP> on three streams"
+                                if a.workload == "mixed" else "sgw::k_engine<%s, K_STEP>" % e0["fam"]),
                      "avg_launch_us": kernel_ms * 1e3,
-                     "algorithmic_bytes_per_env_step": alg_bytes / n_rank if grouped else e0["wl"]["b_step"],
-                     "env_steps_per_launch": n_rank if grouped else e0["n"],
+                     "algorithmic_bytes_per_env_step": alg_bytes / n_rank if a.workload == "mixed" else e0["wl"]["b_step"],
+                     "env_steps_per_launch": n_rank if a.workload == "mixed" else e0["n"],
                      "whole_step_algorithmic_gbs": alg_bytes / (elapsed / KR) / 1e9,
                      "frac_of_measured_copy_rate": achieved / HBM_MEASURED_COPY_GBS, "measured_copy_rate_gbs": HBM_MEASURED_COPY_GBS,
                      "note": ("at this size the launch's working set (%.1f MB of state + outputs) is L2 / Infinity-Cache resident and the "
