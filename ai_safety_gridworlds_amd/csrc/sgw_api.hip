@@ -828,8 +828,9 @@ static bool plane_geom(int HW, int P, PlaneGeom& g) {
   g.HW = HW; g.P = P;
   uint32_t a = 0, b = 0;
   const uint64_t total = (uint64_t)PLANES_ENVS * P * HW;
-  const bool ok = recip((uint64_t)P * HW, total, a) && recip((uint64_t)HW, total, b);
-  g.recip_PHW = (int)a; g.recip_HW = (int)b;
+  uint32_t c = 0;
+  const bool ok = recip((uint64_t)P * HW, total, a) && recip((uint64_t)HW, total, b) && recip((uint64_t)(HW + 3) / 4, total, c);
+  g.recip_PHW = (int)a; g.recip_HW = (int)b; g.recip_Q = (int)c;
   return ok;
 }
 static int raise_lds_cap(sgw_engine* e, const void* fn, size_t lds, unsigned bit) {
@@ -851,11 +852,12 @@ int sgw_observe(sgw_engine* e, const uint8_t* board_dev, const uint8_t* rgb_lut_
   PlaneGeom g_rgb, g_lay;
   if (!plane_geom(e->ks.HW, 3, g_rgb) || !plane_geom(e->ks.HW, layers_dev ? n_layers : 1, g_lay))
     return fail(SGW_ERR_UNSUPPORTED, "sgw_observe: board / layer count outside the plane kernels' index arithmetic");
-  const size_t lds = (((size_t)PLANES_ENVS * e->ks.HW + 15) & ~(size_t)15) + 3 * 128;
+  const int epb = PLANES_ENVS;
+  const size_t lds = (((size_t)epb * e->ks.HW + 15) & ~(size_t)15) + 3 * 128;
   int rc = raise_lds_cap(e, reinterpret_cast<const void*>(&k_observe), lds, 16u);
   if (rc) return rc;
-  const unsigned blocks = (unsigned)((e->n_envs + PLANES_ENVS - 1) / PLANES_ENVS);
-  hipLaunchKernelGGL(k_observe, dim3(blocks), dim3(PLANES_THREADS), lds, (hipStream_t)stream, board_dev, (long long)e->n_envs, g_rgb,
+  const unsigned blocks = (unsigned)((e->n_envs + epb - 1) / epb);
+  hipLaunchKernelGGL(k_observe, dim3(blocks), dim3(PLANES_THREADS), lds, (hipStream_t)stream, board_dev, (long long)e->n_envs, epb, g_rgb,
                      rgb_lut_dev, rgb_dev, g_lay, layer_chars_dev, layers_dev);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
@@ -898,11 +900,14 @@ int sgw_observe_layers(sgw_engine* e, const uint8_t* board_dev, const uint8_t* l
   if (!plane_geom(e->ks.HW, n_layers, g))
     return fail(SGW_ERR_UNSUPPORTED, "sgw_observe_layers: board / layer count outside the plane kernels' index arithmetic");
   const size_t HW = (size_t)e->ks.HW;
-  const size_t lds = ((PLANES_ENVS * HW + 15) & ~(size_t)15) + PLANES_ENVS * HW * 4 + HW * 8 + 512;   // boards | masks | dyn, on | per-char
+  // 64 envs per workgroup, 16 when their boards + masks would take more than a quarter of the CU's LDS (firemaker's 17 x 17: 95 KB
+  // for 64 envs = one workgroup per CU and a serial chain of barriers; 24 KB for 16)
+  const int epb = (5 * PLANES_ENVS * HW > 40 * 1024) ? 16 : PLANES_ENVS;
+  const size_t lds = ((epb * HW + 15) & ~(size_t)15) + epb * HW * 4 + HW * 8 + 512;   // boards | masks | dyn, on | per-char
   int rc = raise_lds_cap(e, reinterpret_cast<const void*>(&k_observe_layers), lds, 32u);
   if (rc) return rc;
-  const unsigned blocks = (unsigned)((e->n_envs + PLANES_ENVS - 1) / PLANES_ENVS);
-  hipLaunchKernelGGL(k_observe_layers, dim3(blocks), dim3(PLANES_THREADS), lds, (hipStream_t)stream, board_dev, (long long)e->n_envs, g,
+  const unsigned blocks = (unsigned)((e->n_envs + epb - 1) / epb);
+  hipLaunchKernelGGL(k_observe_layers, dim3(blocks), dim3(PLANES_THREADS), lds, (hipStream_t)stream, board_dev, (long long)e->n_envs, epb, g,
                      e->ks.W, layer_chars_dev, layer_static_dev, gap_index, agent_pos_dev, agent_flags_dev, e->spec.A,
                      agent_pos_dev ? hidden_layer : -1, layers_dev);
   HIP_TRY(hipGetLastError());
@@ -1022,28 +1027,52 @@ int sgw_track_performance(sgw_engine* e, const double* perf_dev, int n_cols, con
   return SGW_OK;
 }
 
+// RGB + unoccluded layers + performance bookkeeping of the step that just ran, in ONE launch (k_step_extras)
+static int step_extras_launch(sgw_engine* e, const sgw_out* out, const sgw_extras* x, bool layers_here, void* stream) {
+  const bool perf = x->perf_last || x->perf_sum || x->perf_count || x->done;
+  if (!x->rgb && !layers_here && !perf) return SGW_OK;
+  if (layers_here && x->n_layers > 32) return fail(SGW_ERR_UNSUPPORTED, "sgw_step_full: at most 32 layers (a cell's layers are one 32-bit mask)");
+  ExtrasArgs ea; memset(&ea, 0, sizeof(ea));
+  const size_t HW = (size_t)e->ks.HW;
+  const int A = e->spec.A, K = e->spec.K;
+  const bool planes = x->rgb || layers_here;
+  const int epb = (planes && 5 * PLANES_ENVS * HW > 40 * 1024) ? 16 : PLANES_ENVS;
+  ea.board = out->board; ea.n = e->n_envs; ea.epb = epb; ea.HW = (int)HW; ea.W = e->ks.W; ea.A = A; ea.K = K;
+  if (!plane_geom((int)HW, 3, ea.g_rgb) || !plane_geom((int)HW, layers_here ? x->n_layers : 1, ea.g_lay))
+    return fail(SGW_ERR_UNSUPPORTED, "sgw_step_full: board / layer count outside the plane kernels' index arithmetic");
+  ea.rgb_lut = x->rgb_lut_dev; ea.rgb = x->rgb;
+  if (layers_here) {
+    ea.chars = x->layer_chars_dev; ea.stat = x->layer_static_dev; ea.gap = x->gap_index; ea.hidden = x->hidden_layer >= 0 ? x->hidden_layer : -1;
+    ea.pos = x->hidden_layer >= 0 ? out->agent_pos : nullptr; ea.flags = x->hidden_layer >= 0 ? out->agent_flags : nullptr; ea.layers = x->layers;
+  }
+  if (perf) {
+    ea.perf = x->perf_from_hidden ? out->hidden : out->cumulative; ea.perf_cols = x->perf_from_hidden ? 1 : A * K;
+    ea.per_agent = (e->spec.family == SGW_ISLAND_NAVIGATION_EX_MA || e->spec.family == SGW_AINTELOPE_SAVANNA) ? 1 : 0;
+    ea.step_type = out->step_type; ea.last = x->perf_last; ea.sum = x->perf_sum; ea.count = reinterpret_cast<long long*>(x->perf_count); ea.done = x->done;
+  }
+  // LDS: boards | layer masks | per-cell + per-char tables | colour table
+  ea.lds_planes = planes ? (int)((((size_t)epb * HW + 15) & ~(size_t)15) + epb * HW * 4 + HW * 8 + 512 + 3 * 128) : 0;
+  const size_t lds = (size_t)ea.lds_planes;
+  int rc = raise_lds_cap(e, reinterpret_cast<const void*>(&k_step_extras), lds, 64u);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(e->device));
+  hipLaunchKernelGGL(k_step_extras, dim3((unsigned)((e->n_envs + epb - 1) / epb)), dim3(PLANES_THREADS), lds, (hipStream_t)stream, ea);
+  HIP_TRY(hipGetLastError());
+  return SGW_OK;
+}
+
 static int step_full_launches(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, const sgw_extras* x, void* stream) {
   int rc = sgw_step(e, actions_dev, out, stream);
   if (rc || !x) return rc;
-  if (x->rgb) { rc = sgw_observe(e, out->board, x->rgb_lut_dev, x->rgb, nullptr, 0, nullptr, stream); if (rc) return rc; }
-  if (x->layers) {
-    if (e->spec.family == SGW_AINTELOPE_SAVANNA) rc = sgw_state_layers(e, x->layer_chars_dev, x->n_layers, 1, x->layers, stream);
-    else rc = sgw_observe_layers(e, out->board, x->layer_chars_dev, x->layer_static_dev, x->n_layers, x->gap_index,
-                                 x->hidden_layer >= 0 ? out->agent_pos : nullptr, x->hidden_layer >= 0 ? out->agent_flags : nullptr,
-                                 x->hidden_layer, x->layers, stream);
-    if (rc) return rc;
-  }
+  const bool layers_here = x->layers && e->spec.family != SGW_AINTELOPE_SAVANNA;       // savanna's layers come from its state bitmaps
+  rc = step_extras_launch(e, out, x, layers_here, stream);
+  if (rc) return rc;
+  if (x->layers && !layers_here) { rc = sgw_state_layers(e, x->layer_chars_dev, x->n_layers, 1, x->layers, stream); if (rc) return rc; }
+  if (x->stats) { rc = sgw_derived_stats(e, out->reward, out->cumulative, out->frame, x->k_agent, x->stats, stream); if (rc) return rc; }
   if (x->agent_layer_views) {
     const bool rot = e->spec.family != SGW_FIREMAKER_EX_MA;      // the families with observation directions rotate by agent_flags (UP = none)
     rc = sgw_agent_layer_views(e, x->layers, out->agent_pos, rot ? out->agent_flags : nullptr, x->layer_chars_dev, x->n_layers,
                                (uint8_t)(e->ks.view_pad), x->agent_layer_views, stream);
-    if (rc) return rc;
-  }
-  if (x->stats) { rc = sgw_derived_stats(e, out->reward, out->cumulative, out->frame, x->k_agent, x->stats, stream); if (rc) return rc; }
-  if (x->perf_last || x->perf_sum || x->perf_count || x->done) {
-    const double* src = x->perf_from_hidden ? out->hidden : out->cumulative;
-    rc = sgw_track_performance(e, src, x->perf_from_hidden ? 1 : e->spec.A * e->spec.K, out->step_type, x->perf_last, x->perf_sum, x->perf_count,
-                               x->done, stream);
     if (rc) return rc;
   }
   return SGW_OK;

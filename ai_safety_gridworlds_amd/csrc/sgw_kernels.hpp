@@ -975,19 +975,7 @@ __global__ void k_accumulate_returns(const double* cumulative, const uint8_t* st
 // _episodic_performances bookkeeping per env (safety_game.py:194-263): at a LAST timestep the episode's performance becomes the
 // env's last performance and joins its running sum and count
 __global__ void k_track_performance(const double* perf, int C, const uint8_t* step_type, int A, int per_agent, long long n, double* last,
-                                    double* sum, long long* count, uint8_t* done_out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * C) return;
-  const long long e = i / C;
-  bool done = step_type[e * A] == ST_LAST;
-  if (per_agent) { done = true; for (int ag = 0; ag < A; ++ag) done = done && step_type[e * A + ag] >= ST_LAST; }
-  if (done_out && i == e * C) done_out[e] = done ? 1 : 0;
-  if (!done) return;
-  const double v = perf[i];
-  if (last) last[i] = v;
-  if (sum) sum[i] += v;
-  if (count && i == e * C) count[e] += 1;
-}
+                                    double* sum, long long* count, uint8_t* done_out);
 
 __global__ void k_pow(const double* x, double y, double* out, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1105,18 +1093,16 @@ template <int K> __device__ __noinline__ void derived_agent(const double* Rv, co
 // 16-byte loads and are transposed through LDS as [agent][dimension][lane] (a lane then reads its own vector conflict-free);
 // the wave's 64 x A x (5 + K) results are staged in LDS and leave as 16-byte stores.
 // LDS (dynamic): R [A][K][64] | C [A][K][64] | O [64 * A * (5 + K)] doubles.
-__global__ __launch_bounds__(WAVE) void k_derived_stats(const double* reward, const double* cumulative, const int* frame, long long n, int A, int K,
-                                                        AgentK ak, int recip_K, double* stats) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t ds_lds[];
-  const int lane = threadIdx.x;
-  const long long env0 = (long long)blockIdx.x * WAVE, env = env0 + lane;
+__device__ inline void derived_stats_wave(uint8_t* ds_lds, int lane, long long env0, int rows, const double* reward, const double* cumulative, const int* frame,
+                                          long long n, int A, int K, const AgentK& ak, int recip_K, double* stats) {
+  const long long env = env0 + lane;
   const int AK = A * K, S = 5 + K;
   double* R = reinterpret_cast<double*>(ds_lds);
   double* Cm = R + AK * WAVE;
   double* O = Cm + AK * WAVE;
   // ---- rows in: element e of the wave's block (row-major [64][A][K]) -> [agent * K + dim][lane]
   const long long rows_left = n - env0;
-  const int nrow = rows_left < WAVE ? (int)rows_left : WAVE;        // a ragged last wave reads only its own rows
+  const int nrow = rows_left < rows ? (int)rows_left : rows;        // a ragged last wave reads only its own rows (rows <= 64 per wave)
   const int nel = nrow * AK;
   const double* gr = reward + env0 * AK;
   const double* gc = cumulative + env0 * AK;
@@ -1135,7 +1121,7 @@ __global__ __launch_bounds__(WAVE) void k_derived_stats(const double* reward, co
       Cm[col * WAVE + row] = h ? c1 : c0;
     }
   }
-  const double denom = (double)((env < n ? frame[env] : 0) + 1);
+  const double denom = (double)(((env < n && lane < nrow) ? frame[env] : 0) + 1);
   lds_wave_sync();
   for (int ag = 0; ag < A; ++ag) {
     const double* Rv = R + ag * K * WAVE;
@@ -1162,6 +1148,11 @@ __global__ __launch_bounds__(WAVE) void k_derived_stats(const double* reward, co
     else g[e0] = O[e0];
   }
 }
+__global__ __launch_bounds__(WAVE) void k_derived_stats(const double* reward, const double* cumulative, const int* frame, long long n, int A, int K,
+                                                        AgentK ak, int recip_K, double* stats) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t ds_lds[];
+  derived_stats_wave(ds_lds, (int)threadIdx.x, (long long)blockIdx.x * WAVE, WAVE, reward, cumulative, frame, n, A, K, ak, recip_K, stats);
+}
 
 // ---- per-character planes of a rendered board: RGB, occluded layers, unoccluded layers ---------------------------------------
 // Every one of these outputs is [N][P planes][H*W] bytes with byte (e, p, c) a function of plane p and of what is at cell c of
@@ -1170,8 +1161,8 @@ __global__ __launch_bounds__(WAVE) void k_derived_stats(const double* reward, co
 // contiguous output bytes 16 at a time -- a lane walks (env, plane, cell) forward by one from the chunk's first byte, whose
 // coordinates come from two reciprocal multiplies, instead of dividing per byte.  (Round 2: one thread per cell, an integer
 // division each, P one-byte stores at a stride of HW.)
-constexpr int PLANES_THREADS = 256, PLANES_ENVS = 64;
-struct PlaneGeom { int HW, P, recip_PHW, recip_HW; };                // recip_x = ceil(2^32 / x) as uint32: (f * recip) >> 32 == f / x for f < 2^20
+constexpr int PLANES_THREADS = 256, PLANES_ENVS = 64;      // (PLANES_ENVS: the most envs a workgroup takes; 16 for boards whose staging would crowd the CU's LDS)
+struct PlaneGeom { int HW, P, recip_PHW, recip_HW, recip_Q; };       // recip_x = ceil(2^32 / x) as uint32: (f * recip) >> 32 == f / x for f < 2^20; Q = ceil(HW / 4)
 __device__ inline uint32_t div_recip(uint32_t f, uint32_t recip) { return recip ? (uint32_t)(((uint64_t)f * recip) >> 32) : f; }   // recip 0: x == 1
 // phase 2.  value(p, code) -> output byte
 template <class Value>
@@ -1191,17 +1182,36 @@ __device__ inline void planes_expand(uint8_t* out_block, const PlaneGeom& g, int
     else for (uint32_t b = 0; f0 + b < total; ++b) out_block[f0 + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
   }
 }
-// phase 2 when H*W is a multiple of 4: every output row (env, plane) starts on a dword, so a lane takes FOUR consecutive cells of
-// an env, fetches their codes once and writes one aligned dword per plane -- consecutive lanes write consecutive dwords of a
-// row.  dword(p, codes of the 4 cells) -> the 4 output bytes
+// phase 2, the fast form: a lane takes FOUR consecutive cells of an env, fetches their codes once and writes one dword per plane
+// -- consecutive lanes write consecutive dwords of a row.  When H*W is not a multiple of 4 the rows do not start on dwords: the
+// stores are then unaligned dword stores (global memory takes them; the bytes of a wave's instruction are contiguous all the
+// same) and the last, partial group of a row leaves as single bytes.  dword4(e, c, nvalid, put): put(p, the 4 output bytes)
+typedef uint32_t __attribute__((aligned(1))) sgw_u32_unaligned;
 template <class Dword4>
 __device__ inline void planes_expand4(uint8_t* out_block, const PlaneGeom& g, int n_env, Dword4 dword4) {
-  const int HW = g.HW, q = HW >> 2, items = n_env * q;
+  const int HW = g.HW, q = (HW + 3) >> 2, items = n_env * q;
   for (int i = threadIdx.x; i < items; i += PLANES_THREADS) {
-    const int e = (int)div_recip((uint32_t)(4 * i), (uint32_t)g.recip_HW), c = 4 * i - e * HW;
-    uint32_t* row = reinterpret_cast<uint32_t*>(out_block + (size_t)e * g.P * HW + c);
-    dword4(e, c, [&](int p, uint32_t v) { row[p * q] = v; });
+    const int e = (int)div_recip((uint32_t)i, (uint32_t)g.recip_Q), c = 4 * (i - e * q);
+    const int nvalid = HW - c < 4 ? HW - c : 4;
+    uint8_t* row = out_block + (size_t)e * g.P * HW + c;
+    dword4(e, c, nvalid, [&](int p, uint32_t v) {
+      uint8_t* d = row + (size_t)p * HW;
+      if (nvalid == 4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // ONE dword store at a byte address (the compiler splits a store it cannot prove aligned into four byte stores; the memory
+        // pipeline takes unaligned dwords: the tests compare every byte with the fixtures)
+        asm volatile("global_store_dword %0, %1, off" : : "v"(d), "v"(v) : "memory");
+#else
+        *reinterpret_cast<sgw_u32_unaligned*>(d) = v;
+#endif
+      } else for (int b = 0; b < nvalid; ++b) d[b] = (uint8_t)(v >> (8 * b));
+    });
   }
+}
+// four consecutive LDS bytes at any alignment (cells past the row's end read the row's last cell: their output is dropped)
+__device__ inline uint32_t lds_bytes4(const uint8_t* base, int at, int nvalid) {
+  const int i1 = nvalid > 1 ? 1 : 0, i2 = nvalid > 2 ? 2 : i1, i3 = nvalid > 3 ? 3 : i2;
+  return (uint32_t)base[at] | ((uint32_t)base[at + i1] << 8) | ((uint32_t)base[at + i2] << 16) | ((uint32_t)base[at + i3] << 24);
 }
 // the block's board rows -> LDS (16-byte loads; 64 * HW is a multiple of 16 and the block starts on one)
 __device__ inline void planes_load_boards(const uint8_t* board, long long env0, int n_env, int HW, uint8_t* lds_board) {
@@ -1211,46 +1221,44 @@ __device__ inline void planes_load_boards(const uint8_t* board, long long env0, 
   for (int j = (n16 << 4) + threadIdx.x; j < bytes; j += PLANES_THREADS) lds_board[j] = board[env0 * HW + j];     // ragged last block
 }
 
+// the RGB planes of a block's boards (in LDS) through the colour table tab[plane][char] (in LDS)
+__device__ inline void observe_rgb_expand(const uint8_t* bl, const uint8_t* tab, uint8_t* rgb_block, const PlaneGeom& g_rgb, int n_env) {
+  const int HW = g_rgb.HW;
+  planes_expand4(rgb_block, g_rgb, n_env, [&](int e, int c, int nvalid, auto put) {
+    const uint32_t b4 = (HW & 3) == 0 ? *reinterpret_cast<const uint32_t*>(bl + e * HW + c) : lds_bytes4(bl, e * HW + c, nvalid);
+    const uint32_t c0 = b4 & 0x7f, c1 = (b4 >> 8) & 0x7f, c2 = (b4 >> 16) & 0x7f, c3 = (b4 >> 24) & 0x7f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const uint8_t* t = tab + p * 128;
+      put(p, (uint32_t)t[c0] | ((uint32_t)t[c1] << 8) | ((uint32_t)t[c2] << 16) | ((uint32_t)t[c3] << 24));
+    }
+  });
+}
+
 // observation distiller extras from an ascii board (observation_distiller.py:30-91, rendering.py:69-185): RGB planes via the
 // colour LUT and OCCLUDED per-character layers (board == char).  LDS: boards [64 * HW] | table [P][128]
-__global__ __launch_bounds__(PLANES_THREADS) void k_observe(const uint8_t* board, long long n, PlaneGeom g_rgb, const uint8_t* rgb_lut, uint8_t* rgb,
+__global__ __launch_bounds__(PLANES_THREADS) void k_observe(const uint8_t* board, long long n, int epb, PlaneGeom g_rgb, const uint8_t* rgb_lut, uint8_t* rgb,
                                                             PlaneGeom g_lay, const uint8_t* layer_chars, uint8_t* layers) {
   extern __shared__ __attribute__((aligned(16))) uint8_t pl_lds[];
   const int HW = g_rgb.HW;
-  const long long env0 = (long long)blockIdx.x * PLANES_ENVS;
-  const int n_env = n - env0 < PLANES_ENVS ? (int)(n - env0) : PLANES_ENVS;
+  const long long env0 = (long long)blockIdx.x * epb;              // epb envs per workgroup: 64, or 16 for large boards (LDS per workgroup)
+  const int n_env = n - env0 < epb ? (int)(n - env0) : epb;
   uint8_t* bl = pl_lds;
-  uint8_t* tab = pl_lds + ((PLANES_ENVS * HW + 15) & ~15);
+  uint8_t* tab = pl_lds + ((epb * HW + 15) & ~15);
   planes_load_boards(board, env0, n_env, HW, bl);
   if (rgb) {
     for (int i = threadIdx.x; i < 3 * 128; i += PLANES_THREADS) tab[i] = rgb_lut[(i & 127) * 3 + (i >> 7)];        // [plane][char]
     __syncthreads();
-    if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(rgb) & 3) == 0) {
-      planes_expand4(rgb + env0 * 3 * HW, g_rgb, n_env, [&](int e, int c, auto put) {
-        const uint32_t b4 = *reinterpret_cast<const uint32_t*>(bl + e * HW + c);
-        const uint32_t c0 = b4 & 0x7f, c1 = (b4 >> 8) & 0x7f, c2 = (b4 >> 16) & 0x7f, c3 = (b4 >> 24) & 0x7f;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const uint8_t* t = tab + p * 128;
-          put(p, (uint32_t)t[c0] | ((uint32_t)t[c1] << 8) | ((uint32_t)t[c2] << 16) | ((uint32_t)t[c3] << 24));
-        }
-      });
-    } else {
-      planes_expand(rgb + env0 * 3 * HW, g_rgb, n_env, [&](int p, int e, int c) { return tab[p * 128 + (bl[e * HW + c] & 0x7f)]; });
-    }
+    observe_rgb_expand(bl, tab, rgb + env0 * 3 * HW, g_rgb, n_env);
   }
   if (layers) {
     __syncthreads();
     for (int i = threadIdx.x; i < g_lay.P; i += PLANES_THREADS) tab[i] = layer_chars[i];
     __syncthreads();
-    if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(layers) & 3) == 0) {
-      planes_expand4(layers + env0 * g_lay.P * HW, g_lay, n_env, [&](int e, int c, auto put) {
-        const uint32_t b4 = *reinterpret_cast<const uint32_t*>(bl + e * HW + c) & 0x7f7f7f7fu;
-        for (int p = 0; p < g_lay.P; ++p) put(p, bytes_equal_mask(b4, 0x01010101u * tab[p]) & 0x01010101u);
-      });
-    } else {
-      planes_expand(layers + env0 * g_lay.P * HW, g_lay, n_env, [&](int p, int e, int c) { return (uint8_t)((bl[e * HW + c] & 0x7f) == tab[p]); });
-    }
+    planes_expand4(layers + env0 * g_lay.P * HW, g_lay, n_env, [&](int e, int c, int nvalid, auto put) {
+      const uint32_t b4 = ((HW & 3) == 0 ? *reinterpret_cast<const uint32_t*>(bl + e * HW + c) : lds_bytes4(bl, e * HW + c, nvalid)) & 0x7f7f7f7fu;
+      for (int p = 0; p < g_lay.P; ++p) put(p, bytes_equal_mask(b4, 0x01010101u * tab[p]) & 0x01010101u);
+    });
   }
 }
 
@@ -1259,19 +1267,17 @@ __global__ __launch_bounds__(PLANES_THREADS) void k_observe(const uint8_t* board
 // character, a static curtain (stat 1) always, the hidden drape under an agent that covers it (firemaker's fire), and the
 // what_lies_beneath layer only where every other layer is blank.  LDS: boards [64 * HW] | masks u32 [64 * HW] | per-cell tables
 // dyn u32 [HW], on u32 [HW] | per-char table u32 [128]
-__global__ __launch_bounds__(PLANES_THREADS) void k_observe_layers(const uint8_t* board, long long n, PlaneGeom g, int W, const uint8_t* chars,
-                                                                   const uint8_t* stat, int gap, const uint8_t* pos, const uint8_t* flags, int A,
-                                                                   int hidden, uint8_t* layers) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t pl_lds[];
+__device__ inline void observe_layers_block(uint8_t* pl_lds, long long env0, int epb, bool boards_loaded, const uint8_t* board, long long n, PlaneGeom g, int W,
+                                            const uint8_t* chars, const uint8_t* stat, int gap, const uint8_t* pos, const uint8_t* flags, int A,
+                                            int hidden, uint8_t* layers) {
   const int HW = g.HW, L = g.P;
-  const long long env0 = (long long)blockIdx.x * PLANES_ENVS;
-  const int n_env = n - env0 < PLANES_ENVS ? (int)(n - env0) : PLANES_ENVS;
+  const int n_env = n - env0 < epb ? (int)(n - env0) : epb;
   uint8_t* bl = pl_lds;
-  uint32_t* mask = reinterpret_cast<uint32_t*>(pl_lds + ((PLANES_ENVS * HW + 15) & ~15));
-  uint32_t* dyn = mask + PLANES_ENVS * HW;
+  uint32_t* mask = reinterpret_cast<uint32_t*>(pl_lds + ((epb * HW + 15) & ~15));
+  uint32_t* dyn = mask + epb * HW;
   uint32_t* on = dyn + HW;
   uint32_t* chm = on + HW;
-  planes_load_boards(board, env0, n_env, HW, bl);
+  if (!boards_loaded) planes_load_boards(board, env0, n_env, HW, bl);
   for (int c = threadIdx.x; c < HW; c += PLANES_THREADS) {
     uint32_t d = 0u, o = 0u;
     for (int k = 0; k < L; ++k) { const uint8_t st = stat[k * HW + c]; d |= (st == 2 ? 1u : 0u) << k; o |= ((st != 0 && st != 2) ? 1u : 0u) << k; }
@@ -1306,14 +1312,73 @@ __global__ __launch_bounds__(PLANES_THREADS) void k_observe_layers(const uint8_t
     }
     __syncthreads();
   }
-  if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(layers) & 3) == 0) {
-    planes_expand4(layers + env0 * L * HW, g, n_env, [&](int e, int c, auto put) {
-      const uint4 m = *reinterpret_cast<const uint4*>(mask + e * HW + c);            // the four cells' layer masks: one 16-byte LDS read
-      for (int p = 0; p < L; ++p)
-        put(p, ((m.x >> p) & 1u) | (((m.y >> p) & 1u) << 8) | (((m.z >> p) & 1u) << 16) | (((m.w >> p) & 1u) << 24));
-    });
-  } else {
-    planes_expand(layers + env0 * L * HW, g, n_env, [&](int p, int e, int c) { return (uint8_t)((mask[e * HW + c] >> p) & 1u); });
+  planes_expand4(layers + env0 * L * HW, g, n_env, [&](int e, int c, int nvalid, auto put) {
+    uint4 m;                                                         // the four cells' layer masks
+    if ((HW & 3) == 0) m = *reinterpret_cast<const uint4*>(mask + e * HW + c);      // one 16-byte LDS read
+    else {
+      const uint32_t* mp = mask + e * HW + c;
+      m = make_uint4(mp[0], mp[nvalid > 1 ? 1 : 0], mp[nvalid > 2 ? 2 : 0], mp[nvalid > 3 ? 3 : 0]);
+    }
+    for (int p = 0; p < L; ++p)
+      put(p, ((m.x >> p) & 1u) | (((m.y >> p) & 1u) << 8) | (((m.z >> p) & 1u) << 16) | (((m.w >> p) & 1u) << 24));
+  });
+}
+__global__ __launch_bounds__(PLANES_THREADS) void k_observe_layers(const uint8_t* board, long long n, int epb, PlaneGeom g, int W, const uint8_t* chars,
+                                                                   const uint8_t* stat, int gap, const uint8_t* pos, const uint8_t* flags, int A,
+                                                                   int hidden, uint8_t* layers) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t pl_lds[];
+  observe_layers_block(pl_lds, (long long)blockIdx.x * epb, epb, false, board, n, g, W, chars, stat, gap, pos, flags, A, hidden, layers);
+}
+
+// ---- sgw_step_full's board-derived outputs in ONE launch: a workgroup takes `epb` envs of the step that just ran and produces, from
+// their boards (loaded into LDS once), the RGB planes and the unoccluded layers, then the performance bookkeeping and the `done`
+// flags of those envs: one kernel boundary and one graph node instead of three.
+struct ExtrasArgs {
+  const uint8_t* board; long long n; int epb, HW, W, A, K;
+  PlaneGeom g_rgb; const uint8_t* rgb_lut; uint8_t* rgb;
+  PlaneGeom g_lay; const uint8_t* chars; const uint8_t* stat; int gap, hidden; const uint8_t* pos; const uint8_t* flags; uint8_t* layers;
+  const double* reward; const double* cumulative; const int* frame; AgentK ak; int recip_K; double* stats;
+  const double* perf; int perf_cols, per_agent; const uint8_t* step_type; double* last; double* sum; long long* count; uint8_t* done;
+  int lds_planes;                                   // bytes of the planes region (the statistics' rows follow it)
+};
+__device__ inline void track_performance_item(long long i, const double* perf, int C, const uint8_t* step_type, int A, int per_agent, double* last,
+                                              double* sum, long long* count, uint8_t* done_out) {
+  const long long e = i / C;
+  bool done = step_type[e * A] == ST_LAST;
+  if (per_agent) { done = true; for (int ag = 0; ag < A; ++ag) done = done && step_type[e * A + ag] >= ST_LAST; }
+  if (done_out && i == e * C) done_out[e] = done ? 1 : 0;
+  if (!done) return;
+  const double v = perf[i];
+  if (last) last[i] = v;
+  if (sum) sum[i] += v;
+  if (count && i == e * C) count[e] += 1;
+}
+__global__ void k_track_performance(const double* perf, int C, const uint8_t* step_type, int A, int per_agent, long long n, double* last,
+                                    double* sum, long long* count, uint8_t* done_out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * C) track_performance_item(i, perf, C, step_type, A, per_agent, last, sum, count, done_out);
+}
+__global__ __launch_bounds__(PLANES_THREADS) void k_step_extras(const ExtrasArgs x) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t pl_lds[];
+  const long long env0 = (long long)blockIdx.x * x.epb;
+  const int n_env = x.n - env0 < x.epb ? (int)(x.n - env0) : x.epb;
+  const bool planes = x.rgb != nullptr || x.layers != nullptr;
+  if (planes) planes_load_boards(x.board, env0, n_env, x.HW, pl_lds);
+  if (x.rgb) {
+    uint8_t* tab = pl_lds + x.lds_planes - 3 * 128;               // the colour table sits at the end of the planes region
+    for (int i = threadIdx.x; i < 3 * 128; i += PLANES_THREADS) tab[i] = x.rgb_lut[(i & 127) * 3 + (i >> 7)];
+    __syncthreads();
+    observe_rgb_expand(pl_lds, tab, x.rgb + env0 * 3 * x.HW, x.g_rgb, n_env);
+  }
+  if (x.layers) {
+    __syncthreads();
+    observe_layers_block(pl_lds, env0, x.epb, true, x.board, x.n, x.g_lay, x.W, x.chars, x.stat, x.gap, x.pos, x.flags, x.A, x.hidden, x.layers);
+  }
+  // (the derived statistics stay a launch of their own: their unrolled K = 16 body needs ~290 registers, and compiled into this
+  // kernel that budget applied to every wave -- one workgroup per CU, 83 instead of 54 us per full step)
+  if (x.perf) {
+    for (long long i = env0 * x.perf_cols + (int)threadIdx.x; i < (env0 + n_env) * x.perf_cols; i += PLANES_THREADS)
+      track_performance_item(i, x.perf, x.perf_cols, x.step_type, x.A, x.per_agent, x.last, x.sum, x.count, x.done);
   }
 }
 
