@@ -919,12 +919,15 @@ int sgw_state_layers(sgw_engine* e, const uint8_t* layer_chars_dev, int n_layers
   if (!e || !layer_chars_dev || !layers_dev || n_layers < 1) return fail(SGW_ERR_ARG, "sgw_state_layers: bad argument");
   if (e->spec.family != SGW_AINTELOPE_SAVANNA)
     return fail(SGW_ERR_UNSUPPORTED, "sgw_state_layers: this family's layers follow from its board (sgw_observe_layers)");
+  if (n_layers > 32) return fail(SGW_ERR_UNSUPPORTED, "sgw_state_layers: at most 32 layers");
   HIP_TRY(hipSetDevice(e->device));
-  const long long total = e->n_envs * e->ks.HW;
-  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(k_savanna_layers, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e->state_dev, e->n_pad, e->n_envs,
-                     e->ks.words, e->ks.HW, e->ks.W, (e->spec.flags & Savanna::F_TWO) ? 1 : 0, layer_chars_dev, n_layers, gap_only_blank,
-                     layers_dev);
+  PlaneGeom g;
+  if (!plane_geom(e->ks.HW, n_layers, g)) return fail(SGW_ERR_UNSUPPORTED, "sgw_state_layers: board / layer count outside the plane kernels' index arithmetic");
+  const int epb = 16;                                             // 16 envs: 3.5 KB of state words + 10.6 KB of code vectors per workgroup
+  const size_t lds = (size_t)epb * SAV_LAYER_WORDS * 8 + (size_t)epb * e->ks.HW * 4 + 32 * 4;
+  hipLaunchKernelGGL(k_savanna_layers, dim3((unsigned)((e->n_envs + epb - 1) / epb)), dim3(PLANES_THREADS), lds, (hipStream_t)stream, e->state_dev,
+                     e->n_pad, (long long)e->n_envs, e->ks.words, g, e->ks.W, (e->spec.flags & Savanna::F_TWO) ? 1 : 0, layer_chars_dev, gap_only_blank,
+                     epb, layers_dev);
   HIP_TRY(hipGetLastError());
   return SGW_OK;
 }
