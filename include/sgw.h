@@ -196,8 +196,9 @@ int sgw_reset(sgw_engine* e, const uint8_t* mask_dev, const sgw_out* out, void* 
 
 /* One env.step() per env: actions_dev int8 [N, A].  Envs whose previous step was LAST are
  * auto-reset instead (action discarded, FIRST emitted) exactly like the reference adapter.
- * island_navigation_ex_ma / aintelope_savanna: an action < 0 = that agent is not in the submitted dict and does not play
- * this round (EnvironmentMa.step with a subset of the agents, pycolab_interface_ma.py:173-246; the AEC wrapper's way). */
+ * Multi-agent families (island_navigation_ex_ma, aintelope_savanna, firemaker_ex_ma): an action < 0 = that agent is not in the
+ * submitted dict and does not play this round (EnvironmentMa.step with a subset of the agents, pycolab_interface_ma.py:173-246:
+ * the AEC wrapper's way, and the Gym wrapper's with agent_character, gridworld_gym_env.py:476-479). */
 int sgw_step(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, void* stream);
 
 /* T consecutive sgw_step launches (one kernel launch per step, host loop in C): actions_dev int8

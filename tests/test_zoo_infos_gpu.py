@@ -188,3 +188,39 @@ def test_gym_facade_agent_observation_infos_at_reset(agent):
   assert {k: [list(x) for x in v] for k, v in info["info_agent_observation_coordinates"].items()} == agent_coords[0][agent]
   assert np.array_equal(info["info_observation_layers_cube"], fx["cube"][0].astype(bool))
   env.close()
+
+
+@pytest.mark.parametrize("name,kw,n", [
+    ("firemaker_ex_ma", dict(amount_agents=3, max_iterations=60), 300),
+    ("island_navigation_ex_ma", dict(level=9, observation_direction_mode=2, action_direction_mode=2), 200),
+    ("aintelope_savanna", dict(amount_agents=2, amount_predators=1, amount_water_tiles=2, observation_radius=[2, 2, 2, 2]), 150),
+])
+def test_step_full_of_the_multi_agent_families_equals_the_separate_kernels(name, kw, n):
+  """sgw_step_full over the multi-agent families -- unoccluded layers (firemaker: the fire hidden under an agent; savanna: from
+  the state bitmaps), the per-agent layer cubes and the derived statistics chained behind the step in one call, replayed as a
+  graph from the third step on -- against the same outputs produced by the separate entry points on a twin engine."""
+  import numpy as np
+  import torch
+  from ai_safety_gridworlds_amd.engine import BatchedEngine
+  from ai_safety_gridworlds_amd.specs import make_spec
+  spec = make_spec(name, **kw)
+  outs = ("board", "reward", "cumulative", "frame", "step_type", "agent_pos", "agent_flags")
+  a, b = BatchedEngine(spec, n, outputs=outs), BatchedEngine(spec, n, outputs=outs)
+  for e in (a, b):
+    e.set_rng_seeds(np.arange(n) + 3)
+    e.reset()
+  acts = a.fill_actions(40, 17)
+  buf = torch.empty_like(acts[0])
+  for t in range(40):
+    buf.copy_(acts[t])
+    o = a.step_full(buf, layers=True, stats=True, agent_layer_views=True)
+    b.step(acts[t])
+    for k in outs:
+      assert torch.equal(o[k], b._views()[k]), (t, k)
+    assert torch.equal(o["layers"], b.observe_layers()), t
+    for x, y in zip(o["agent_layer_views"], b.agent_layer_views()):
+      assert torch.equal(x, y), t
+    ds = b.derived_stats()
+    for k in ("gini_index", "cumulative_gini_index", "mo_variance", "cumulative_mo_variance", "average_mo_variance", "average_reward"):
+      assert torch.equal(torch.nan_to_num(o[k], nan=-7.0), torch.nan_to_num(ds[k], nan=-7.0)), (t, k)
+  a.close(); b.close()

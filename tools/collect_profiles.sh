@@ -25,7 +25,8 @@ done
 if [ -x $R/tools/diag/stamp_probe.bin ]; then $R/tools/diag/stamp_probe.bin 65536 > $OUT/phase_stamps.txt 2>&1; $R/tools/diag/stamp_probe.bin 1048576 >> $OUT/phase_stamps.txt 2>&1; fi
 # round 3: the side kernels of the step path (derived statistics, RGB / layers, agent windows) on their own, the firemaker round
 # kernel with the agents' windows written by the same launch, and the mixed suite as one heterogeneous launch per step
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_side -- python3 $R/tools/diag/side_probe.py $OUT/side_probe.json > $OUT/side_probe.txt 2>&1 || exit 1
+python3 $R/tools/diag/side_probe.py $OUT/side_probe.json > $OUT/side_probe.txt 2>&1 || exit 1       # HIP-event timings, unprofiled
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_side -- python3 $R/tools/diag/side_probe.py > $OUT/side_probe_rocprof.txt 2>&1 || exit 1   # kernel durations (the probe's own event timings are inflated under the profiler)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_firemaker -- python3 $R/bench.py --workload firemaker_ex_ma --steps 300 --warmup 30 --min-seconds 0.2 --no-cpu-baseline --no-fused > $OUT/stats_firemaker.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_mixed -- python3 $R/bench.py --workload mixed --steps 500 --warmup 50 --min-seconds 0.2 --no-cpu-baseline > $OUT/stats_mixed.log 2>&1 || exit 1
 python3 $R/tools/diag/vec_probe.py > $OUT/vec_probe.txt 2>&1
