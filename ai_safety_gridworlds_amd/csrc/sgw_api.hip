@@ -24,6 +24,7 @@
 #include "sgw_tomato.hpp"
 #include "sgw_whisky.hpp"
 #include "sgw_group.hpp"
+#include "sgw_savanna_layers.hpp"
 
 using namespace sgw;
 
