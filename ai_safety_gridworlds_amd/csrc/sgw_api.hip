@@ -1010,7 +1010,17 @@ int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_
     HIP_TRY(hipGetLastError());
     return SGW_OK;
   }
-  long long total = e->n_envs * (long long)v.A * n_layers * WAVE;        // one wave per (env, agent, layer) window
+  // a workgroup per env: the env's layer planes and its whole output row in LDS (k_agent_layer_views_lds)
+  const int lay_bytes = (n_layers * e->ks.HW + 15) / 16 * 16;
+  const size_t lds = (size_t)lay_bytes + ((size_t)v.total * n_layers + 15) / 16 * 16;
+  if (lds <= 64 * 1024) {
+    const int blocks = (int)(e->n_envs < 4096 ? e->n_envs : 4096);
+    hipLaunchKernelGGL(k_agent_layer_views_lds, dim3(blocks), dim3(256), lds, (hipStream_t)stream, layers_dev, agent_pos_dev, agent_flags_dev,
+                       (long long)e->n_envs, v, layer_chars_dev, n_layers, outside_chr, out_dev, lay_bytes);
+    HIP_TRY(hipGetLastError());
+    return SGW_OK;
+  }
+  long long total = e->n_envs * (long long)v.A * n_layers * WAVE;        // (rows too large for LDS) one wave per (env, agent, layer) window
   int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   const int lds_per_wave = view_stage_bytes(v);
   hipLaunchKernelGGL(k_agent_layer_views, dim3(blocks), dim3(256), 4 * lds_per_wave, (hipStream_t)stream, layers_dev, agent_pos_dev,

@@ -1521,6 +1521,98 @@ __global__ void k_agent_layer_views_small(const uint8_t* layers, const uint8_t* 
   }
 }
 
+// per-layer agent windows, windows larger than 64 cells (firemaker's 33 x 33, savanna's 21 x 21): a WORKGROUP per env.  The env's L
+// layer planes come into LDS once, each of the A x L windows is assembled in an LDS image of the env's whole output row by one wave
+// (a window larger than the plane: pad fill, then the plane's cells dropped where they land; else a gather), and the row leaves
+// as dword stores at its byte address (rows of L * view_bytes bytes are not aligned to anything).  Round 2's kernel below -- one
+// wave per window, every cell a byte load from global memory -- took 208 us for 16 384 firemaker envs (0.13 of HBM).
+__global__ __launch_bounds__(256) void k_agent_layer_views_lds(const uint8_t* layers, const uint8_t* pos, const uint8_t* flags, long long n, ViewSpec v,
+                                                               const uint8_t* chars, int L, uint8_t outside, uint8_t* out, int lay_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t view_lds[];
+  uint8_t* lay = view_lds;                                   // [L][H*W]
+  uint8_t* img = view_lds + lay_bytes;                       // the env's output row: [agent][layer][vh][vw]
+  const int HW = v.H * v.W, lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int row_bytes = v.total * L;
+  // lane constants, once per kernel (no division inside the env loop): the plane cells this lane drops into a large window
+  // (cell k = lane + 64 j: row, column) and, per agent, the window cells it gathers for a small one
+  constexpr int NP = (SGW_MAX_CELLS + WAVE - 1) / WAVE;
+  int prr[NP], pcc[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) { const int k = lane + WAVE * j; prr[j] = k / v.W; pcc[j] = k - prr[j] * v.W; }
+  const int npass = (HW + WAVE - 1) / WAVE;
+  for (long long e = blockIdx.x; e < n; e += gridDim.x) {
+    const uint8_t* src = layers + e * (long long)(L * HW);
+    for (int i = threadIdx.x; i < L * HW; i += blockDim.x) lay[i] = src[i];
+    __syncthreads();
+    for (int ag = 0; ag < v.A; ++ag) {                         // scalar loops: agent, then this wave's layers
+      const int vh = v.vh[ag], vw = v.vw[ag], cells = vh * vw;
+      if (cells == 0) continue;
+      const long long ea = e * v.A + ag;
+      const int pr = (int)pos[ea * 2] - v.up[ag], pc = (int)pos[ea * 2 + 1] - v.left[ag];
+      const int dir = flags ? (flags[ea] >> 3) & 3 : 2;
+      if (cells > HW) {
+        // landing offset of plane cell (r, c): +-(r * n + c) or +-(c * n - r) plus an env scalar (see views_stage_wave_per_env)
+        const int n1 = vw - 1;
+        const int base = dir == 2 ? -(pr * vw + pc) : (dir == 3 ? (n1 + pr) * vw + n1 + pc : (dir == 0 ? n1 + pr - pc * vw : (n1 + pc) * vw - pr));
+        const bool useQ = dir < 2, neg = dir == 3 || dir == 1;
+        const bool covers = v.up[ag] >= v.H - 1 && vh - 1 - v.up[ag] >= v.H - 1 && v.left[ag] >= v.W - 1 && vw - 1 - v.left[ag] >= v.W - 1;
+        int at[NP]; bool ok[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          const int t = useQ ? pcc[j] * vw - prr[j] : prr[j] * vw + pcc[j];
+          at[j] = (neg ? -t : t) + base;
+          ok[j] = j < npass && lane + WAVE * j < HW;
+          if (!covers) { const int cr = prr[j] - pr, c2 = pcc[j] - pc; ok[j] = ok[j] && cr >= 0 && cr < vh && c2 >= 0 && c2 < vw; }
+        }
+        for (int l = wave; l < L; l += nwave) {
+          const uint32_t pad = chars[l] == outside ? 0x01010101u : 0u;
+          const uint8_t* pl = lay + l * HW;
+          uint8_t* dst = img + v.off[ag] * L + l * cells;
+          // pad fill: bytes up to the first dword boundary, dwords, tail bytes (dst is byte-aligned only)
+          const int head = (int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3), nh = head < cells ? head : cells;
+          if (lane < nh) dst[lane] = (uint8_t)pad;
+          uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + nh);
+          const int nd = (cells - nh) >> 2;
+          for (int k = lane; k < nd; k += WAVE) d4[k] = pad;
+          const int done = nh + 4 * nd;
+          if (lane < cells - done) dst[done + lane] = (uint8_t)pad;
+          lds_wave_sync();
+          uint8_t val[NP];
+#pragma unroll
+          for (int j = 0; j < NP; ++j) val[j] = pl[ok[j] ? lane + WAVE * j : 0];
+#pragma unroll
+          for (int j = 0; j < NP; ++j) if (ok[j]) dst[at[j]] = val[j];
+        }
+      } else {
+        for (int l = wave; l < L; l += nwave) {
+          const uint8_t pad = (uint8_t)(chars[l] == outside);
+          const uint8_t* pl = lay + l * HW;
+          uint8_t* dst = img + v.off[ag] * L + l * cells;
+          for (int k = lane; k < cells; k += WAVE) {
+            int vr = k / vw, vc = k - vr * vw;
+            view_unrotate(dir, vw, vr, vc);
+            const int r = vr + pr, c = vc + pc;
+            dst[k] = (r >= 0 && r < v.H && c >= 0 && c < v.W) ? pl[r * v.W + c] : pad;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    uint8_t* g = out + e * (long long)row_bytes;
+    const int ndw = row_bytes >> 2;
+    for (int j = threadIdx.x; j < ndw; j += blockDim.x) {
+      const uint32_t val = reinterpret_cast<const uint32_t*>(img)[j];
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("global_store_dword %0, %1, off" : : "v"(g + 4 * j), "v"(val) : "memory");      // a dword at a byte address
+#else
+      for (int b = 0; b < 4; ++b) g[4 * j + b] = (uint8_t)(val >> (8 * b));
+#endif
+    }
+    for (int j = 4 * ndw + (int)threadIdx.x; j < row_bytes; j += blockDim.x) g[j] = img[j];
+    __syncthreads();                                         // the next env reuses the planes and the image
+  }
+}
+
 // per-layer agent windows: out[e][agent][layer][vr][vc]; one wave per (env, agent, layer)
 __global__ void k_agent_layer_views(const uint8_t* layers, const uint8_t* pos, const uint8_t* flags, long long n, ViewSpec v,
                                     const uint8_t* chars, int L, uint8_t outside, uint8_t* out, int lds_per_wave) {
