@@ -134,7 +134,8 @@ indices: serial LDS round trips) → 7.2-7.4 µs (compile-time K, vectors in reg
 → 10.6 µs, `k_observe_layers` 21.8 → 12.9 µs (first LDS-staged version, 16 output bytes per lane → four cells and a dword store per lane and
 plane; unaligned dword stores where H·W is odd).  Firemaker's 17 × 17 layers 88 → 51 (dword path) → 23.8 µs (16 instead of 64 envs per
 workgroup: 24 instead of 95 KB of LDS).  `k_savanna_layers` 137 → 45 µs (state words and code vectors in LDS, the same plane writer).
-`k_agent_layer_views` and `k_agent_views` are round 2's kernels (first measured here; firemaker's windows now come from the round's launch).
+`k_agent_layer_views` 208 → 160 (a workgroup per env, planes and the env's output row in LDS) → 121 µs (lane constants hoisted out of the env loop,
+dword pad fill); `k_agent_views` is round 2's kernel (first measured here; firemaker's windows now come from the round's launch).
 
 ## Other workloads (`r03_{tag}_bench_*.json`; in brackets round 2's µs per launch)
 
@@ -148,8 +149,8 @@ instead of 282 µs per round (DESIGN.md §4.9).  The firemaker VALU fraction use
 Python-level step paths (`r03_{tag}_vec_probe.txt`, `r03_{tag}_zoo_vector_probe.txt`): `GridworldVectorEnv.step` 18-19 µs per call including the
 in-place action copy (default outputs), 20-25 µs of host time with `full_info=True` (51 µs end to end: device-bound); `GridworldZooVectorEnv.step`
 firemaker 82.5-87 µs per round (125 in round 2), island_navigation_ex_ma 43.6 (51), aintelope_savanna 105 (103; its default 21 × 21 windows are
-larger than the board and stay a separate launch); with the layer cubes (`layers_in_observation=True`) firemaker 314 µs (377 before the layer
-kernels' rewrite), ima 187 µs.
+larger than the board and stay a separate launch); with the layer cubes (`layers_in_observation=True`) firemaker 233 µs (377 before the layer
+kernels' rewrite), ima 186 µs.
 
 '''
 open(P + "README.md", "w").write(new + earlier)
