@@ -985,6 +985,19 @@ int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agen
     HIP_TRY(hipGetLastError());
     return SGW_OK;
   }
+  {
+    // one wave per env: the board and the env's row of windows in LDS, the row out as dword stores at its byte address (the layer-cube
+    // kernel with one plane; round 2's k_agent_views -- a wave per window, cells loaded from global memory -- took 26 us for 16 384 envs)
+    const int lay_bytes = (e->ks.HW + 15) / 16 * 16;
+    const size_t lds = (size_t)lay_bytes + ((size_t)v.total + 15) / 16 * 16;
+    if (lds <= 64 * 1024) {
+      const int blocks = (int)(e->n_envs < 16384 ? e->n_envs : 16384);
+      hipLaunchKernelGGL(k_agent_layer_views_lds, dim3(blocks), dim3(WAVE), lds, (hipStream_t)stream, board_dev, agent_pos_dev, agent_flags_dev,
+                         (long long)e->n_envs, v, (const uint8_t*)nullptr, 1, outside_chr, views_dev, lay_bytes, 1);
+      HIP_TRY(hipGetLastError());
+      return SGW_OK;
+    }
+  }
   long long total = e->n_envs * (long long)v.A * WAVE;                   // one wave per (env, agent) window
   int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   const int lds_per_wave = view_stage_bytes(v);
@@ -1016,7 +1029,7 @@ int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_
   if (lds <= 64 * 1024) {
     const int blocks = (int)(e->n_envs < 4096 ? e->n_envs : 4096);
     hipLaunchKernelGGL(k_agent_layer_views_lds, dim3(blocks), dim3(256), lds, (hipStream_t)stream, layers_dev, agent_pos_dev, agent_flags_dev,
-                       (long long)e->n_envs, v, layer_chars_dev, n_layers, outside_chr, out_dev, lay_bytes);
+                       (long long)e->n_envs, v, layer_chars_dev, n_layers, outside_chr, out_dev, lay_bytes, 0);
     HIP_TRY(hipGetLastError());
     return SGW_OK;
   }

@@ -1527,7 +1527,9 @@ __global__ void k_agent_layer_views_small(const uint8_t* layers, const uint8_t* 
 // as dword stores at its byte address (rows of L * view_bytes bytes are not aligned to anything).  Round 2's kernel below -- one
 // wave per window, every cell a byte load from global memory -- took 208 us for 16 384 firemaker envs (0.13 of HBM).
 __global__ __launch_bounds__(256) void k_agent_layer_views_lds(const uint8_t* layers, const uint8_t* pos, const uint8_t* flags, long long n, ViewSpec v,
-                                                               const uint8_t* chars, int L, uint8_t outside, uint8_t* out, int lay_bytes) {
+                                                               const uint8_t* chars, int L, uint8_t outside, uint8_t* out, int lay_bytes, int pad_is_char) {
+  // pad_is_char: the planes are ascii boards (L = 1: sgw_agent_views) and cells outside the board read `outside` itself; otherwise
+  // they are layer planes and read 1 on the outside character's own layer (agent_perspectives_with_layers)
   extern __shared__ __attribute__((aligned(16))) uint8_t view_lds[];
   uint8_t* lay = view_lds;                                   // [L][H*W]
   uint8_t* img = view_lds + lay_bytes;                       // the env's output row: [agent][layer][vh][vw]
@@ -1565,7 +1567,7 @@ __global__ __launch_bounds__(256) void k_agent_layer_views_lds(const uint8_t* la
           if (!covers) { const int cr = prr[j] - pr, c2 = pcc[j] - pc; ok[j] = ok[j] && cr >= 0 && cr < vh && c2 >= 0 && c2 < vw; }
         }
         for (int l = wave; l < L; l += nwave) {
-          const uint32_t pad = chars[l] == outside ? 0x01010101u : 0u;
+          const uint32_t pad = pad_is_char ? 0x01010101u * outside : (chars[l] == outside ? 0x01010101u : 0u);
           const uint8_t* pl = lay + l * HW;
           uint8_t* dst = img + v.off[ag] * L + l * cells;
           // pad fill: bytes up to the first dword boundary, dwords, tail bytes (dst is byte-aligned only)
@@ -1585,7 +1587,7 @@ __global__ __launch_bounds__(256) void k_agent_layer_views_lds(const uint8_t* la
         }
       } else {
         for (int l = wave; l < L; l += nwave) {
-          const uint8_t pad = (uint8_t)(chars[l] == outside);
+          const uint8_t pad = pad_is_char ? outside : (uint8_t)(chars[l] == outside);
           const uint8_t* pl = lay + l * HW;
           uint8_t* dst = img + v.off[ag] * L + l * cells;
           for (int k = lane; k < cells; k += WAVE) {
