@@ -61,7 +61,7 @@ boat_us, _ = rocprof(T + "kernel_stats_mixed.csv", "sgw::Boat, 0>")
 mi_us, _ = rocprof(T + "kernel_stats_mixed.csv", "IslandT<false, true>, 0>")
 si_us, _ = rocprof(T + "kernel_stats_mixed.csv", "sgw::SafeInt, 0>")
 side_rp = "; ".join("%s %.1f µs" % (k, rocprof(T + "kernel_stats_side.csv", k)[0]) for k in
-                    ("k_derived_stats", "k_savanna_layers", "k_agent_views", "k_agent_layer_views"))
+                    ("k_derived_stats", "k_savanna_layers", "k_agent_layer_views_lds"))
 fm_valu = json.load(open(P + "r03_pmc_firemaker_ex_ma.json"))["pmc_median_per_launch"]["SQ_INSTS_VALU"]
 new = f'''# profiles/ — measurements (1× MI355X, gfx950, ROCm 7.2)
 
@@ -135,7 +135,8 @@ indices: serial LDS round trips) → 7.2-7.4 µs (compile-time K, vectors in reg
 plane; unaligned dword stores where H·W is odd).  Firemaker's 17 × 17 layers 88 → 51 (dword path) → 23.8 µs (16 instead of 64 envs per
 workgroup: 24 instead of 95 KB of LDS).  `k_savanna_layers` 137 → 45 µs (state words and code vectors in LDS, the same plane writer).
 `k_agent_layer_views` 208 → 160 (a workgroup per env, planes and the env's output row in LDS) → 121 µs (lane constants hoisted out of the env loop,
-dword pad fill); `k_agent_views` is round 2's kernel (first measured here; firemaker's windows now come from the round's launch).
+dword pad fill); `sgw_agent_views` 26.3 → 17.5 µs through the same kernel with one plane (one wave per env; firemaker's windows normally come
+from the round's own launch).
 
 ## Other workloads (`r03_{tag}_bench_*.json`; in brackets round 2's µs per launch)
 
