@@ -128,7 +128,7 @@ overlap their latencies -- hence one launch per step is 6 % slower than three an
 | kernel | µs / launch | MB | GB/s | frac of 8 TB/s |
 |---|---|---|---|---|
 {sidetab}
-rocprofv3 durations of the same launches (`r03_{tag}_kernel_stats_side.csv`; `k_observe*` rows average several board sizes): {side_rp}.
+rocprofv3 durations of the same launches (`r03_{tag}_kernel_stats_side.csv`; `k_observe*` rows average several board sizes; `k_agent_layer_views_lds` averages its layer-cube launches, 121 µs, and the one-plane launches of `sgw_agent_views`, 17.5 µs): {side_rp}.
 History inside the round: `k_derived_stats` 29.7 µs with 2.6 KB of scratch per lane (round 2) → 23.1 µs (vectors streamed from LDS at run-time
 indices: serial LDS round trips) → 7.2-7.4 µs (compile-time K, vectors in registers).  `k_observe` RGB 9.0 → 4.6 µs, RGB + occluded layers 23.2
 → 10.6 µs, `k_observe_layers` 21.8 → 12.9 µs (first LDS-staged version, 16 output bytes per lane → four cells and a dword store per lane and
