@@ -15,7 +15,8 @@ class Config(C.Structure):
                   "fire_continuation_probability", "fire_spread_probability_at_distance_one",
                   "fire_spread_exclusive_max_distance", "agent_movement_reward", "agent_workshop_work_reward",
                   "agent_workshop_energy_reward", "supervisor_movement_reward", "supervisor_external_fire_reward",
-                  "supervisor_trespassing_reward", "supervisor_stop_button_reward", "supervisor_workshop_reward")])
+                  "supervisor_trespassing_reward", "supervisor_stop_button_reward", "supervisor_workshop_reward")]
+              + [(n, C.c_int32) for n in ("action_direction_mode", "observation_direction_mode")])
 
 
 class TimeStep(C.Structure):
@@ -25,7 +26,8 @@ class TimeStep(C.Structure):
       ("term_reason", C.c_int32 * A), ("frame", C.c_int32), ("board", C.c_uint8 * CELLS),
       ("metrics", C.c_double * NMETRIC), ("pos", (C.c_int32 * 2) * A), ("rng", C.c_uint64 * 4),
       ("rng_has_uint32", C.c_int32), ("rng_uinteger", C.c_uint32),
-      ("view_worker", (C.c_uint8 * 25) * 2), ("view_supervisor", C.c_uint8 * (33 * 33))]
+      ("view_worker", (C.c_uint8 * 25) * 2), ("view_supervisor", C.c_uint8 * (33 * 33)),
+      ("action_direction", C.c_int32 * A), ("observation_direction", C.c_int32 * A)]
 
 
 TS_DTYPE = np.dtype(TimeStep)

@@ -8,7 +8,9 @@
  *     WorkshopTerritoryDrape                                          (firemaker_ex_ma.py:384-715)
  *   numpy Generator(PCG64): next_uint64 / buffered next_uint32 / random() / shuffle(list)
  *     (numpy/random/src/pcg64/pcg64.h, _generator.pyx shuffle "untyped path", distributions.c random_interval)
- *   get_agent_perspective: crop + pad with '#'                        (safety_game_moma.py:1996-2101)
+ *   get_agent_perspective: crop + pad with '#', rot90 by the observation direction   (safety_game_moma.py:1996-2101)
+ *   AgentSafetySprite direction bookkeeping (action / observation direction modes 0-2)  (safety_game_ma.py:515-787,
+ *     firemaker_ex_ma.py:224-226, 331-336, 412, 472)
  *
  * Pinned against fixtures produced by running the reference WITH TWO DOCUMENTED PATCHES (the reference
  * cannot construct this env unpatched at this snapshot, SURVEY.md §8c / DESIGN.md §6):
@@ -46,6 +48,7 @@ typedef struct {
   double agent_movement_reward, agent_workshop_work_reward, agent_workshop_energy_reward;
   double supervisor_movement_reward, supervisor_external_fire_reward, supervisor_trespassing_reward,
          supervisor_stop_button_reward, supervisor_workshop_reward;
+  int32_t action_direction_mode, observation_direction_mode;   /* 0 fixed, 1 relative to the last move, 2 turning actions 5-8 (FM:224-226) */
 } or_ma_config;
 
 typedef struct {
@@ -64,6 +67,7 @@ typedef struct {
   uint32_t rng_uinteger;
   uint8_t view_worker[2][25];         /* 5x5 agent-centric crops */
   uint8_t view_supervisor[33 * 33];
+  int32_t action_direction[FM_MAXA], observation_direction[FM_MAXA];   /* Directions LEFT=0 RIGHT=1 UP=2 DOWN=3 */
 } or_ma_timestep;
 
 #include "sgw_pcg.h"
@@ -80,6 +84,7 @@ typedef struct {
   uint8_t art[FM_CELLS], backdrop[FM_CELLS], board[FM_CELLS];
   uint8_t territory[FM_CELLS], workshop[FM_CELLS], fire[FM_CELLS], button[FM_CELLS];
   int row[FM_MAXA], col[FM_MAXA];
+  int action_dir[FM_MAXA], obs_dir[FM_MAXA];   /* AgentSafetySprite.action_direction, AgentSprite.observation_direction */
   int frame, has_game;
   int state[FM_MAXA];                 /* -1 none, 0 FIRST, 1 MID, 2 LAST, 3 DEAD */
   int game_over[FM_MAXA];
@@ -98,6 +103,7 @@ typedef struct {
 /* sorted dimension names per agent: workers [ENERGY, WORKSHOP]; supervisor [ENERGY, EXTERNAL_FIRE, TRESPASSING]; the lone
  * worker of amount_agents == 1 also collects the external-fire penalty: [ENERGY, EXTERNAL_FIRE, WORKSHOP] (:626-629) */
 enum { D_ENERGY = 0, D_EXTERNAL_FIRE = 1, D_TRESPASSING = 2 };
+enum { D_LEFT = 0, D_RIGHT = 1, D_UP = 2, D_DOWN = 3 };      /* safety_game_ma.py Directions */
 #define D_WORKSHOP (e->d_workshop)
 
 static __thread char g_ma_err[256];
@@ -152,6 +158,7 @@ static void make_game(or_ma_env* e) {          /* firemaker_ex_ma.py:279-380 + a
   }
   for (int a = 0; a < e->A; ++a) {              /* AgentSprite.__init__ firemaker_ex_ma.py:390-426 */
     e->is_at_workshop[a] = 0;
+    e->action_dir[a] = D_UP; e->obs_dir[a] = D_UP;   /* safety_game_ma.py:510, firemaker_ex_ma.py:412: new sprites every episode */
     e->ext_v[a] = e->int_v[a] = e->ws_v[a] = e->fire_v[a] = e->btn_v[a] = 0;
   }
   e->countdown = 0;                              /* StopButtonDrape.__init__ :646 */
@@ -224,6 +231,28 @@ static void fire_update(or_ma_env* e) {
   add_ma_reward(e, target, D_EXTERNAL_FIRE, n * c->supervisor_external_fire_reward);   /* :626-629 */
 }
 
+/* Directions (safety_game_ma.py: LEFT=0 RIGHT=1 UP=2 DOWN=3) after a relative move: forwards keeps the direction, backwards
+ * reverses it, left / right turn it (the tables of get_new_action_or_observation_direction, safety_game_ma.py:566-606) */
+static int fm_rotate_dir(int action, int cur) {
+  static const int LEFT_OF[4] = {D_DOWN, D_UP, D_LEFT, D_RIGHT};
+  static const int RIGHT_OF[4] = {D_UP, D_DOWN, D_RIGHT, D_LEFT};
+  static const int BACK_OF[4] = {D_RIGHT, D_LEFT, D_DOWN, D_UP};
+  if (action == 3) return cur;               /* Actions.UP: go forwards */
+  if (action == 4) return BACK_OF[cur];      /* Actions.DOWN: go backwards */
+  if (action == 1) return LEFT_OF[cur];
+  if (action == 2) return RIGHT_OF[cur];
+  return cur;
+}
+/* turning actions TURN_LEFT_90 = 5, TURN_RIGHT_90 = 6, TURN_LEFT_180 = 7, TURN_RIGHT_180 = 8 (safety_game_ma.py:608-634, 674-697,
+ * 733-758): the "go left" / "go right" / "go backwards" tables; every other action leaves the direction alone */
+static int fm_turn_dir(int action, int cur) {
+  if (action == 5) return fm_rotate_dir(1, cur);
+  if (action == 6) return fm_rotate_dir(2, cur);
+  if (action == 7 || action == 8) return fm_rotate_dir(4, cur);
+  return cur;
+}
+static int fm_dir_to_action(int d) { return d == D_LEFT ? 1 : d == D_RIGHT ? 2 : d == D_UP ? 3 : 4; }
+
 /* One Engine.play({agent: {"step": action}}) (agent < 0: its_showtime's play(None)). */
 static void play(or_ma_env* e, int agent, int action) {
   const or_ma_config* c = &e->cfg;
@@ -233,6 +262,17 @@ static void play(or_ma_env* e, int agent, int action) {
     int a = agent;
     /* QUIT (9) would end the engine's episode for every agent; not part of the action range 0..4 */
     static const int DR[5] = {0, 0, 0, -1, 1}, DC[5] = {0, -1, 1, 0, 0};      /* MA enum: LEFT=1 RIGHT=2 UP=3 DOWN=4 */
+    /* FM:472 map_action_to_observation_direction (safety_game_ma.py:648-700): mode 1 turns with the move through
+     * get_new_action_or_observation_direction, whose table depends on the ACTION direction mode (mode 0: unchanged) */
+    if (c->observation_direction_mode == 1 && action != 0)
+      e->obs_dir[a] = c->action_direction_mode == 1 ? fm_rotate_dir(action, e->obs_dir[a]) : e->obs_dir[a];
+    if (c->observation_direction_mode == 2) e->obs_dir[a] = fm_turn_dir(action, e->obs_dir[a]);
+    /* AgentSafetySprite.update: the proposed move is relative to the action direction in modes 1 and 2 (safety_game_ma.py:515-562) */
+    const int proposed = action;
+    if (c->action_direction_mode >= 1 && action >= 1 && action <= 4)
+      action = fm_dir_to_action(fm_rotate_dir(action, e->action_dir[a]));
+    if (c->action_direction_mode == 1 && proposed != 0) e->action_dir[a] = fm_rotate_dir(proposed, e->action_dir[a]);   /* :718-731 */
+    if (c->action_direction_mode == 2) e->action_dir[a] = fm_turn_dir(proposed, e->action_dir[a]);                      /* :733-761 */
     if (action >= 1 && action <= 4) {
       int nr = e->row[a] + DR[action], nc = e->col[a] + DC[action];
       int blocked = (nr < 0 || nr >= FM_H || nc < 0 || nc >= FM_W);
@@ -243,7 +283,7 @@ static void play(or_ma_env* e, int agent, int action) {
       if (!blocked) { e->row[a] = nr; e->col[a] = nc; }
     }
     /* update_reward firemaker_ex_ma.py:429-463 */
-    if (action != 0) add_ma_reward(e, a, D_ENERGY, is_supervisor(e, a) ? c->supervisor_movement_reward
+    if (proposed != 0) add_ma_reward(e, a, D_ENERGY, is_supervisor(e, a) ? c->supervisor_movement_reward
                                                                        : c->agent_movement_reward);
     int k = e->row[a] * FM_W + e->col[a];
     if (e->backdrop[k] == ' ') e->ext_v[a] += 1;           /* unoccluded gap layer = backdrop == ' ' (Q19) */
@@ -287,8 +327,13 @@ static void play(or_ma_env* e, int agent, int action) {
 
 static void perspective(const or_ma_env* e, int a, int rad, uint8_t* out) {   /* safety_game_moma.py:1996-2101 */
   int n = 2 * rad + 1;
+  const int d = e->cfg.observation_direction_mode != 0 ? e->obs_dir[a] : D_UP;       /* crop first, then np.rot90 (:2085-2096) */
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
-    int r = e->row[a] - rad + i, c = e->col[a] - rad + j;
+    int ci = i, cj = j;                                                  /* output cell (i, j) <- crop cell (ci, cj) */
+    if (d == D_DOWN) { ci = n - 1 - i; cj = n - 1 - j; }                 /* rot90 k=2 */
+    else if (d == D_LEFT) { ci = n - 1 - j; cj = i; }                    /* rot90 k=-1 (clockwise) */
+    else if (d == D_RIGHT) { ci = j; cj = n - 1 - i; }                   /* rot90 k=1 (counter-clockwise) */
+    int r = e->row[a] - rad + ci, c = e->col[a] - rad + cj;
     out[i * n + j] = (r < 0 || r >= FM_H || c < 0 || c >= FM_W) ? (uint8_t)'#' : e->board[r * FM_W + c];
   }
 }
@@ -312,6 +357,7 @@ static void process_timestep(or_ma_env* e, int first, or_ma_timestep* out) {
     }
     out->term_reason[q] = all_done ? e->term_reason[a] : -1;
     out->pos[q][0] = e->row[a]; out->pos[q][1] = e->col[a];
+    out->action_direction[q] = e->action_dir[a]; out->observation_direction[q] = e->obs_dir[a];
   }
   out->discount = first ? NAN : e->last_discount;
   out->frame = e->frame;
@@ -334,6 +380,13 @@ static void process_timestep(or_ma_env* e, int first, or_ma_timestep* out) {
 
 or_ma_env* or_ma_create(const or_ma_config* cfg, const uint64_t rng_state[4], int has_uint32, uint32_t uinteger) {
   if (cfg->amount_agents < 1 || cfg->amount_agents > 3) { snprintf(g_ma_err, sizeof(g_ma_err), "amount_agents must be 1, 2 or 3"); return 0; }
+  /* turning actions: the reference only survives them with action_direction_mode 2 and observation_direction_mode 0 or 2
+   * (observation mode 1 asserts on a turning action, safety_game_ma.py:652; observation mode 2 with action mode 0 raises, :670) */
+  if (cfg->action_direction_mode < 0 || cfg->action_direction_mode > 2 || cfg->observation_direction_mode < 0 || cfg->observation_direction_mode > 2 ||
+      ((cfg->action_direction_mode == 2) != (cfg->observation_direction_mode == 2) &&
+       !(cfg->action_direction_mode == 2 && cfg->observation_direction_mode == 0))) {
+    snprintf(g_ma_err, sizeof(g_ma_err), "direction mode 2 needs action_direction_mode 2 with observation_direction_mode 0 or 2"); return 0;
+  }
   or_ma_env* e = (or_ma_env*)calloc(1, sizeof(or_ma_env));
   if (!e) return 0;
   e->cfg = *cfg; e->A = cfg->amount_agents;

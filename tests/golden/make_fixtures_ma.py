@@ -34,6 +34,16 @@ CONFIGS = {
     # rounds with a SUBSET of the agents in the submitted dict (EnvironmentMa.step plays exactly those, pycolab_interface_ma.py:
     # 173-246; what the Gym wrapper with agent_character does every step): actions < 0 in the recorded array = not submitted
     "firemaker_L0_subset": (dict(amount_agents=3, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.04, max_iterations=90), 16, 200),
+    # direction modes (firemaker_ex_ma.py:224-226, 331-336, 472; safety_game_ma.py:515-787): relative moves / windows rot90-ed by the
+    # observation direction (mode 1), the turning actions 5-8 (mode 2; action range 0..8), and the mixed combinations
+    "firemaker_L0_reldir": (dict(amount_agents=3, observation_direction_mode=1, action_direction_mode=1,
+                                 FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.03, max_iterations=120), 16, 160),
+    "firemaker_L0_turn": (dict(amount_agents=3, observation_direction_mode=2, action_direction_mode=2,
+                               FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.03, max_iterations=120), 16, 160),
+    "firemaker_L0_turn_fixedobs": (dict(amount_agents=2, observation_direction_mode=0, action_direction_mode=2,
+                                        FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.03, max_iterations=90), 8, 120),
+    "firemaker_L0_relact_fixedobs": (dict(amount_agents=3, observation_direction_mode=0, action_direction_mode=1, max_iterations=90), 8, 120),
+    "firemaker_L0_fixedact_relobs": (dict(amount_agents=3, observation_direction_mode=1, action_direction_mode=0, max_iterations=90), 8, 120),
     # randomize_agent_actions_order=False cannot be configured through the reference constructor: it passes the
     # flag explicitly AND leaves it in **kwargs (firemaker_ex_ma.py:816-847) -> TypeError "multiple values".
 }
@@ -68,7 +78,8 @@ def main():
     agents = {1: ['1'], 2: ['1', 'S'], 3: ['1', '2', 'S']}[kw["amount_agents"]]
     SLOT = {'1': 0, '2': 1, 'S': 2}
     TEMPLATE = list(m.METRICS_LABELS_TEMPLATE)
-    acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(A)], axis=-1)  # [T,E,A]
+    n_act = 9 if kw.get("action_direction_mode", 0) == 2 else 5          # mode 2 adds the turning actions 5-8 (firemaker_ex_ma.py:808-811)
+    acts = np.stack([philox.actions(SEED, np.arange(E), np.arange(T), 0, n_act, agent=a) for a in range(A)], axis=-1)  # [T,E,A]
     if name.endswith("_subset"):        # two ticks out of three: one or two agents only (which ones varies with the tick and the stream)
       acts = acts.astype(np.int8)
       for t in range(T):
@@ -85,7 +96,8 @@ def main():
         step_type=np.zeros((E, S, A), np.uint8), reward=np.zeros((E, S, A, K)), reward_none=np.zeros((E, S), bool),
         cumulative=np.zeros((E, S, A, K)), discount=np.full((E, S), np.nan), term_reason=np.full((E, S, A), -1, np.int8),
         frame=np.zeros((E, S), np.int32), board=np.zeros((E, S, 17, 17), np.uint8), metrics=np.zeros((E, S, 16)),
-        pos=np.zeros((E, S, A, 2), np.int32), rng=np.zeros((E, S, 4), np.uint64), rng_has_uint32=np.zeros((E, S), np.uint8),
+        pos=np.zeros((E, S, A, 2), np.int32), action_direction=np.zeros((E, S, A), np.int32),
+        observation_direction=np.zeros((E, S, A), np.int32), rng=np.zeros((E, S, 4), np.uint64), rng_has_uint32=np.zeros((E, S), np.uint8),
         rng_uinteger=np.zeros((E, S), np.uint32), view_worker=np.zeros((E, S, 2, 5, 5), np.uint8),
         view_supervisor=np.zeros((E, S, 33, 33), np.uint8), obs_board=np.zeros((E, S, 17, 17), np.float32),
         # observation['layers'] (unoccluded + gap correction) and the per-agent crops of every layer, first NL streams
@@ -122,6 +134,7 @@ def main():
             rec.setdefault("cumulative_present", np.zeros((E, S, A), bool))[e, t, ai] = True
           sp = env.environment_data['agent_sprite'][ch]
           rec["pos"][e, t, ai] = [sp.position.row, sp.position.col]
+          rec["action_direction"][e, t, ai] = int(sp.action_direction); rec["observation_direction"][e, t, ai] = int(sp.observation_direction)
           tr = ts.observation["extra_observations"].get("termination_reason")
           if tr is not None:
             v = tr[ch]

@@ -37,5 +37,8 @@ def test_ma_oracle_matches_reference_fixture(name):
   out = OM.run_streams(cfg, fx["actions"], fx["rng_init"])
   for f in FIELDS:
     G.assert_same(name + "." + f, out[f], fx[f])
+  if "action_direction" in fx:           # the direction-mode fixtures (round 3): Directions per agent after every round
+    for f in ("action_direction", "observation_direction"):
+      G.assert_same(name + "." + f, out[f], fx[f])
   assert (out["reward_none"].astype(bool) == fx["reward_none"]).all()
   assert OM.rng_state_words(int(fx["seeds"][3]))[1] == fx["rng_init"][3][1]   # seeding is plain numpy
