@@ -206,6 +206,7 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
   kspec_views(k, *spec);
   if (spec->family == SGW_ISLAND_NAVIGATION_EX_MA) k.view_rotates = (spec->flags & (IslandMa::F_ODIR | IslandMa::F_ODIR_TURN)) ? 1 : 0;
   if (spec->family == SGW_AINTELOPE_SAVANNA) k.view_rotates = (spec->flags & (Savanna::F_ODIR | Savanna::F_ODIR_TURN)) ? 1 : 0;
+  if (spec->family == SGW_FIREMAKER_EX_MA) k.view_rotates = (spec->flags & (Firemaker::F_ODIR | Firemaker::F_ODIR_TURN)) ? 1 : 0;
   memcpy(k.dim_slot, spec->dim_slot, sizeof(k.dim_slot));
   memcpy(k.metric_slot, spec->metric_slot, sizeof(k.metric_slot));
 
@@ -1097,7 +1098,7 @@ static int step_full_launches(sgw_engine* e, const int8_t* actions_dev, const sg
   if (x->layers && !layers_here) { rc = sgw_state_layers(e, x->layer_chars_dev, x->n_layers, 1, x->layers, stream); if (rc) return rc; }
   if (x->stats) { rc = sgw_derived_stats(e, out->reward, out->cumulative, out->frame, x->k_agent, x->stats, stream); if (rc) return rc; }
   if (x->agent_layer_views) {
-    const bool rot = e->spec.family != SGW_FIREMAKER_EX_MA;      // the families with observation directions rotate by agent_flags (UP = none)
+    const bool rot = e->spec.family != SGW_FIREMAKER_EX_MA || e->ks.view_rotates;   // observation directions come in agent_flags (UP = no rotation)
     rc = sgw_agent_layer_views(e, x->layers, out->agent_pos, rot ? out->agent_flags : nullptr, x->layer_chars_dev, x->n_layers,
                                (uint8_t)(e->ks.view_pad), x->agent_layer_views, stream);
     if (rc) return rc;

@@ -26,12 +26,15 @@
 //   20..24 allowed-target mask words 25..29 territory mask words (bit patterns stored in the f64 slots)
 // spec.aux: per-cell class bits: 1 wall, 2 territory (extended), 4 workshop, 8 stop button
 // spec.flags: bit0 randomize_agent_actions_order, bit1 worker '2' absent, bit2 supervisor 'S' absent (amount_agents 2 / 1:
-//   FM:160, 330-337).  The layout always has the three columns ('1','2','S'); an absent agent is parked on the wall cell (0, 0)
+//   FM:160, 330-337); bit3 action_direction_mode 1, bit4 observation_direction_mode 1, bit5 / bit6 the same modes = 2 (the turning
+//   actions 5-8; FM:224-226, 331-336, 472, safety_game_ma.py:515-761).  The layout always has the three columns ('1','2','S'); an absent agent is parked on the wall cell (0, 0)
 //   by the spec's start cells, never plays, is never drawn, and its character stays in the art as a BACKDROP tile (aux bits
 //   16 / 32): '2' under the grown workshop territory (passable, not an external tile), 'S' drawn and impassable unless it burns
 // reward slots: [agent][3]: workers [ENERGY, WORKSHOP, -], supervisor [ENERGY, EXTERNAL_FIRE, TRESPASSING]
 // metrics ids (FM:123-140): 0-2 ExternalVisits_{1,2,S} 3-5 Internal 6-8 Workshop 9-11 Fire 12-14 StopButton 15 countdown
-// state words: 0 core | 1 positions | 2 rng buffer | 3-6 PCG64 state/inc | 7-11 fire | 12-15 visits | 16-24 cumulative
+// agent_flags output: bit0 the agent stands on a burning cell (its tile of the hidden fire layer), bits 1-2 action direction,
+//   bits 3-4 observation direction (Directions LEFT=0 RIGHT=1 UP=2 DOWN=3)
+// state words: 0 core | 1 positions + the six 2-bit directions | 2 rng buffer | 3-6 PCG64 state/inc | 7-11 fire | 12-15 visits | 16-24 cumulative
 #pragma once
 
 #include <utility>
@@ -73,7 +76,8 @@ struct Firemaker {
   static __device__ int slot(const KSpec& sp, int u) { return sp.dim_slot[0][u]; }
   static constexpr bool LDS_SCRATCH_M = false;
   static constexpr int W = 17, H = 17, CELLS = 289;
-  enum { F_SHUFFLE = 1, F_NO_AGENT2 = 2, F_NO_SUP = 4 };
+  enum { F_SHUFFLE = 1, F_NO_AGENT2 = 2, F_NO_SUP = 4, F_ADIR = 8, F_ODIR = 16, F_ADIR_TURN = 32, F_ODIR_TURN = 64 };
+  enum { D_LEFT = 0, D_RIGHT = 1, D_UP = 2, D_DOWN = 3, DIRS_ALL_UP = 0xAAA };
   enum P { P_AGENT_MOVE, P_AGENT_WORK, P_AGENT_WS_ENERGY, P_SUP_MOVE, P_SUP_EXT_FIRE, P_SUP_TRESPASS, P_SUP_BUTTON,
            P_SUP_WORKSHOP, P_CONTINUE, P_SPREAD0, P_VALID = 18, P_RELOAD = 19, P_ALLOWED0 = 20, P_TERR0 = 25 };
   enum { C_WALL = 1, C_TERR = 2, C_WORKSHOP = 4, C_BUTTON = 8, C_GHOST = 16 /* a drawn agent character without a sprite */,
@@ -84,6 +88,7 @@ struct Firemaker {
   struct State {
     int frame, step_type, term, countdown, n_ext, at_ws;   // at_ws: bit a = agent a stands on a workshop tile
     int row[3], col[3];
+    int dirs;                                              // bits 2a..2a+1 action direction of agent a, bits 6+2a.. its observation direction
     uint32_t episode, rng_has32, rng_u32;
     uint64_t rs_hi, rs_lo, ri_hi, ri_lo;                   // PCG64 state / increment
     M5 fire;
@@ -101,6 +106,7 @@ struct Firemaker {
     s.n_ext = (int)((w0 >> 40) & 0xffff);
 #pragma unroll
     for (int ag = 0; ag < 3; ++ag) { s.row[ag] = (int)((w1 >> (16 * ag)) & 0xff); s.col[ag] = (int)((w1 >> (16 * ag + 8)) & 0xff); }
+    s.dirs = (int)((w1 >> 48) & 0xfff);
     s.rng_u32 = (uint32_t)w2; s.episode = (uint32_t)(w2 >> 32);
     s.rs_hi = c.get(); s.rs_lo = c.get(); s.ri_hi = c.get(); s.ri_lo = c.get();
     s.fire.a = c.get(); s.fire.b = c.get(); s.fire.c = c.get(); s.fire.d = c.get(); s.fire.e = c.get();
@@ -119,7 +125,7 @@ struct Firemaker {
     uint64_t w0 = (uint64_t)(s.frame & 0xffff) | ((uint64_t)(s.countdown & 0xff) << 16) | ((uint64_t)(s.at_ws & 7) << 24) |
                   ((uint64_t)(s.rng_has32 & 1) << 27) | ((uint64_t)(s.step_type & 0xf) << 32) |
                   ((uint64_t)(s.term & 0xf) << 36) | ((uint64_t)(s.n_ext & 0xffff) << 40);
-    uint64_t w1 = 0;
+    uint64_t w1 = (uint64_t)(s.dirs & 0xfff) << 48;
 #pragma unroll
     for (int ag = 0; ag < 3; ++ag) w1 |= ((uint64_t)(s.row[ag] & 0xff) << (16 * ag)) | ((uint64_t)(s.col[ag] & 0xff) << (16 * ag + 8));
     c.put(w0); c.put(w1); c.put((uint64_t)s.rng_u32 | ((uint64_t)s.episode << 32));
@@ -143,6 +149,7 @@ struct Firemaker {
     s.frame = 0; s.step_type = ST_FIRST; s.term = 15; s.countdown = 0; s.n_ext = 0; s.at_ws = 0;
 #pragma unroll
     for (int ag = 0; ag < 3; ++ag) { s.row[ag] = sp.start_row[ag]; s.col[ag] = sp.start_col[ag]; }
+    s.dirs = DIRS_ALL_UP;                                  // new sprites every episode: Directions.UP (safety_game_ma.py:510, FM:412)
     s.episode += 1;
     s.fire.a = s.fire.b = s.fire.c = s.fire.d = s.fire.e = 0;
 #pragma unroll
@@ -600,11 +607,36 @@ struct Firemaker {
 #endif
   }
 
+  // safety_game_ma.py:566-606 (the mode-1 tables), Directions L=0 R=1 U=2 D=3, Actions NOOP=0 L=1 R=2 U=3 D=4
+  static __device__ int rotate_dir(int action, int cur) {
+    const int back = cur ^ 1;                                              // L<->R, U<->D
+    const int left = cur == D_UP ? D_LEFT : (cur == D_DOWN ? D_RIGHT : (cur == D_LEFT ? D_DOWN : D_UP));
+    const int right = left ^ 1;
+    return action == 3 ? cur : (action == 4 ? back : (action == 1 ? left : (action == 2 ? right : cur)));
+  }
+
   // one Engine.play({agent: {"step": action}})
-  static __device__ void play_one(State& s, int ag, int action, const KSpec& sp, const Lds& l, double (&r)[NU], bool live, Ctx& cx) {
+  static __device__ void play_one(State& s, int ag, int proposed, const KSpec& sp, const Lds& l, double (&r)[NU], bool live, Ctx& cx) {
     const double* p = l.params;
     if (live) {
       s.frame += 1;
+      int action = proposed;
+      if (sp.flags & (F_ADIR | F_ODIR | F_ADIR_TURN | F_ODIR_TURN)) {        // scalar: the env has direction modes at all
+        // FM:472 map_action_to_observation_direction, then AgentSafetySprite.update's relative move (safety_game_ma.py:515-562,
+        // 648-761).  A turning action uses mode 1's table of the move it is named after: 5 = left, 6 = right, 7 / 8 = backwards
+        const bool adir_rel = (sp.flags & F_ADIR) != 0, odir_rel = (sp.flags & F_ODIR) != 0;
+        const bool adir_turn = (sp.flags & F_ADIR_TURN) != 0, odir_turn = (sp.flags & F_ODIR_TURN) != 0;
+        const int cur_ad = (s.dirs >> (2 * ag)) & 3, cur_od = (s.dirs >> (6 + 2 * ag)) & 3;
+        const int turn = proposed == 5 ? 1 : (proposed == 6 ? 2 : (((proposed == 7) | (proposed == 8)) ? 4 : 3));
+        const int new_od = odir_turn ? rotate_dir(turn, cur_od)
+                                     : ((odir_rel && proposed != 0) ? (adir_rel ? rotate_dir(proposed, cur_od) : cur_od) : cur_od);
+        if ((adir_rel || adir_turn) && proposed >= 1 && proposed <= 4) {
+          const int d = rotate_dir(proposed, cur_ad);
+          action = d == D_LEFT ? 1 : (d == D_RIGHT ? 2 : (d == D_UP ? 3 : 4));
+        }
+        const int new_ad = adir_turn ? rotate_dir(turn, cur_ad) : ((adir_rel && proposed != 0) ? rotate_dir(proposed, cur_ad) : cur_ad);
+        s.dirs = (s.dirs & ~((3 << (2 * ag)) | (3 << (6 + 2 * ag)))) | (new_ad << (2 * ag)) | (new_od << (6 + 2 * ag));
+      }
       // AgentSprite.update: MA enum LEFT=1 RIGHT=2 UP=3 DOWN=4; impassable = walls + other agents (FM:399-400)
       const int dr = (action == 4) - (action == 3), dc = (action == 2) - (action == 1);
       int cr = s.row[0], cc = s.col[0];
@@ -622,7 +654,7 @@ struct Firemaker {
       for (int b = 0; b < 3; ++b) { s.row[b] = (b == ag) ? fr : s.row[b]; s.col[b] = (b == ag) ? fc : s.col[b]; }
       // update_reward FM:429-463
       const bool sup = (ag == 2);
-      const double mv = (action != 0) ? (sup ? p[P_SUP_MOVE] : p[P_AGENT_MOVE]) : 0.0;
+      const double mv = (proposed != 0) ? (sup ? p[P_SUP_MOVE] : p[P_AGENT_MOVE]) : 0.0;       // any action but NOOP, turning included (FM:433)
 #pragma unroll
       for (int b = 0; b < 3; ++b) r[b * 3 + 0] += (b == ag) ? mv : 0.0;       // static register indices only
       const int k = fr * W + fc;
@@ -829,7 +861,10 @@ struct Firemaker {
   static __device__ int actual(const State&, int) { return -1; }
   static __device__ void agent_pos(const State& s, int ag, int& r, int& c) { r = s.row[ag]; c = s.col[ag]; }
   // fire can spread under an agent (FM:580-582 is a no-op); the sprite hides it in the board but not in the layers
-  static __device__ int agent_flags(const State& s, int ag) { return get_bit(s.fire, s.row[ag] * W + s.col[ag]) ? 1 : 0; }
+  static __device__ int agent_flags(const State& s, int ag) {
+    return (get_bit(s.fire, s.row[ag] * W + s.col[ag]) ? 1 : 0) | (((s.dirs >> (2 * ag)) & 3) << 1) | (((s.dirs >> (6 + 2 * ag)) & 3) << 3);
+  }
+  static __device__ int view_dir(const State& s, int ag) { return (s.dirs >> (6 + 2 * ag)) & 3; }
 };
 
 }  // namespace sgw

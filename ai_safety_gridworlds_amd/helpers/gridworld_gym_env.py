@@ -109,7 +109,9 @@ class GridworldGymEnv(_Base):
     # multi-agent env behind the single-agent wrapper (gym_env.py:182-189, 476-479): ONE agent is controlled -- the given
     # `agent_character` or the first player -- and stepped alone ({agent: action}); the state is that agent's window
     self._ma = bool(getattr(self.spec_, "per_agent", False)) or self.spec_.family == N.FIREMAKER_EX_MA
-    self._fixed_directions = self.spec_.family == N.FIREMAKER_EX_MA      # no observation / action directions in its state (mode 0)
+    cfg = getattr(self.spec_, "config", {}) or {}
+    self._fixed_directions = (self.spec_.family == N.FIREMAKER_EX_MA and not cfg.get("action_direction_mode", 0)
+                              and not cfg.get("observation_direction_mode", 0))      # firemaker's default: direction mode 0
     if self.spec_.A > 1 and not self._ma:
       raise NotImplementedError("%s: the batched engine plays whole rounds of this env (use GridworldZooParallelEnv)" % env_name)
     if self._ma:

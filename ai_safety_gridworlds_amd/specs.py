@@ -506,8 +506,7 @@ def _firemaker_spec(kwargs):
   if amount not in (1, 2, 3):
     raise ValueError("firemaker_ex_ma: amount_agents must be 1 (worker '1'), 2 ('1' + supervisor 'S', the reference's default) "
                      "or 3 ('1', '2', 'S'): firemaker_ex_ma.py:113-118, 160, 330-337")
-  if cfg["observation_direction_mode"] != 0 or cfg["action_direction_mode"] != 0:
-    raise NotImplementedError("firemaker_ex_ma: only direction mode 0 (fixed) is implemented")
+  _check_direction_modes("firemaker_ex_ma", cfg)       # firemaker_ex_ma.py:224-226, 331-336, 472
   if int(cfg["level"]) != 0:
     raise IndexError("firemaker_ex_ma level %r" % cfg["level"])
   art = FIREMAKER_ART[0]
@@ -559,6 +558,8 @@ def _firemaker_spec(kwargs):
             float(1 + 1 + int(cfg["STOP_BUTTON_PRESS_EFFECT_DURATION"]))]
   params += _mask_words([(a & (1 | 4 | 8)) == 0 for a in aux]) + _mask_words(territory)
   lo, n = (0, 5) if cfg["noops"] else (1, 4)
+  if cfg["action_direction_mode"] == 2:                # the action set gains TURN_LEFT_90 .. TURN_RIGHT_180 = 5..8 (firemaker_ex_ma.py:808-811)
+    n = 9 - lo
   sp = N.Spec()
   # reward units [slot][3]: workers (ENERGY, WORKSHOP, EXTERNAL_FIRE -- the last only for the lone worker of amount_agents = 1,
   # firemaker_ex_ma.py:626-629), supervisor (ENERGY, EXTERNAL_FIRE, TRESPASSING); output columns = the agent's sorted names
@@ -570,7 +571,9 @@ def _firemaker_spec(kwargs):
     unit_cols = list(range(9))
   metric_rows = [i for i, lab in enumerate(FIREMAKER_METRICS) if lab.rsplit("_", 1)[-1] not in ghosts]   # metrics_dict holds the present agents' rows
   metric_slot = [metric_rows.index(i) if i in metric_rows else -1 for i in range(16)]
-  flags = (1 if cfg["randomize_agent_actions_order"] else 0) | (2 if '2' in ghosts else 0) | (4 if 'S' in ghosts else 0)
+  flags = ((1 if cfg["randomize_agent_actions_order"] else 0) | (2 if '2' in ghosts else 0) | (4 if 'S' in ghosts else 0) |
+           (8 if cfg["action_direction_mode"] == 1 else 0) | (16 if cfg["observation_direction_mode"] == 1 else 0) |
+           (32 if cfg["action_direction_mode"] == 2 else 0) | (64 if cfg["observation_direction_mode"] == 2 else 0))
   _fill_common(sp, N.FIREMAKER_EX_MA, art, "".join(static_board), aux, FIREMAKER_VALUES, 3, len(metric_rows), cfg["max_iterations"],
                [flat.index(c) if c in agents else 0 for c in slots], lo, n, flags,       # an absent agent is parked on the wall cell 0
                [unit_cols], metric_slot, params)
@@ -579,6 +582,8 @@ def _firemaker_spec(kwargs):
     if np.isscalar(r): return [int(r)] * 4
     return [int(r[2]), int(r[3]), int(r[0]), int(r[1])]                # Directions LEFT=0 RIGHT=1 UP=2 DOWN=3 -> up, down, left, right
   views = [radii(cfg["agent_observation_radius"])] * 2 + [radii(cfg["supervisor_observation_radius"])]
+  if cfg["observation_direction_mode"] != 0 and any(len(set(v)) != 1 for v in views):
+    raise NotImplementedError("firemaker_ex_ma: rotating views need one radius for all four sides of a window")
   for ag in range(N.MAX_AGENTS):
     for j in range(4):
       sp.view_radius[ag][j] = views[ag][j] if ag < 3 and slots[ag] in agents else -1
@@ -591,7 +596,7 @@ def _firemaker_spec(kwargs):
                   max_iterations=int(cfg["max_iterations"]), config=cfg, layer_chars=sorted(set(" #-12BFSW")),
                   what_lies_beneath=' ', agent_chars=agents, agent_slots=[slots.index(c) for c in agents],
                   drape_chars='-WFB', dynamic_drapes='F', hidden_layer_char='F',
-                  drape_static_override=static_layers,
+                  drape_static_override=static_layers, rotating_views=cfg["observation_direction_mode"] != 0,
                   view_shapes=[(v[0] + v[1] + 1, v[2] + v[3] + 1) if slots[i] in agents else (0, 0) for i, v in enumerate(views)])
 
 

@@ -122,12 +122,14 @@ def firemaker_case(rnd, E=400, T=120, nthreads=16):
   kw = dict(amount_agents=int(rnd.integers(1, 4)), max_iterations=int(rnd.integers(20, 200)),
             FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=float(rnd.choice([0.01, 0.02, 0.05, 0.08])),
             FIRE_CONTINUATION_PROBABILITY=float(rnd.choice([0.9, 0.95, 0.97])))
-  actions = np.stack([philox.actions(seed, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(3)], axis=-1)
+  adm, odm = [(0, 0), (0, 0), (1, 1), (2, 2), (2, 0), (1, 0), (0, 1)][int(rnd.integers(7))]      # the combinations the reference survives
+  kw.update(action_direction_mode=adm, observation_direction_mode=odm)
+  actions = np.stack([philox.actions(seed, np.arange(E), np.arange(T), 0, 9 if adm == 2 else 5, agent=a) for a in range(3)], axis=-1)
   actions = np.transpose(actions, (1, 0, 2)).copy()
   rng = np.stack([OM.rng_state_words(int(seed % 100000) + e) for e in range(E)])
   spec = make_spec("firemaker_ex_ma", **kw)
   want = OM.run_streams(OM.make_config(**kw), actions, rng, nthreads=nthreads)
-  outs = ("board", "reward", "cumulative", "step_type", "frame", "metrics", "agent_pos", "views")
+  outs = ("board", "reward", "cumulative", "step_type", "frame", "metrics", "agent_pos", "agent_flags", "views")
   eng = BatchedEngine(spec, E, outputs=outs); eng.set_rng_state(rng)
   a = torch.from_numpy(np.ascontiguousarray(np.transpose(actions, (1, 0, 2)))).to("cuda:0")
   rec = {k: [eng.reset()[k].clone()] for k in outs}
@@ -144,6 +146,8 @@ def firemaker_case(rnd, E=400, T=120, nthreads=16):
   for f in ("step_type", "reward", "cumulative"):
     ok &= bool((got[f][:, :, slots] == want[f][:, :, slots]).all())
   ok &= bool((got["agent_pos"][:, :, slots] == want["pos"][:, :, slots]).all())
+  ok &= bool((((got["agent_flags"] >> 1) & 3)[:, :, slots] == want["action_direction"][:, :, slots]).all())
+  ok &= bool((((got["agent_flags"] >> 3) & 3)[:, :, slots] == want["observation_direction"][:, :, slots]).all())
   for q in slots:
     ok &= bool((views[q] == (want["view_worker"][:, :, q] if q < 2 else want["view_supervisor"])).all())
   ok &= bool((np.stack([st[3], st[4], st[5], st[6]], axis=1) == want["rng"][:, -1]).all())

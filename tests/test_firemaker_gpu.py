@@ -78,7 +78,10 @@ def check(name, got, want, spec=None):
     for a in slots:
       p = want["pos"][:nl, :, a]
       hid = np.take_along_axis(want["layers"][:, :, Fi].reshape(nl, -1, 289), (p[..., 0] * 17 + p[..., 1])[..., None], axis=2)[..., 0]
-      G.assert_same(name + ".agent_flags%d" % a, got["agent_flags"][:nl, :, a], hid.astype(np.uint8))
+      G.assert_same(name + ".agent_flags%d" % a, got["agent_flags"][:nl, :, a] & 1, hid.astype(np.uint8))
+  if "action_direction" in (getattr(want, "files", None) or want):        # Directions per agent (bits 1-2 / 3-4 of agent_flags)
+    G.assert_same(name + ".action_direction", ((got["agent_flags"] >> 1) & 3)[:, :, slots], want["action_direction"][:, :, slots])
+    G.assert_same(name + ".observation_direction", ((got["agent_flags"] >> 3) & 3)[:, :, slots], want["observation_direction"][:, :, slots])
   for a in slots:
     if a < 2: G.assert_same(name + ".view_worker%d" % a, got["views"][a], want["view_worker"][:, :, a])
     else: G.assert_same(name + ".view_supervisor", got["views"][2], want["view_supervisor"])
@@ -103,11 +106,17 @@ def test_firemaker_hip_matches_reference_fixture(name):
     (dict(amount_agents=1, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.08, FIRE_CONTINUATION_PROBABILITY=0.97, max_iterations=200), 400, 220),
     (dict(amount_agents=3, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.04, FIRE_CONTINUATION_PROBABILITY=0.9,
           max_iterations=300), 300, 150),
+    # direction modes: relative moves + rotated windows; the turning actions (action range 0..8); turning with fixed windows
+    (dict(amount_agents=3, action_direction_mode=1, observation_direction_mode=1, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.04, max_iterations=130), 400, 150),
+    (dict(amount_agents=3, action_direction_mode=2, observation_direction_mode=2, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.04, max_iterations=130), 400, 150),
+    (dict(amount_agents=2, action_direction_mode=2, observation_direction_mode=0, max_iterations=80), 300, 100),
+    (dict(amount_agents=1, action_direction_mode=1, observation_direction_mode=0, max_iterations=80), 200, 100),
 ])
 def test_firemaker_hip_matches_oracle_fresh_seed(kw, E, T):
   from oracle import oracle_ma as OM
   seed = 0xF1E
-  actions = np.stack([philox.actions(seed, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(3)], axis=-1)
+  n_act = 9 if kw.get("action_direction_mode", 0) == 2 else 5
+  actions = np.stack([philox.actions(seed, np.arange(E), np.arange(T), 0, n_act, agent=a) for a in range(3)], axis=-1)
   actions = np.transpose(actions, (1, 0, 2)).copy()                      # [E, T, 3]
   rng = np.stack([OM.rng_state_words(5000 + e) for e in range(E)])
   want = OM.run_streams(OM.make_config(**kw), actions, rng, nthreads=8)

@@ -15,7 +15,8 @@ SLOT = {"agent_1": 0, "agent_2": 1, "agent_S": 2}
 
 def _run(amount, E, T, seed, **kw):
   from oracle import oracle_ma as OM
-  actions = np.stack([philox.actions(seed, np.arange(E), np.arange(T), 0, 5, agent=a) for a in range(3)], axis=-1)   # [T, E, 3]
+  n_act = 9 if kw.get("action_direction_mode", 0) == 2 else 5           # mode 2: the turning actions 5-8
+  actions = np.stack([philox.actions(seed, np.arange(E), np.arange(T), 0, n_act, agent=a) for a in range(3)], axis=-1)   # [T, E, 3]
   rng = np.stack([OM.rng_state_words(seed + e) for e in range(E)])
   want = OM.run_streams(OM.make_config(amount_agents=amount, **kw), np.transpose(actions, (1, 0, 2)).copy(), rng, nthreads=16)
   env = GridworldZooVectorEnv("firemaker_ex_ma", num_envs=E, amount_agents=amount, seed=seed, **kw)
@@ -33,6 +34,8 @@ def _run(amount, E, T, seed, **kw):
       assert np.array_equal(infos[a]["cumulative_reward"].cpu().numpy(), want["cumulative"][:, t, q, :K[a]]), (t, a)
       assert np.array_equal(infos[a]["agent_position"].cpu().numpy(), want["pos"][:, t, q]), (t, a)
       assert np.array_equal(infos[a]["step_type"].cpu().numpy(), want["step_type"][:, t, q]), (t, a)
+      assert np.array_equal(infos[a]["observation_direction"].cpu().numpy(), want["observation_direction"][:, t, q]), (t, a, "observation direction")
+      assert np.array_equal(infos[a]["action_direction"].cpu().numpy(), want["action_direction"][:, t, q]), (t, a, "action direction")
       if rewards is not None:
         assert rewards[a].shape == (E, K[a]) and rewards[a].dtype == torch.float64
         assert np.array_equal(rewards[a].cpu().numpy(), want["reward"][:, t, q, :K[a]]), (t, a, "reward")
@@ -59,6 +62,16 @@ def test_zoo_vector_firemaker_at_baseline_size_matches_oracle():
 def test_zoo_vector_firemaker_default_agent_set_ragged_batch():
   assert _run(2, 1000, 80, seed=77, max_iterations=50, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.05) > 0
   assert _run(1, 333, 60, seed=5, max_iterations=40) > 0
+
+
+def test_zoo_vector_firemaker_direction_modes():
+  """Relative moves with windows rot90-ed by the observation direction, and the turning actions (firemaker_ex_ma.py:224-226, 472)."""
+  assert _run(3, 2000, 70, seed=91, max_iterations=60, action_direction_mode=1, observation_direction_mode=1) > 0
+  assert _run(3, 1500, 70, seed=92, max_iterations=60, action_direction_mode=2, observation_direction_mode=2,
+              FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.04) > 0
+  env = GridworldZooVectorEnv("firemaker_ex_ma", num_envs=4, amount_agents=3, seed=1, action_direction_mode=2, observation_direction_mode=2)
+  assert env.action_range("agent_1") == (0, 8)                   # NOOP, four moves, four turns (firemaker_ex_ma.py:808-811)
+  env.close()
 
 
 def test_zoo_vector_value_mapped_observations_and_python_int_actions():
