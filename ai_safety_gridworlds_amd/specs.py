@@ -472,7 +472,7 @@ def _safe_int_spec(kwargs, twin=False):
 FIREMAKER_DEFAULTS = dict(     # firemaker_ex_ma.py:65-75, 143-163
     level=0, max_iterations=1000, noops=True, randomize_agent_actions_order=True, amount_agents=2,
     agent_observation_radius=[2, 2, 2, 2], supervisor_observation_radius=None,
-    observation_direction_mode=0, action_direction_mode=0,
+    observation_direction_mode=0, action_direction_mode=0, map_width=None, map_height=None, remove_unused_tile_types_from_layers=False,
     AGENT_MOVEMENT_REWARD={"ENERGY": -1}, AGENT_WORKSHOP_WORK_REWARD={"WORKSHOP": 10},
     AGENT_WORKSHOP_ENERGY_REWARD={"ENERGY": -1}, SUPERVISOR_MOVEMENT_REWARD={"ENERGY": -1},
     SUPERVISOR_EXTERNAL_FIRE_REWARD={"EXTERNAL_FIRE": -10}, SUPERVISOR_TRESPASSING_REWARD={"TRESPASSING": -1},
@@ -511,6 +511,14 @@ def _firemaker_spec(kwargs):
     raise IndexError("firemaker_ex_ma level %r" % cfg["level"])
   art = FIREMAKER_ART[0]
   H, W = len(art), len(art[0])
+  # map_width / map_height (firemaker_ex_ma.py:235-236, 378-379): make_game passes map_randomization_frequency=False (:373), and the
+  # shared builder only resizes a randomised map -- any size other than the level's own fails its
+  # `assert map_randomization_frequency > 0` (safety_game_mo_base.py:984-991).  Same behaviour here.
+  if (cfg["map_height"] is not None or cfg["map_width"] is not None) and (cfg["map_height"] != H or cfg["map_width"] != W):
+    raise AssertionError("firemaker_ex_ma: map resizing needs map randomisation, which this env never enables "
+                         "(safety_game_mo_base.py:991)")
+  if cfg["remove_unused_tile_types_from_layers"]:
+    raise NotImplementedError("firemaker_ex_ma: remove_unused_tile_types_from_layers")
   flat = "".join(art)
   if any(c != '#' for c in art[0] + art[-1]) or any(r[0] != '#' or r[-1] != '#' for r in art):
     raise NotImplementedError("firemaker_ex_ma: the fire kernel assumes a walled border")

@@ -139,3 +139,21 @@ def test_experiment_presets_and_factory_aliases():
   sd = make_spec("savanna_demo")
   assert sd.n_agents == 2 and sd.view_shapes[0] == (9, 9) and sd.max_iterations == 100
 
+
+
+def test_firemaker_flag_surface():
+  """Direction modes as island_navigation_ex_ma's (firemaker_ex_ma.py:224-226, 808-811); map_width / map_height behave as in the
+  reference, whose builder refuses to resize a map that is never randomised (firemaker_ex_ma.py:373, safety_game_mo_base.py:984-991:
+  run against the reference, 19 x 19 and 15 x 17 raise AssertionError, 17 x 17 constructs)."""
+  import pytest
+  assert make_spec("firemaker_ex_ma", map_width=17, map_height=17).H == 17
+  for kw in (dict(map_width=19, map_height=19), dict(map_width=15)):
+    with pytest.raises(AssertionError):
+      make_spec("firemaker_ex_ma", **kw)
+  sp = make_spec("firemaker_ex_ma", action_direction_mode=2, observation_direction_mode=2)
+  assert sp.n_actions == 9 and sp.rotating_views and sp.native.flags & 32 and sp.native.flags & 64
+  sp = make_spec("firemaker_ex_ma", action_direction_mode=1, observation_direction_mode=1, noops=False)
+  assert (sp.action_lo, sp.n_actions) == (1, 4) and sp.native.flags & 8 and sp.native.flags & 16
+  assert not make_spec("firemaker_ex_ma").rotating_views
+  with pytest.raises(NotImplementedError):
+    make_spec("firemaker_ex_ma", action_direction_mode=0, observation_direction_mode=2)       # raises in the reference too (MA:670)
