@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsgw.so")
 
 MAX_CELLS, MAX_K, MAX_M, MAX_AGENTS, N_PARAMS, ENV_ALIGN = 320, 16, 32, 4, 72, 64
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ISLAND_NAVIGATION_EX, BOAT_RACE_EX, BOAT_RACE, SAFE_INTERRUPTIBILITY, FIREMAKER_EX_MA, ISLAND_NAVIGATION_EX_MA, TILE_EVENTS, SIDE_EFFECTS_SOKOBAN, CONVEYOR_BELT, TOMATO_WATERING, FRIEND_FOE, WHISKY_GOLD, ROCKS_DIAMONDS, AINTELOPE_SAVANNA = range(14)
 FIRST, MID, LAST, DEAD = 0, 1, 2, 3
@@ -40,7 +40,7 @@ class Spec(C.Structure):
 
 OUT_FIELDS = ("board", "obs_board", "reward", "cumulative", "step_type", "term_reason",
               "actual_action", "discount", "hidden", "safety", "metrics", "frame", "agent_pos", "agent_flags", "safety2",
-              "views", "obs_views")
+              "views", "obs_views", "done", "obs_dir", "act_dir")
 
 
 class Out(C.Structure):
@@ -54,7 +54,7 @@ class Extras(C.Structure):
               ("layer_static_dev", C.c_void_p), ("n_layers", C.c_int32), ("gap_index", C.c_int32), ("hidden_layer", C.c_int32),
               ("perf_from_hidden", C.c_int32), ("stats", C.c_void_p), ("k_agent", C.c_int32 * MAX_AGENTS),
               ("agent_layer_views", C.c_void_p), ("perf_last", C.c_void_p), ("perf_sum", C.c_void_p), ("perf_count", C.c_void_p),
-              ("done", C.c_void_p)]
+              ("done", C.c_void_p), ("replay", C.c_int32), ("reserved_", C.c_int32)]
 
 
 _lib = None

@@ -403,6 +403,10 @@ static int prepare_args(sgw_engine* e, KArgs& a) {
     return fail(SGW_ERR_ARG, "island_navigation_ex: spec.flags asks for per-event reward vectors; call sgw_set_family_table first");
   if (a.out.safety2 && e->spec.family != SGW_AINTELOPE_SAVANNA)
     return fail(SGW_ERR_UNSUPPORTED, "launch: the safety2 output exists for aintelope_savanna only");
+  if ((a.out.obs_dir || a.out.act_dir) && e->spec.family != SGW_ISLAND_NAVIGATION_EX_MA && e->spec.family != SGW_AINTELOPE_SAVANNA &&
+      e->spec.family != SGW_FIREMAKER_EX_MA)
+    return fail(SGW_ERR_UNSUPPORTED, "launch: the obs_dir / act_dir outputs exist for the families whose agents carry directions "
+                                     "(island_navigation_ex_ma, aintelope_savanna, firemaker_ex_ma)");
   a.sp = e->ks; a.tables = e->tables_dev; a.state = e->state_dev; a.ftable = e->ftable_dev;
   a.n_pad = e->n_pad; a.n_envs = e->n_envs; a.env_id_base = e->env_id_base;
   a.ep_bits = e->ep_bits; a.ep_bits_n = e->ep_bits_n; a.ep_seed = e->ep_seed;
@@ -507,6 +511,9 @@ static void offset_out(sgw_out& o, const sgw_spec& sp, long long n_pad, long lon
   if (o.frame) o.frame += r;
   if (o.agent_pos) o.agent_pos += r * A * 2;
   if (o.agent_flags) o.agent_flags += r * A;
+  if (o.done) o.done += r * A;
+  if (o.obs_dir) o.obs_dir += r * A;
+  if (o.act_dir) o.act_dir += r * A;
   const long long VB = kspec_view_total(sp);
   if (o.views) o.views += r * VB;
   if (o.obs_views) o.obs_views += r * VB;
@@ -1125,7 +1132,7 @@ int sgw_step_full(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, 
   const hipStream_t st = (hipStream_t)stream;
   sgw_extras key_x; memset(&key_x, 0, sizeof(key_x));
   if (x) key_x = *x;
-  if (step_graphs_min_T() > 8) return step_full_launches(e, actions_dev, out, x, stream);     // SGW_STEP_GRAPHS=0
+  if (!x || !x->replay || step_graphs_min_T() > 8) return step_full_launches(e, actions_dev, out, x, stream);     // (SGW_STEP_GRAPHS=0: never replay)
   sgw_engine::FullGraph* hit = nullptr;
   for (auto& g : e->full_graphs)
     if (g.actions == actions_dev && memcmp(&g.out, out, sizeof(sgw_out)) == 0 && memcmp(&g.ex, &key_x, sizeof(key_x)) == 0) { hit = &g; break; }

@@ -180,14 +180,16 @@ __host__ __device__ inline size_t lds_board_bytes(int HW) { return ((size_t)64 *
 enum { LN_REWARD = 1, LN_CUMULATIVE = 2, LN_METRICS = 4, LN_RETURNS = 8, LN_ST = 16, LN_TR = 32, LN_ACT = 64, LN_POS = 128,
        LN_FLG = 256, LN_DISC = 512, LN_HID = 1024, LN_SAF = 2048, LN_FRM = 4096, LN_BOARD = 8192, LN_OBS = 16384,
        LN_SAF2 = 32768,     // safety2: written straight from registers (emit_small_direct), no staging region
-       LN_VIEWS = 65536, LN_OBSVIEWS = 131072 };   // agent windows (u8 / value-mapped f32): one LDS image serves both
+       LN_VIEWS = 65536, LN_OBSVIEWS = 131072,     // agent windows (u8 / value-mapped f32): one LDS image serves both
+       LN_DONE = 262144, LN_ODIR = 524288, LN_ADIR = 1048576 };   // the wrappers' decodes: straight from registers (emit_decodes_direct)
 __host__ __device__ inline int lds_need(const KArgs& a, bool family_scratch_m) {
   const sgw_out& o = a.out;
   return (o.reward ? LN_REWARD : 0) | (o.cumulative ? LN_CUMULATIVE : 0) | ((o.metrics || family_scratch_m) ? LN_METRICS : 0) |
          (a.ep_acc ? LN_RETURNS : 0) | (o.step_type ? LN_ST : 0) | (o.term_reason ? LN_TR : 0) | (o.actual_action ? LN_ACT : 0) |
          (o.agent_pos ? LN_POS : 0) | (o.agent_flags ? LN_FLG : 0) | (o.discount ? LN_DISC : 0) | (o.hidden ? LN_HID : 0) |
          (o.safety ? LN_SAF : 0) | (o.frame ? LN_FRM : 0) | (o.board ? LN_BOARD : 0) | (o.obs_board ? LN_OBS : 0) |
-         (o.safety2 ? LN_SAF2 : 0) | (o.views ? LN_VIEWS : 0) | (o.obs_views ? LN_OBSVIEWS : 0);
+         (o.safety2 ? LN_SAF2 : 0) | (o.views ? LN_VIEWS : 0) | (o.obs_views ? LN_OBSVIEWS : 0) |
+         (o.done ? LN_DONE : 0) | (o.obs_dir ? LN_ODIR : 0) | (o.act_dir ? LN_ADIR : 0);
 }
 __host__ __device__ inline size_t lds_view_bytes(int vb, int need) { return (need & (LN_VIEWS | LN_OBSVIEWS)) ? ((size_t)64 * vb + 15) / 16 * 16 : 0; }
 __host__ __device__ inline size_t lds_rows(int A, int K, int M, int need, int which) {

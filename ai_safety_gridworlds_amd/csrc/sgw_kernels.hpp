@@ -245,6 +245,38 @@ __device__ inline void emit_small_direct(const typename F::State& s, double disc
   if (nd & LN_FRM) store_wt(o.frame + row, s.frame);
 }
 
+// sgw_out.done / obs_dir / act_dir: what the wrappers compute from step_type and agent_flags every step, written by the wave that
+// holds the state (one byte per lane and agent: a handful of narrow stores per wave, no staging).  The three pointers are read
+// from the kernarg segment HERE, through a pointer the compiler cannot see through, and only when asked for: as ordinary
+// members of the argument block they were six more SGPRs live across the rules of every step kernel (boat_race_ex: 2 -> 6 SGPR
+// spills, 7.07 -> 7.40 us per launch at the mixed suite's shard size) whether or not a launch wanted them.
+template <class F>
+__device__ inline void emit_decodes_direct(const typename F::State& s, const KArgs& a, long long env0, int lane, long long toff, bool active,
+                                           int kargs_off) {
+  const int nd = a.need;
+  if (!(nd & (LN_DONE | LN_ODIR | LN_ADIR)) || !active) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const sgw_out __attribute__((address_space(4))) * OutSeg;
+  OutSeg seg = (OutSeg)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kargs_off + (int)offsetof(KArgs, out));
+  asm volatile("" : "+s"(seg) : : "memory");
+  struct { uint8_t *done, *obs_dir, *act_dir; } o = {seg->done, seg->obs_dir, seg->act_dir};
+#else
+  const sgw_out& o = a.out;
+#endif
+  const long long row = toff + env0 + lane;
+#pragma unroll
+  for (int ag = 0; ag < F::NA; ++ag) {
+    int st;
+    if constexpr (F::PER_AGENT) st = F::agent_step_type(s, ag); else st = s.step_type;
+    if (nd & LN_DONE) store_wt(o.done + row * F::NA + ag, (uint8_t)(st >= ST_LAST ? 1 : 0));
+    if (nd & (LN_ODIR | LN_ADIR)) {
+      const int fl = F::agent_flags(s, ag);
+      if (nd & LN_ODIR) store_wt(o.obs_dir + row * F::NA + ag, (uint8_t)((fl >> 3) & 3));
+      if (nd & LN_ADIR) store_wt(o.act_dir + row * F::NA + ag, (uint8_t)((fl >> 1) & 3));
+    }
+  }
+}
+
 // workgroup barrier that orders LDS only: __syncthreads() also drains the wave's global stores (s_waitcnt vmcnt(0)),
 // which is exactly what the draining wave of the pipelined rollout must not wait for
 __device__ inline void lds_workgroup_barrier() {
@@ -727,6 +759,7 @@ __device__ __forceinline__ void engine_body(const KArgs& a, const long long bloc
       lds_wave_sync();
       emit_drain<F, false>(a, l, env0, lane, 0, a.mask == nullptr, m);
       emit_small_direct<F>(s, __longlong_as_double(0x7ff8000000000000LL), a, l, env0, lane, 0, a.mask == nullptr || m);
+      emit_decodes_direct<F>(s, a, env0, lane, 0, a.mask == nullptr || m, kargs_off);
     }
     return;
   }
@@ -856,7 +889,10 @@ __device__ __forceinline__ void engine_body(const KArgs& a, const long long bloc
         }
         if constexpr (PIPE) { if (lane == 0) le.flag[0] = acc_any ? 1u : 0u; }
       }
-      if (writes) emit_stage<F, PIPE, !has_board_part<F>::value>(s, r, discount, ae, le, lane);
+      if (writes) {
+        emit_stage<F, PIPE, !has_board_part<F>::value>(s, r, discount, ae, le, lane);
+        emit_decodes_direct<F>(s, ae, env0, lane, ae.write_every != 0 ? (long long)t * ae.n_pad : 0, true, kargs_off);
+      }
     }
     if constexpr (has_board_part<F>::value) {
       // cooperative family: the WORKGROUP produces the step's big outputs -- every wave writes a slice of the board rows, then

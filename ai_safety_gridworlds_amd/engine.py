@@ -19,7 +19,7 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda id
 
 DEFAULT_OUTPUTS = ("board", "reward", "step_type", "term_reason")
 # every family's outputs; "safety2": aintelope_savanna only; "views" / "obs_views": the families with agent windows
-ALL_OUTPUTS = tuple(f for f in N.OUT_FIELDS if f not in ("safety2", "views", "obs_views"))
+ALL_OUTPUTS = tuple(f for f in N.OUT_FIELDS if f not in ("safety2", "views", "obs_views", "obs_dir", "act_dir"))   # (family-specific outputs are asked for by name)
 
 
 # families whose step launch can write the agent windows itself (sgw_out.views / obs_views)
@@ -46,6 +46,7 @@ def _dtype_shape(spec, name):
       "metrics": (torch.float64, (M,)), "frame": (torch.int32, ()), "agent_pos": (torch.uint8, (A * 2,)),
       "agent_flags": (torch.uint8, (A,)), "safety2": (torch.int32, per_agent),
       "views": (torch.uint8, (_view_bytes(spec),)), "obs_views": (torch.float32, (_view_bytes(spec),)),
+      "done": (torch.uint8, (A,)), "obs_dir": (torch.uint8, (A,)), "act_dir": (torch.uint8, (A,)),
   }[name]
 
 
@@ -155,9 +156,10 @@ class BatchedEngine(object):
       return ks
     return [sp.K]
 
-  def step_full(self, actions, rgb=False, layers=False, stats=False, agent_layer_views=False, performance=False):
+  def step_full(self, actions, rgb=False, layers=False, stats=False, agent_layer_views=False, performance=False, replay=False):
     """One env.step() per env AND the derived observations of that step from ONE library call (sgw_step_full: the launches are
-    chained in C and replayed as one hipGraph from the third call on): dict of the engine's outputs plus "RGB" uint8
+    chained in C; `replay`: captured and replayed as one hipGraph from the third call on -- ~5 us of host time per step instead
+    of ~25, at ~5 us more GPU time per step): dict of the engine's outputs plus "RGB" uint8
     [N, 3, H, W], "layers" uint8 [N, L, H, W] (unoccluded, gap-corrected), the derived statistics (gini_index, ...,
     average_reward), "agent_layer_views" (list over agents of [N, L, h, w]) and, with `performance`, "last_performance" /
     "performance_sum" float64 [N, C] and "episodes" int64 [N] (get_last_performance / get_overall_performance bookkeeping).
@@ -170,11 +172,12 @@ class BatchedEngine(object):
     if actions.numel() != self.n_envs * sp.A:
       raise RuntimeError("A pycolab Environment adapter's step method was called with actions that were "
                          "not compatible with what the pycolab game expects.")
-    key = (bool(rgb), bool(layers or agent_layer_views), bool(stats), bool(agent_layer_views), bool(performance))
+    key = (bool(rgb), bool(layers or agent_layer_views), bool(stats), bool(agent_layer_views), bool(performance), bool(replay))
     fx = getattr(self, "_full", None)
     if fx is None or fx["key"] != key or fx["for"] is not self._bufs.get("step_type", self._bufs.get("board")):
       n, dev = self.n_envs, self.device
       x, t, res = N.Extras(), {}, {}
+      x.replay = 1 if replay else 0
       if key[0]:
         t["lut"] = torch.from_numpy(sp.rgb_lut().reshape(-1)).to(dev)
         res["RGB"] = torch.empty((n, 3, sp.H, sp.W), dtype=torch.uint8, device=dev)

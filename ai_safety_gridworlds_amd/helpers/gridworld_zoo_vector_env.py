@@ -30,7 +30,7 @@ from ..engine import fused_views
 from ..environments import BatchedSafetyEnvironment
 from ..specs import make_spec
 
-OUTS = ("board", "reward", "cumulative", "step_type", "term_reason", "discount", "metrics", "agent_pos", "agent_flags")
+OUTS = ("board", "reward", "cumulative", "step_type", "term_reason", "discount", "metrics", "agent_pos", "agent_flags", "done")
 
 
 class GridworldZooVectorEnv(object):
@@ -40,7 +40,10 @@ class GridworldZooVectorEnv(object):
                env_id_base=0, **kwargs):
     self._fused = fused_views(make_spec(env_name, **kwargs))
     self._ascii = bool(ascii_observation_format)
-    outs = OUTS + ((("views",) if self._ascii else ("obs_views",)) if self._fused else ())
+    cfg0 = getattr(make_spec(env_name, **kwargs), "config", None) or {}
+    self._turning = bool(cfg0.get("action_direction_mode", 0) or cfg0.get("observation_direction_mode", 0))
+    # `terminated` and the decoded directions leave with the step launch (sgw_out.done / obs_dir / act_dir): no torch launch per step
+    outs = OUTS + (("obs_dir", "act_dir") if self._turning else ()) + ((("views",) if self._ascii else ("obs_views",)) if self._fused else ())
     self._env = BatchedSafetyEnvironment(env_name, num_envs=num_envs, device=device, env_id_base=env_id_base, outputs=outs,
                                          track_performance=False, **kwargs)
     sp = self.spec_ = self._env.spec
@@ -58,8 +61,6 @@ class GridworldZooVectorEnv(object):
     self._vm = torch.tensor([sp.native.value_map[i] for i in range(128)], dtype=torch.float32, device=self.device)
     self._acts = torch.zeros((self.num_envs, sp.A), dtype=torch.int8, device=self.device)
     self._never = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)            # truncated: always False
-    cfg = getattr(sp, "config", None) or {}
-    self._turning = bool(cfg.get("action_direction_mode", 0) or cfg.get("observation_direction_mode", 0))
     self._up = torch.full((self.num_envs,), 2, dtype=torch.uint8, device=self.device)         # Directions.UP: the fixed-direction envs
     if sp.family == N.FIREMAKER_EX_MA or getattr(sp, "needs_rng", False):
       # env i draws from Generator(PCG64(SeedSequence(seed + global id))): what seeding.np_random gives N separately seeded envs
@@ -81,9 +82,9 @@ class GridworldZooVectorEnv(object):
 
   def _pack(self, o):
     """A step from Python is host-bound (every torch op is a launch, every view a microsecond).  The step's outputs live in
-    persistent buffers, so the per-agent dicts of views are built ONCE; a step then only refreshes what is computed from them:
-    the agent windows (one launch into a reused buffer) and the done flags (one comparison; two shifts more when the env has
-    moving directions).  The returned tensors are valid until the next step / reset, like the engine's outputs."""
+    persistent buffers -- the `terminated` flags and the decoded directions among them (sgw_out.done / obs_dir / act_dir) -- so the
+    per-agent dicts of views are built ONCE; a step then only refreshes the agent windows where the step launch does not write them
+    (one launch into a reused buffer).  The returned tensors are valid until the next step / reset, like the engine's outputs."""
     sp = self.spec_
     n = self.num_envs
     eng = self._env.engine
@@ -96,13 +97,12 @@ class GridworldZooVectorEnv(object):
         self._view_buf = torch.empty((n, vb), dtype=torch.uint8, device=self.device)
         views = eng.agent_views(out=self._view_buf)
       st = o["step_type"].reshape(n, -1)
-      self._st = st
-      self._done = torch.empty_like(st, dtype=torch.bool)
+      self._done = o["done"].reshape(n, -1).view(torch.bool)
       rew = o["reward"].reshape(n, sp.A, sp.K)
       cum = o["cumulative"].reshape(n, sp.A, sp.K)
       pos = o["agent_pos"].reshape(n, sp.A, 2)
-      self._flags = o["agent_flags"].reshape(n, sp.A)
-      self._odir = torch.empty_like(self._flags); self._adir = torch.empty_like(self._flags)
+      if self._turning:
+        self._odir, self._adir = o["obs_dir"].reshape(n, sp.A), o["act_dir"].reshape(n, sp.A)
       metrics = o["metrics"][:, :sp.M]
       obs, rewards, terms, truncs, infos = {}, {}, {}, {}, {}
       for i, a in enumerate(self.possible_agents):
@@ -119,10 +119,6 @@ class GridworldZooVectorEnv(object):
       self._cached = (obs, rewards, terms, truncs, infos)
     elif not self._fused:
       eng.agent_views(out=self._view_buf)
-    torch.ge(self._st, N.LAST, out=self._done)
-    if self._turning:
-      torch.bitwise_right_shift(self._flags, 3, out=self._odir).bitwise_and_(3)
-      torch.bitwise_right_shift(self._flags, 1, out=self._adir).bitwise_and_(3)
     obs, rewards, terms, truncs, infos = self._cached
     obs, infos = dict(obs), {a: dict(d) for a, d in infos.items()}
     if not self._ascii and not self._fused:

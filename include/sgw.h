@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SGW_ABI_VERSION 7
+#define SGW_ABI_VERSION 8
 #define SGW_MAX_CELLS 320      /* >= 17*17 */
 #define SGW_MAX_K 16           /* reward dimensions per agent */
 #define SGW_MAX_M 32           /* metrics per env */
@@ -122,6 +122,15 @@ typedef struct sgw_out {
                           *               (firemaker_ex_ma, island_navigation_ex_ma, aintelope_savanna), SGW_ERR_UNSUPPORTED elsewhere */
   float* obs_views;      /* [N_pad, view_bytes] the same windows value-mapped to float32 (ascii_observation_format=False:
                           *               the window of observation['board'], observation_distiller_ex.py:147-187) */
+  /* The wrappers' per-step decodes of the outputs above, written by the same launch so that a Python step does not launch a
+   * torch kernel per derived tensor (a step from Python is host-bound; every extra launch is ~5 us of host and ~2.5 us of GPU time): */
+  uint8_t* done;         /* [N_pad, A]    1 where the (agent's) step_type is LAST or later: the `terminated` of the Gym / Zoo wrappers
+                          *               (gridworld_gym_env.py:563-578, gridworld_zoo_parallel_env.py:589-600) */
+  uint8_t* obs_dir;      /* [N_pad, A]    the agent's observation direction (bits 3-4 of agent_flags; Directions LEFT=0 RIGHT=1 UP=2
+                          *               DOWN=3): the wrappers' INFO_OBSERVATION_DIRECTION (gridworld_zoo_parallel_env.py:325-335).
+                          *               Meaningful for the families that carry directions (island_navigation_ex_ma,
+                          *               aintelope_savanna, firemaker_ex_ma); 0 elsewhere */
+  uint8_t* act_dir;      /* [N_pad, A]    the agent's action direction (bits 1-2 of agent_flags): INFO_ACTION_DIRECTION */
 } sgw_out;
 
 typedef struct sgw_engine sgw_engine;
@@ -286,9 +295,10 @@ int sgw_track_performance(sgw_engine* e, const double* perf_dev, int n_cols, con
 /* Everything env.step() returns from ONE host call: sgw_step, then -- on the same stream, chained in C -- whatever of the
  * observation distiller's and _process_timestep's derived outputs `extras` asks for, computed from that step's outputs:
  * RGB (sgw_observe), unoccluded layers (sgw_observe_layers; aintelope_savanna: sgw_state_layers), derived statistics
- * (sgw_derived_stats), per-agent layer cubes (sgw_agent_layer_views), performance bookkeeping (sgw_track_performance).  The second
- * call with the same (actions_dev, out, extras) pointers captures the launches into a hipGraph and replays it from then on (one
- * graph launch per step instead of up to six kernel launches; refill the action buffer in place).  `out` must carry what the
+ * (sgw_derived_stats), per-agent layer cubes (sgw_agent_layer_views), performance bookkeeping (sgw_track_performance).  With
+ * extras->replay != 0 the second call with the same (actions_dev, out, extras) pointers captures the launches into a hipGraph and
+ * replays it from then on (one graph launch per step instead of up to six kernel launches; refill the action buffer in place);
+ * replay == 0 issues the launches directly, which is the faster end to end while the host keeps up.  `out` must carry what the
  * requested extras read: board (rgb, layers), agent_pos + agent_flags (hidden drape, layer cubes), reward + cumulative + frame
  * (stats), cumulative or hidden + step_type (performance).  Reference: gridworld_gym_env.py:455-585, safety_game_mo.py:971-1107,
  * observation_distiller_ex.py:147-187. */
@@ -306,6 +316,12 @@ typedef struct sgw_extras {
   double* perf_sum;
   int64_t* perf_count;
   uint8_t* done;
+  int32_t replay;                     /* 0: the launches are issued one by one (lowest end-to-end time per step: 38.7 us for the full
+                                       * island_navigation_ex set at 65 536 envs, ~25 us of host time); != 0: the chain is captured
+                                       * on the second identical call and replayed as ONE hipGraph from the third on (~5 us of host
+                                       * time per step for a consumer whose host thread is the bottleneck, at ~5 us more GPU time
+                                       * per step: 44.3 us) */
+  int32_t reserved_;
 } sgw_extras;
 int sgw_step_full(sgw_engine* e, const int8_t* actions_dev, const sgw_out* out, const sgw_extras* extras, void* stream);
 
