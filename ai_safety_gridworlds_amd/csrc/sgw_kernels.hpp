@@ -422,23 +422,25 @@ __device__ inline void views_stage_lane_per_env(const typename F::State& s, cons
     if (len == 0) continue;
     int prow, pcol, dir = 2;
     F::agent_pos(s, ag, prow, pcol);
-    if constexpr (has_view_dir<F>::value) dir = F::view_dir(s, ag);
+    if constexpr (has_view_dir<F>::value) dir = sp.view_rotates ? F::view_dir(s, ag) : 2;
     const int pr = prow - (int)sp.view_up[ag], pc = pcol - (int)sp.view_left[ag], n1 = vw - 1;
     uint8_t* dst = row + sp.view_off[ag];
-    const bool rot = sp.view_rotates != 0;                    // scalar: the env has observation directions at all
+    // Board cell of output cell (vr, vc), rot90 by the lane's direction (view_unrotate): LINEAR in the scalar window coordinates,
+    //   r = r0 + vr * drr + vc * drv,  c = c0 + vr * dcr + vc * dcv
+    // with per-lane constants worked out once per agent -- a cell then costs three multiply-adds, the bounds test and the two LDS
+    // accesses (a lone wave per SIMD issues a dependent VALU instruction every ~8 cycles: the select chains of the first version,
+    // ~25 instructions per cell, made 50 window bytes cost 11 of island_navigation_ex_ma's 28.6 us)
+    const int r0 = pr + ((dir == 3 || dir == 0) ? n1 : 0), c0 = pc + ((dir == 3 || dir == 1) ? n1 : 0);
+    const int drv = dir == 0 ? -1 : (dir == 1 ? 1 : 0), dcv = dir == 2 ? 1 : (dir == 3 ? -1 : 0);
+    const int drr = dir == 2 ? 1 : (dir == 3 ? -1 : 0), dcr = dir == 0 ? 1 : (dir == 1 ? -1 : 0);
     int vr = 0, vc = 0;                                       // scalar window coordinates of cell k
     constexpr int NB = 8;                                     // cells per batch: eight independent LDS reads in flight, then the eight writes
     for (int k = 0; k < len; k += NB) {
       uint32_t got[NB]; bool inside[NB];
 #pragma unroll
       for (int h = 0; h < NB; ++h) {
-        int cr = vr, cc = vc;                                 // crop coordinates of output cell (vr, vc): view_unrotate per lane
-        if (rot) {
-          cr = dir == 2 ? vr : (dir == 3 ? n1 - vr : (dir == 0 ? n1 - vc : vc));
-          cc = dir == 2 ? vc : (dir == 3 ? n1 - vc : (dir == 0 ? vr : n1 - vr));
-        }
-        const int r = cr + pr, c = cc + pc;
-        inside[h] = r >= 0 && r < H && c >= 0 && c < W;
+        const int r = r0 + vr * drr + vc * drv, c = c0 + vr * dcr + vc * dcv;
+        inside[h] = (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W;
         got[h] = src[inside[h] ? r * W + c : 0];
         if (++vc == vw) { vc = 0; ++vr; }                     // (past the window's end the coordinates run on harmlessly: reads are clamped)
       }

@@ -424,8 +424,9 @@ def main():
     engv.close()
 
   # everything env.step() returns: the step with every output + RGB + unoccluded layers + derived
-  # statistics + performance bookkeeping, ONE sgw_step_full call per step (its launches replayed as one hipGraph), actions
-  # refilled in place in a persistent buffer as an RL loop does
+  # statistics + performance bookkeeping, ONE sgw_step_full call per step (its launches issued directly: replaying them as one
+  # hipGraph, sgw_extras.replay, costs ~5 us of host time per step instead of ~25 but ~5 us more GPU time -- 44 instead of 39 us),
+  # actions refilled in place in a persistent buffer as an RL loop does
   full_obs = None
   if a.workload != "mixed" and world == 1 and engines[0]["spec"].A == 1:
     from ai_safety_gridworlds_amd.helpers.gridworld_gym_env import GridworldVectorEnv
@@ -454,7 +455,8 @@ def main():
                 "host_us_per_call": fhost / nf * 1e6, "steps": nf,
                 "outputs_bytes_per_env_step": int(HWc * (1 + 4 + 3 + (Lc if kw["layers"] else 0)) + sp.K * 8 * 3 + (5 + sp.K) * 8 + max(sp.M, 0) * 8 + 40),
                 "note": "sgw_step_full: step kernel (board, float board, reward, cumulative, metrics, ...) + RGB + unoccluded layers + "
-                        "gini / variances / average reward + per-env performance bookkeeping, one library call per step"}
+                        "gini / variances / average reward + per-env performance bookkeeping, one library call per step "
+                        "(launches issued directly; sgw_extras.replay = one hipGraph per step: less host, more GPU time)"}
     engf.close()
 
   if rank == 0:
