@@ -996,12 +996,14 @@ int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agen
   {
     // one wave per env: the board and the env's row of windows in LDS, the row out as dword stores at its byte address (the layer-cube
     // kernel with one plane; round 2's k_agent_views -- a wave per window, cells loaded from global memory -- took 26 us for 16 384 envs)
-    const int lay_bytes = (e->ks.HW + 15) / 16 * 16;
-    const size_t lds = (size_t)lay_bytes + ((size_t)v.total + 15) / 16 * 16;
+    const int lay_bytes = (e->ks.HW + 15) / 16 * 16, img_bytes = (v.total + 15) / 16 * 16 + 16;      // (+ 16: the image sits at its row's 16-byte phase)
+    constexpr int G = 4;      // envs a one-wave workgroup takes per pass (k_agent_layer_views_lds; G = 2 for 16 384 envs measured 18.9 vs 17.8 us)
+    const size_t lds = 128 + 16 * G + (size_t)G * ((size_t)lay_bytes + (size_t)img_bytes);       // table | per-env words | G x (planes | image)
     if (lds <= 64 * 1024) {
-      const int blocks = (int)(e->n_envs < 16384 ? e->n_envs : 16384);
-      hipLaunchKernelGGL(k_agent_layer_views_lds, dim3(blocks), dim3(WAVE), lds, (hipStream_t)stream, board_dev, agent_pos_dev, agent_flags_dev,
-                         (long long)e->n_envs, v, (const uint8_t*)nullptr, 1, outside_chr, views_dev, lay_bytes, 1);
+      const long long groups = (e->n_envs + G - 1) / G;
+      const int blocks = (int)(groups < 8192 ? groups : 8192);           // (256 CUs x 32 one-wave workgroups: each walks its groups)
+      hipLaunchKernelGGL(k_agent_layer_views_lds<G>, dim3(blocks), dim3(WAVE), lds, (hipStream_t)stream, board_dev, agent_pos_dev, agent_flags_dev,
+                         (long long)e->n_envs, v, (const uint8_t*)nullptr, 1, outside_chr, views_dev, lay_bytes, img_bytes, 1);
       HIP_TRY(hipGetLastError());
       return SGW_OK;
     }
@@ -1032,12 +1034,12 @@ int sgw_agent_layer_views(sgw_engine* e, const uint8_t* layers_dev, const uint8_
     return SGW_OK;
   }
   // a workgroup per env: the env's layer planes and its whole output row in LDS (k_agent_layer_views_lds)
-  const int lay_bytes = (n_layers * e->ks.HW + 15) / 16 * 16;
-  const size_t lds = (size_t)lay_bytes + ((size_t)v.total * n_layers + 15) / 16 * 16;
+  const int lay_bytes = (n_layers * e->ks.HW + 15) / 16 * 16, img_bytes = (v.total * n_layers + 15) / 16 * 16 + 16;
+  const size_t lds = 128 + 16 + (size_t)lay_bytes + (size_t)img_bytes;
   if (lds <= 64 * 1024) {
     const int blocks = (int)(e->n_envs < 4096 ? e->n_envs : 4096);
-    hipLaunchKernelGGL(k_agent_layer_views_lds, dim3(blocks), dim3(256), lds, (hipStream_t)stream, layers_dev, agent_pos_dev, agent_flags_dev,
-                       (long long)e->n_envs, v, layer_chars_dev, n_layers, outside_chr, out_dev, lay_bytes, 0);
+    hipLaunchKernelGGL(k_agent_layer_views_lds<1>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, layers_dev, agent_pos_dev, agent_flags_dev,
+                       (long long)e->n_envs, v, layer_chars_dev, n_layers, outside_chr, out_dev, lay_bytes, img_bytes, 0);
     HIP_TRY(hipGetLastError());
     return SGW_OK;
   }

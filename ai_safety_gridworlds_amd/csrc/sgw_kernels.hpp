@@ -1562,97 +1562,174 @@ __global__ void k_agent_layer_views_small(const uint8_t* layers, const uint8_t* 
   }
 }
 
-// per-layer agent windows, windows larger than 64 cells (firemaker's 33 x 33, savanna's 21 x 21): a WORKGROUP per env.  The env's L
-// layer planes come into LDS once, each of the A x L windows is assembled in an LDS image of the env's whole output row by one wave
-// (a window larger than the plane: pad fill, then the plane's cells dropped where they land; else a gather), and the row leaves
-// as dword stores at its byte address (rows of L * view_bytes bytes are not aligned to anything).  Round 2's kernel below -- one
-// wave per window, every cell a byte load from global memory -- took 208 us for 16 384 firemaker envs (0.13 of HBM).
+// per-layer agent windows, windows larger than 64 cells (firemaker's 33 x 33, savanna's 21 x 21): a WORKGROUP takes G envs at a
+// time.  Their L layer planes come into LDS, each of the A x L windows of an env is assembled in an LDS image of the env's whole
+// output row by one wave (a window larger than the plane: pad fill, then the plane's cells dropped where they land; else a
+// gather), and the rows leave as dword stores at their byte address (rows of L * view_bytes bytes are not aligned to anything).
+// Why G envs at once: an env is a chain of dependent waits -- planes and positions from global memory, the LDS passes, and the
+// next env's loads queue behind this env's stores (vmcnt counts both) -- about 8 us per env whatever its size; with one env per
+// wave (the L = 1 form: sgw_agent_views) a CU had 32 such chains in flight and 16 384 firemaker envs took 17.5 us, 65 536
+// savanna envs 60 us.  G envs share every wait of the chain.  Round 2's kernel below -- one wave per window, every cell a byte
+// load from global memory -- took 208 us for 16 384 firemaker envs' layer cubes (0.13 of HBM).
+template <int G>
 __global__ __launch_bounds__(256) void k_agent_layer_views_lds(const uint8_t* layers, const uint8_t* pos, const uint8_t* flags, long long n, ViewSpec v,
-                                                               const uint8_t* chars, int L, uint8_t outside, uint8_t* out, int lay_bytes, int pad_is_char) {
+                                                               const uint8_t* chars, int L, uint8_t outside, uint8_t* out, int lay_bytes, int img_bytes,
+                                                               int pad_is_char) {
   // pad_is_char: the planes are ascii boards (L = 1: sgw_agent_views) and cells outside the board read `outside` itself; otherwise
   // they are layer planes and read 1 on the outside character's own layer (agent_perspectives_with_layers)
+  // LDS: [ per-agent table: off, up, left, vh, vw x 4 | per-env words of the group: row | col << 8 | flags << 16, x G x 4 |
+  //        G x ( [L][H*W] planes | the env's output row [agent][layer][vh][vw] at its 16-byte phase ) ]
+  // What a loop indexes at run time (the agent's window, the env's position) is READ from LDS: as members of the kernel
+  // argument / as register arrays they became select chains over every agent and env -- 2 200 scalar and 420 spill
+  // instructions, 400 branches in the first G-env version, and the kernel was bound by exactly that (75 us for savanna's
+  // 65 536 envs, 26 of them with loads, assembly and stores all switched off).
   extern __shared__ __attribute__((aligned(16))) uint8_t view_lds[];
-  uint8_t* lay = view_lds;                                   // [L][H*W]
-  uint8_t* img = view_lds + lay_bytes;                       // the env's output row: [agent][layer][vh][vw]
-  const int HW = v.H * v.W, lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  int* tab = reinterpret_cast<int*>(view_lds);
+  uint32_t* ppos = reinterpret_cast<uint32_t*>(view_lds + 128);
+  uint8_t* envs = view_lds + 128 + 16 * G;
+  const int env_lds = lay_bytes + img_bytes;
+  const int HW = v.H * v.W, H = v.H, W = v.W, A = v.A, lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   const int row_bytes = v.total * L;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < SGW_MAX_AGENTS; ++k) { tab[k] = v.off[k] * L; tab[4 + k] = v.up[k]; tab[8 + k] = v.left[k]; tab[12 + k] = v.vh[k]; tab[16 + k] = v.vw[k]; }
+  }
   // lane constants, once per kernel (no division inside the env loop): the plane cells this lane drops into a large window
-  // (cell k = lane + 64 j: row, column) and, per agent, the window cells it gathers for a small one
+  // (cell k = lane + 64 j: row, column)
   constexpr int NP = (SGW_MAX_CELLS + WAVE - 1) / WAVE;
   int prr[NP], pcc[NP];
 #pragma unroll
-  for (int j = 0; j < NP; ++j) { const int k = lane + WAVE * j; prr[j] = k / v.W; pcc[j] = k - prr[j] * v.W; }
+  for (int j = 0; j < NP; ++j) { const int k = lane + WAVE * j; prr[j] = k / W; pcc[j] = k - prr[j] * W; }
   const int npass = (HW + WAVE - 1) / WAVE;
-  for (long long e = blockIdx.x; e < n; e += gridDim.x) {
-    const uint8_t* src = layers + e * (long long)(L * HW);
-    for (int i = threadIdx.x; i < L * HW; i += blockDim.x) lay[i] = src[i];
-    __syncthreads();
-    for (int ag = 0; ag < v.A; ++ag) {                         // scalar loops: agent, then this wave's layers
-      const int vh = v.vh[ag], vw = v.vw[ag], cells = vh * vw;
-      if (cells == 0) continue;
-      const long long ea = e * v.A + ag;
-      const int pr = (int)pos[ea * 2] - v.up[ag], pc = (int)pos[ea * 2 + 1] - v.left[ag];
-      const int dir = flags ? (flags[ea] >> 3) & 3 : 2;
-      if (cells > HW) {
-        // landing offset of plane cell (r, c): +-(r * n + c) or +-(c * n - r) plus an env scalar (see views_stage_wave_per_env)
-        const int n1 = vw - 1;
-        const int base = dir == 2 ? -(pr * vw + pc) : (dir == 3 ? (n1 + pr) * vw + n1 + pc : (dir == 0 ? n1 + pr - pc * vw : (n1 + pc) * vw - pr));
-        const bool useQ = dir < 2, neg = dir == 3 || dir == 1;
-        const bool covers = v.up[ag] >= v.H - 1 && vh - 1 - v.up[ag] >= v.H - 1 && v.left[ag] >= v.W - 1 && vw - 1 - v.left[ag] >= v.W - 1;
-        int at[NP]; bool ok[NP];
+  constexpr int PF = G > 1 ? 5 : 12;                        // plane bytes per thread held in registers between the load and the LDS write
+  const int nbytes = L * HW;
+  const bool in_regs = nbytes <= PF * (int)blockDim.x;
+  for (long long e0 = (long long)blockIdx.x * G; e0 < n; e0 += (long long)gridDim.x * G) {
+    // ---- every load of the G envs first: planes (into registers), positions and flags (a lane per (env, agent))
+    uint32_t pl[G][PF];
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-          const int t = useQ ? pcc[j] * vw - prr[j] : prr[j] * vw + pcc[j];
-          at[j] = (neg ? -t : t) + base;
-          ok[j] = j < npass && lane + WAVE * j < HW;
-          if (!covers) { const int cr = prr[j] - pr, c2 = pcc[j] - pc; ok[j] = ok[j] && cr >= 0 && cr < vh && c2 >= 0 && c2 < vw; }
+    for (int g = 0; g < G; ++g) {
+      const long long e = e0 + g < n ? e0 + g : n - 1;       // (a ragged last group re-reads the last env; nothing of it is stored)
+      const uint8_t* src = layers + e * (long long)nbytes;
+      if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+          const int idx = (int)threadIdx.x + j * (int)blockDim.x;
+          pl[g][j] = idx < nbytes ? src[idx] : 0u;
         }
-        for (int l = wave; l < L; l += nwave) {
-          const uint32_t pad = pad_is_char ? 0x01010101u * outside : (chars[l] == outside ? 0x01010101u : 0u);
-          const uint8_t* pl = lay + l * HW;
-          uint8_t* dst = img + v.off[ag] * L + l * cells;
-          // pad fill: bytes up to the first dword boundary, dwords, tail bytes (dst is byte-aligned only)
-          const int head = (int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3), nh = head < cells ? head : cells;
-          if (lane < nh) dst[lane] = (uint8_t)pad;
-          uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + nh);
-          const int nd = (cells - nh) >> 2;
-          for (int k = lane; k < nd; k += WAVE) d4[k] = pad;
-          const int done = nh + 4 * nd;
-          if (lane < cells - done) dst[done + lane] = (uint8_t)pad;
-          lds_wave_sync();
-          uint8_t val[NP];
+      }
+    }
+    if ((int)threadIdx.x < 4 * G) {
+      const int g = threadIdx.x >> 2, ag = threadIdx.x & 3;
+      const long long e = e0 + g < n ? e0 + g : n - 1;
+      uint32_t w = 16u << 16;                                  // (no flags: observation direction UP)
+      if (ag < A) {
+        const long long ea = e * A + ag;
+        w = (uint32_t)*reinterpret_cast<const uint16_t*>(pos + ea * 2) | ((flags ? (uint32_t)flags[ea] : 16u) << 16);
+      }
+      ppos[threadIdx.x] = w;
+    }
 #pragma unroll
-          for (int j = 0; j < NP; ++j) val[j] = pl[ok[j] ? lane + WAVE * j : 0];
+    for (int g = 0; g < G; ++g) {
+      uint8_t* lay = envs + g * env_lds;
+      if (in_regs) {
 #pragma unroll
-          for (int j = 0; j < NP; ++j) if (ok[j]) dst[at[j]] = val[j];
+        for (int j = 0; j < PF; ++j) {
+          const int idx = (int)threadIdx.x + j * (int)blockDim.x;
+          if (idx < nbytes) lay[idx] = (uint8_t)pl[g][j];
         }
       } else {
-        for (int l = wave; l < L; l += nwave) {
-          const uint8_t pad = pad_is_char ? outside : (uint8_t)(chars[l] == outside);
-          const uint8_t* pl = lay + l * HW;
-          uint8_t* dst = img + v.off[ag] * L + l * cells;
-          for (int k = lane; k < cells; k += WAVE) {
-            int vr = k / vw, vc = k - vr * vw;
-            view_unrotate(dir, vw, vr, vc);
-            const int r = vr + pr, c = vc + pc;
-            dst[k] = (r >= 0 && r < v.H && c >= 0 && c < v.W) ? pl[r * v.W + c] : pad;
+        const long long e = e0 + g < n ? e0 + g : n - 1;
+        const uint8_t* src = layers + e * (long long)nbytes;
+        for (int i = threadIdx.x; i < nbytes; i += blockDim.x) lay[i] = src[i];
+      }
+    }
+    __syncthreads();
+    // ---- the windows of the G envs into their LDS images: agent by agent, so that what only depends on the agent's window
+    // (the landing constants of the plane cells) is worked out once for the G envs
+    for (int ag = 0; ag < A; ++ag) {                           // scalar loops: agent, env of the group, then this wave's layers
+      const int vh = __builtin_amdgcn_readfirstlane(tab[12 + ag]), vw = __builtin_amdgcn_readfirstlane(tab[16 + ag]), cells = vh * vw;
+      if (cells == 0) continue;
+      const int up = __builtin_amdgcn_readfirstlane(tab[4 + ag]), left = __builtin_amdgcn_readfirstlane(tab[8 + ag]);
+      const int off = __builtin_amdgcn_readfirstlane(tab[ag]), n1 = vw - 1;
+      const bool big = cells > HW;
+      const bool covers = up >= H - 1 && vh - 1 - up >= H - 1 && left >= W - 1 && vw - 1 - left >= W - 1;
+      int P[NP], Q[NP];                                        // landing offset of plane cell (r, c): +-(r * n + c) or +-(c * n - r) plus an env scalar
+#pragma unroll
+      for (int j = 0; j < NP; ++j) { P[j] = prr[j] * vw + pcc[j]; Q[j] = pcc[j] * vw - prr[j]; }
+#pragma nounroll
+      for (int g = 0; g < G; ++g) {
+        const uint8_t* lay = envs + g * env_lds;
+        // the image sits at the 16-byte phase of its row in global memory, so that the row's aligned 16-byte chunks are aligned in
+        // LDS too (img_bytes has 16 bytes of slack for it)
+        const long long eg = e0 + g < n ? e0 + g : n - 1;
+        uint8_t* img = envs + g * env_lds + lay_bytes + (int)(reinterpret_cast<uintptr_t>(out + eg * (long long)row_bytes) & 15);
+        const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)ppos[g * 4 + ag]);
+        const int pr = (int)(pw & 0xffu) - up, pc = (int)((pw >> 8) & 0xffu) - left;
+        const int dir = (int)((pw >> 19) & 3u);
+        if (big) {
+          const int base = dir == 2 ? -(pr * vw + pc) : (dir == 3 ? (n1 + pr) * vw + n1 + pc : (dir == 0 ? n1 + pr - pc * vw : (n1 + pc) * vw - pr));
+          const bool useQ = dir < 2, neg = dir == 3 || dir == 1;
+          int at[NP]; bool ok[NP];
+#pragma unroll
+          for (int j = 0; j < NP; ++j) {
+            const int t = useQ ? Q[j] : P[j];
+            at[j] = (neg ? -t : t) + base;
+            ok[j] = j < npass && lane + WAVE * j < HW;
+            if (!covers) ok[j] = ok[j] && (unsigned)(prr[j] - pr) < (unsigned)vh && (unsigned)(pcc[j] - pc) < (unsigned)vw;
+          }
+          for (int l = wave; l < L; l += nwave) {
+            const uint32_t pad = pad_is_char ? 0x01010101u * outside : (chars[l] == outside ? 0x01010101u : 0u);
+            const uint8_t* plane = lay + l * HW;
+            uint8_t* dst = img + off + l * cells;
+            // pad fill: bytes up to the first dword boundary, dwords, tail bytes (dst is byte-aligned only)
+            const int head = (int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3), nh = head < cells ? head : cells;
+            if (lane < nh) dst[lane] = (uint8_t)pad;
+            uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + nh);
+            const int nd = (cells - nh) >> 2;
+            for (int k = lane; k < nd; k += WAVE) d4[k] = pad;
+            const int done = nh + 4 * nd;
+            if (lane < cells - done) dst[done + lane] = (uint8_t)pad;
+            lds_wave_sync();
+            uint8_t val[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) val[j] = plane[ok[j] ? lane + WAVE * j : 0];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) if (ok[j]) dst[at[j]] = val[j];
+          }
+        } else {
+          for (int l = wave; l < L; l += nwave) {
+            const uint8_t pad = pad_is_char ? outside : (uint8_t)(chars[l] == outside);
+            const uint8_t* plane = lay + l * HW;
+            uint8_t* dst = img + off + l * cells;
+            for (int k = lane; k < cells; k += WAVE) {
+              int vr = k / vw, vc = k - vr * vw;
+              view_unrotate(dir, vw, vr, vc);
+              const int r = vr + pr, c = vc + pc;
+              dst[k] = ((unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W) ? plane[r * W + c] : pad;
+            }
           }
         }
       }
     }
     __syncthreads();
-    uint8_t* g = out + e * (long long)row_bytes;
-    const int ndw = row_bytes >> 2;
-    for (int j = threadIdx.x; j < ndw; j += blockDim.x) {
-      const uint32_t val = reinterpret_cast<const uint32_t*>(img)[j];
-#if defined(__HIP_DEVICE_COMPILE__)
-      asm volatile("global_store_dword %0, %1, off" : : "v"(g + 4 * j), "v"(val) : "memory");      // a dword at a byte address
-#else
-      for (int b = 0; b < 4; ++b) g[4 * j + b] = (uint8_t)(val >> (8 * b));
-#endif
+    // ---- the G rows out
+#pragma nounroll
+    for (int g = 0; g < G; ++g) {
+      if (e0 + g < n) {
+        uint8_t* gp = out + (e0 + g) * (long long)row_bytes;
+        const int phase = (int)(reinterpret_cast<uintptr_t>(gp) & 15);
+        const uint8_t* img = envs + g * env_lds + lay_bytes + phase;
+        // head bytes up to the first 16-byte boundary, aligned 16-byte chunks, tail bytes
+        const int head = ((16 - phase) & 15) < row_bytes ? ((16 - phase) & 15) : row_bytes;
+        const int nq = (row_bytes - head) >> 4, done = head + 16 * nq;
+        if ((int)threadIdx.x < head) gp[threadIdx.x] = img[threadIdx.x];
+        for (int q = threadIdx.x; q < nq; q += blockDim.x)
+          *reinterpret_cast<uint4*>(gp + head + 16 * q) = *reinterpret_cast<const uint4*>(img + head + 16 * q);
+        if ((int)threadIdx.x < row_bytes - done) gp[done + threadIdx.x] = img[done + threadIdx.x];
+      }
     }
-    for (int j = 4 * ndw + (int)threadIdx.x; j < row_bytes; j += blockDim.x) g[j] = img[j];
-    __syncthreads();                                         // the next env reuses the planes and the image
+    __syncthreads();                                         // the next group reuses the planes and the images
   }
 }
 
