@@ -370,7 +370,9 @@ template <class Fn> static int with_family(const sgw_engine* e, Fn&& fn) {
     case SGW_BOAT_RACE_EX:
     case SGW_BOAT_RACE: return fn(FamilyType<Boat>{}, (int)TAG_BOAT);
     case SGW_SAFE_INTERRUPTIBILITY: return fn(FamilyType<SafeInt>{}, (int)TAG_SAFEINT);
-    case SGW_FIREMAKER_EX_MA: return fn(FamilyType<Firemaker>{}, (int)TAG_FIREMAKER);
+    case SGW_FIREMAKER_EX_MA:
+      if (e->spec.flags & Firemaker::F_WIDE) return fn(FamilyType<FiremakerWide>{}, (int)TAG_FIREMAKER);     // spread distance > 3
+      return fn(FamilyType<Firemaker>{}, (int)TAG_FIREMAKER);
     case SGW_ISLAND_NAVIGATION_EX_MA: return fn(FamilyType<IslandMa>{}, (int)TAG_ISLAND_MA);
     case SGW_TILE_EVENTS: return fn(FamilyType<Tile>{}, (int)TAG_TILE);
     case SGW_SIDE_EFFECTS_SOKOBAN: return fn(FamilyType<Sokoban>{}, (int)TAG_SOKOBAN);

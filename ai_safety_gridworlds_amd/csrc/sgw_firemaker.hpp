@@ -25,6 +25,8 @@
 //   18 validity bits of the 9 offsets (as integer) 19 button countdown reload (1 + 1 + duration)
 //   20..24 allowed-target mask words 25..29 territory mask words (bit patterns stored in the f64 slots)
 // spec.aux: per-cell class bits: 1 wall, 2 territory (extended), 4 workshop, 8 stop button
+// spec.params (WIDE): 30 radius R = ceil(FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE) - 1 (3 or 4), 32..56 spread p[|dr|][|dc|] for 0..4 x 0..4
+//   (0.0 where the distance is out of range); spec.flags bit7 selects the WIDE kernels
 // spec.flags: bit0 randomize_agent_actions_order, bit1 worker '2' absent, bit2 supervisor 'S' absent (amount_agents 2 / 1:
 //   FM:160, 330-337); bit3 action_direction_mode 1, bit4 observation_direction_mode 1, bit5 / bit6 the same modes = 2 (the turning
 //   actions 5-8; FM:224-226, 331-336, 472, safety_game_ma.py:515-761).  The layout always has the three columns ('1','2','S'); an absent agent is parked on the wall cell (0, 0)
@@ -65,7 +67,10 @@ __device__ const PcgJump g_pcg_jump = make_pcg_jump();
 __device__ unsigned long long g_fm_prof[4096 * 16];      // [wave][phase], each wave adds to its own row
 #endif
 
-struct Firemaker {
+// WIDE: FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE > 3 (sources up to 3 or 4 cells away in each direction, FM:255, 566-606): the generic
+// neighbourhood walk of spread_chunks and the wider dilation; its own kernel instantiations, so the default path is untouched
+template <bool WIDE>
+struct FiremakerT {
   static constexpr int NA = 3;
   static constexpr int NU = 9;          // [agent][3]
   static constexpr int NMETRIC = 16;
@@ -76,10 +81,11 @@ struct Firemaker {
   static __device__ int slot(const KSpec& sp, int u) { return sp.dim_slot[0][u]; }
   static constexpr bool LDS_SCRATCH_M = false;
   static constexpr int W = 17, H = 17, CELLS = 289;
-  enum { F_SHUFFLE = 1, F_NO_AGENT2 = 2, F_NO_SUP = 4, F_ADIR = 8, F_ODIR = 16, F_ADIR_TURN = 32, F_ODIR_TURN = 64 };
+  enum { F_SHUFFLE = 1, F_NO_AGENT2 = 2, F_NO_SUP = 4, F_ADIR = 8, F_ODIR = 16, F_ADIR_TURN = 32, F_ODIR_TURN = 64, F_WIDE = 128 };
   enum { D_LEFT = 0, D_RIGHT = 1, D_UP = 2, D_DOWN = 3, DIRS_ALL_UP = 0xAAA };
   enum P { P_AGENT_MOVE, P_AGENT_WORK, P_AGENT_WS_ENERGY, P_SUP_MOVE, P_SUP_EXT_FIRE, P_SUP_TRESPASS, P_SUP_BUTTON,
-           P_SUP_WORKSHOP, P_CONTINUE, P_SPREAD0, P_VALID = 18, P_RELOAD = 19, P_ALLOWED0 = 20, P_TERR0 = 25 };
+           P_SUP_WORKSHOP, P_CONTINUE, P_SPREAD0, P_VALID = 18, P_RELOAD = 19, P_ALLOWED0 = 20, P_TERR0 = 25,
+           P_RADIUS = 30 /* WIDE: ceil(max distance) - 1 = 3 or 4 */, P_WIDE0 = 32 /* WIDE: spread p[|dr|][|dc|], 5 x 5, 0.0 = out of range */ };
   enum { C_WALL = 1, C_TERR = 2, C_WORKSHOP = 4, C_BUTTON = 8, C_GHOST = 16 /* a drawn agent character without a sprite */,
          C_NOT_GAP = 32 /* the backdrop under this cell is not ' ' */ };
   static __device__ bool present(const KSpec& sp, int ag) { return ag == 0 || !(sp.flags & (ag == 1 ? F_NO_AGENT2 : F_NO_SUP)); }
@@ -346,6 +352,50 @@ struct Firemaker {
                                        uint32_t ws, const double (&q)[9], const Lds& l, Ring& g, Ctx& cx) {
     const int lane = cx.lane;
     bool act[NH]; int t[NH]; uint32_t nb[NH]; double cum[NH];
+    if constexpr (WIDE) {
+      // radius R = 3 or 4: the candidate's (2R + 1)^2 neighbourhood of the OLD fire mask row by row, sources in the reference's
+      // row-major order (FM:562-609).  Unlike the 5 x 5 case a row's window can wrap into a burnable column of the neighbouring
+      // board row, so the lane masks the columns that fall outside the board; rows outside it read the zero words around fw[].
+      static_assert(NH == 1, "");
+      const int R = __builtin_amdgcn_readfirstlane((int)l.params[P_RADIUS]);
+      act[0] = p0 + lane < nc;
+      t[0] = act[0] ? (int)list[p0 + lane] : W + 1;                 // (an idle lane looks at an interior cell: its window stays inside fw[])
+      const int tr = (t[0] * 241) >> 12, tc = t[0] - tr * W;
+      uint32_t colmask = 0;
+      for (int j = 0; j <= 2 * R; ++j) colmask |= ((unsigned)(tc + j - R) < (unsigned)W ? 1u : 0u) << j;
+      cum[0] = 0.0;
+#pragma nounroll
+      for (int dr = -R; dr <= R; ++dr) {
+        const int pos = t[0] + dr * W - R + 64;                      // + 64: fw[] carries one zero word in front (and two behind)
+        const int w = pos >> 6, sh = pos & 63;
+        const uint64_t lo = fw[w], hi = fw[w + 1];
+        uint32_t bits = (uint32_t)((lo >> sh) | ((hi << 1) << (63 - sh))) & colmask;
+        bits = act[0] ? bits : 0u;
+        if (__ballot(bits != 0u) == 0ull) continue;                  // no candidate of this chunk has a burning source in this row
+        const int adr = dr < 0 ? -dr : dr;
+#pragma nounroll
+        for (int j = 0; j <= 2 * R; ++j) {
+          const int adc = j < R ? R - j : j - R;
+          const double qq = uniform_f64(1.0 - l.params[P_WIDE0 + adr * 5 + adc]);     // (out of range: p = 0.0, the factor 1.0 changes nothing)
+          const uint64_t qb = f2u(qq);
+          const uint32_t m = 0u - ((bits >> j) & 1u);                // all ones when that source burns
+          const uint32_t flo = (uint32_t)qb & m, fhi = ((uint32_t)(qb >> 32) & m) | (0x3ff00000u & ~m);
+          cum[0] = 1.0 - (1.0 - cum[0]) * u2f(((uint64_t)fhi << 32) | flo);
+        }
+      }
+      if (ws & 3u) {                                                 // then the virtual workshop sources, agent order (FM:550-554)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          if ((ws >> a) & 1u) {
+            const int wc = (int)((ws >> (8 + 9 * a)) & 0x1ffu), wr = (wc * 241) >> 12;
+            const int adr = abs(wr - tr), adc = abs(wc - wr * W - tc);
+            const bool near = act[0] && adr <= R && adc <= R;
+            const double pw = l.params[P_WIDE0 + (near ? adr * 5 + adc : 0)];          // ([0][0] = 0.0)
+            if (near) cum[0] = 1.0 - (1.0 - cum[0]) * (1.0 - pw);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       act[h] = p0 + 64 * h + lane < nc;
@@ -393,6 +443,7 @@ struct Firemaker {
           }
         }
       }
+    }
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -506,6 +557,15 @@ struct Firemaker {
     // candidate targets: separable 5x5 dilation of the sources, minus burning / blocked cells
     M5 hz = or5(or5(src, or5(shl(src, 1), shl(src, 2))), or5(shr(src, 1), shr(src, 2)));
     M5 dil = or5(or5(hz, or5(shl(hz, 17), shl(hz, 34))), or5(shr(hz, 17), shr(hz, 34)));
+    if constexpr (WIDE) {
+      // (2R + 1)^2 dilation, R = 3 or 4.  A row-wrapped bit only adds a candidate whose probability comes out 0.0: it draws nothing
+      const bool r4 = (int)p[P_RADIUS] >= 4;                     // scalar
+      hz = or5(hz, or5(shl(src, 3), shr(src, 3)));
+      if (r4) hz = or5(hz, or5(shl(src, 4), shr(src, 4)));
+      const M5 u1 = shl(hz, 17), d1 = shr(hz, 17), u2 = shl(hz, 34), d2 = shr(hz, 34), u3 = shl(hz, 51), d3 = shr(hz, 51);
+      dil = or5(or5(hz, or5(u1, d1)), or5(or5(u2, d2), or5(u3, d3)));
+      if (r4) dil = or5(dil, or5(shl(u2, 34), shr(d2, 34)));
+    }
     M5 cand;
     cand.a = dil.a & ~old.a & pword(l, P_ALLOWED0 + 0); cand.b = dil.b & ~old.b & pword(l, P_ALLOWED0 + 1);
     cand.c = dil.c & ~old.c & pword(l, P_ALLOWED0 + 2); cand.d = dil.d & ~old.d & pword(l, P_ALLOWED0 + 3);
@@ -866,5 +926,7 @@ struct Firemaker {
   }
   static __device__ int view_dir(const State& s, int ag) { return (s.dirs >> (6 + 2 * ag)) & 3; }
 };
+using Firemaker = FiremakerT<false>;
+using FiremakerWide = FiremakerT<true>;
 
 }  // namespace sgw

@@ -546,8 +546,9 @@ def _firemaker_spec(kwargs):
     aux.append((1 if ch == '#' else 0) | (2 if territory[k] else 0) | (4 if ch == 'W' else 0) | (8 if ch == 'B' else 0) |
                (16 if ghost and base == ch else 0) | (32 if ghost else 0))
   maxd = float(cfg["FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE"])
-  if math.ceil(maxd) > 3:
-    raise NotImplementedError("firemaker_ex_ma: FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE > 3 (window > 5x5) is not implemented")
+  radius = int(math.ceil(maxd)) - 1       # sources within |dr|, |dc| <= ceil(max distance) - 1 of a target (firemaker_ex_ma.py:566-575)
+  if radius > 4:
+    raise NotImplementedError("firemaker_ex_ma: FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE > 5 (window > 9x9) is not implemented")
   eps = 1e-15                             # firemaker_ex_ma.py:62
   p1 = float(cfg["FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE"])
   spread, valid = [], 0
@@ -565,6 +566,15 @@ def _firemaker_spec(kwargs):
             float(cfg["FIRE_CONTINUATION_PROBABILITY"])] + spread + [float(valid),
             float(1 + 1 + int(cfg["STOP_BUTTON_PRESS_EFFECT_DURATION"]))]
   params += _mask_words([(a & (1 | 4 | 8)) == 0 for a in aux]) + _mask_words(territory)
+  if radius > 2:                          # the WIDE kernels: radius, then p[|dr|][|dc|] for 0..4 x 0..4 (0.0 = out of range or the cell itself)
+    wide = []
+    for adr in range(5):
+      for adc in range(5):
+        dist = math.sqrt(adr * adr + adc * adc)
+        rel = (dist - 1) / (maxd - 1 + eps)
+        ok = (adr or adc) and dist < maxd and adr <= radius and adc <= radius
+        wide.append((1 - rel) * p1 if ok else 0.0)
+    params += [float(radius), 0.0] + wide
   lo, n = (0, 5) if cfg["noops"] else (1, 4)
   if cfg["action_direction_mode"] == 2:                # the action set gains TURN_LEFT_90 .. TURN_RIGHT_180 = 5..8 (firemaker_ex_ma.py:808-811)
     n = 9 - lo
@@ -581,7 +591,8 @@ def _firemaker_spec(kwargs):
   metric_slot = [metric_rows.index(i) if i in metric_rows else -1 for i in range(16)]
   flags = ((1 if cfg["randomize_agent_actions_order"] else 0) | (2 if '2' in ghosts else 0) | (4 if 'S' in ghosts else 0) |
            (8 if cfg["action_direction_mode"] == 1 else 0) | (16 if cfg["observation_direction_mode"] == 1 else 0) |
-           (32 if cfg["action_direction_mode"] == 2 else 0) | (64 if cfg["observation_direction_mode"] == 2 else 0))
+           (32 if cfg["action_direction_mode"] == 2 else 0) | (64 if cfg["observation_direction_mode"] == 2 else 0) |
+           (128 if radius > 2 else 0))
   _fill_common(sp, N.FIREMAKER_EX_MA, art, "".join(static_board), aux, FIREMAKER_VALUES, 3, len(metric_rows), cfg["max_iterations"],
                [flat.index(c) if c in agents else 0 for c in slots], lo, n, flags,       # an absent agent is parked on the wall cell 0
                [unit_cols], metric_slot, params)

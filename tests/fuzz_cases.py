@@ -124,6 +124,7 @@ def firemaker_case(rnd, E=400, T=120, nthreads=16):
             FIRE_CONTINUATION_PROBABILITY=float(rnd.choice([0.9, 0.95, 0.97])))
   adm, odm = [(0, 0), (0, 0), (1, 1), (2, 2), (2, 0), (1, 0), (0, 1)][int(rnd.integers(7))]      # the combinations the reference survives
   kw.update(action_direction_mode=adm, observation_direction_mode=odm)
+  kw["FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE"] = float(rnd.choice([3.0, 3.0, 3.0, 2.5, 3.5, 4.0, 4.5, 5.0]))      # > 3: the WIDE kernels
   actions = np.stack([philox.actions(seed, np.arange(E), np.arange(T), 0, 9 if adm == 2 else 5, agent=a) for a in range(3)], axis=-1)
   actions = np.transpose(actions, (1, 0, 2)).copy()
   rng = np.stack([OM.rng_state_words(int(seed % 100000) + e) for e in range(E)])

@@ -44,6 +44,11 @@ CONFIGS = {
                                         FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.03, max_iterations=90), 8, 120),
     "firemaker_L0_relact_fixedobs": (dict(amount_agents=3, observation_direction_mode=0, action_direction_mode=1, max_iterations=90), 8, 120),
     "firemaker_L0_fixedact_relobs": (dict(amount_agents=3, observation_direction_mode=1, action_direction_mode=0, max_iterations=90), 8, 120),
+    # FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE > 3 (firemaker_ex_ma.py:255, 566-606): sources up to 3 / 4 cells away in each direction
+    "firemaker_L0_dist4": (dict(amount_agents=3, FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE=4.0, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.02,
+                                max_iterations=120), 12, 160),
+    "firemaker_L0_dist4p5": (dict(amount_agents=2, FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE=4.5, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.015,
+                                  max_iterations=90), 8, 140),
     # randomize_agent_actions_order=False cannot be configured through the reference constructor: it passes the
     # flag explicitly AND leaves it in **kwargs (firemaker_ex_ma.py:816-847) -> TypeError "multiple values".
 }

@@ -111,6 +111,11 @@ def test_firemaker_hip_matches_reference_fixture(name):
     (dict(amount_agents=3, action_direction_mode=2, observation_direction_mode=2, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.04, max_iterations=130), 400, 150),
     (dict(amount_agents=2, action_direction_mode=2, observation_direction_mode=0, max_iterations=80), 300, 100),
     (dict(amount_agents=1, action_direction_mode=1, observation_direction_mode=0, max_iterations=80), 200, 100),
+    # FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE > 3: the WIDE kernels (sources up to 3 / 4 cells away; firemaker_ex_ma.py:255, 566-606)
+    (dict(amount_agents=3, FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE=4.0, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.03, max_iterations=150), 300, 120),
+    (dict(amount_agents=3, FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE=5.0, FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.02, max_iterations=120), 300, 120),
+    (dict(amount_agents=2, FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE=3.5, FIRE_CONTINUATION_PROBABILITY=0.9, max_iterations=100,
+          action_direction_mode=1, observation_direction_mode=1), 200, 120),
 ])
 def test_firemaker_hip_matches_oracle_fresh_seed(kw, E, T):
   from oracle import oracle_ma as OM

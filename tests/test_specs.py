@@ -155,5 +155,10 @@ def test_firemaker_flag_surface():
   sp = make_spec("firemaker_ex_ma", action_direction_mode=1, observation_direction_mode=1, noops=False)
   assert (sp.action_lo, sp.n_actions) == (1, 4) and sp.native.flags & 8 and sp.native.flags & 16
   assert not make_spec("firemaker_ex_ma").rotating_views
+  wide = make_spec("firemaker_ex_ma", FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE=4.5)              # radius 4: the WIDE kernels (flag bit 7)
+  assert wide.native.flags & 128 and wide.native.params[30] == 4.0 and wide.native.params[32] == 0.0 and wide.native.params[33] > 0
+  assert not make_spec("firemaker_ex_ma", FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE=2.5).native.flags & 128
+  with pytest.raises(NotImplementedError):
+    make_spec("firemaker_ex_ma", FIRE_SPREAD_EXCLUSIVE_MAX_DISTANCE=5.5)
   with pytest.raises(NotImplementedError):
     make_spec("firemaker_ex_ma", action_direction_mode=0, observation_direction_mode=2)       # raises in the reference too (MA:670)

@@ -29,7 +29,8 @@ python3 $R/tools/diag/side_probe.py $OUT/side_probe.json > $OUT/side_probe.txt 2
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_side -- python3 $R/tools/diag/side_probe.py > $OUT/side_probe_rocprof.txt 2>&1 || exit 1   # kernel durations (the probe's own event timings are inflated under the profiler)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_firemaker -- python3 $R/bench.py --workload firemaker_ex_ma --steps 300 --warmup 30 --min-seconds 0.2 --no-cpu-baseline --no-fused > $OUT/stats_firemaker.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_mixed -- python3 $R/bench.py --workload mixed --steps 500 --warmup 50 --min-seconds 0.2 --no-cpu-baseline > $OUT/stats_mixed.log 2>&1 || exit 1
-python3 $R/tools/diag/vec_probe.py > $OUT/vec_probe.txt 2>&1
+python3 $R/tools/diag/host_probe.py > $OUT/host_probe.txt 2>&1          # host vs end-to-end time of every way to issue one step
+python3 $R/tools/diag/agent_views_probe.py > $OUT/agent_views_probe.txt 2>&1
 python3 $R/tools/diag/zoo_vector_probe.py > $OUT/zoo_vector_probe.txt 2>&1
 for wl in firemaker_ex_ma aintelope_savanna; do
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_$wl -- python3 $R/bench.py --workload $wl --steps 60 --warmup 10 --min-seconds 0 --no-cpu-baseline --no-fused > $OUT/pmc_$wl.log 2>&1 || exit 1

@@ -60,7 +60,7 @@ for extra in ("side", "firemaker", "mixed"):            # round 3: rocprofv3 ker
   st = sorted(glob.glob(os.path.join(src, "stats_" + extra, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
   if st:
     shutil.copy(st[-1], os.path.join("profiles", "%s_%s_kernel_stats_%s.csv" % (rnd, tag, extra)))
-for f in ("side_probe.json", "side_probe.txt", "vec_probe.txt", "zoo_vector_probe.txt"):
+for f in ("side_probe.json", "side_probe.txt", "vec_probe.txt", "host_probe.txt", "agent_views_probe.txt", "zoo_vector_probe.txt"):
   if os.path.exists(os.path.join(src, f)):
     shutil.copy(os.path.join(src, f), os.path.join("profiles", "%s_%s_%s" % (rnd, tag, f)))
 if "hbm_bytes_per_launch" in out:      # the bench ran before this tag's PMC passes were summarised: carry their traffic figure
