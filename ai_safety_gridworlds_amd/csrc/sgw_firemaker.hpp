@@ -498,40 +498,38 @@ struct FiremakerT {
     for (int j = 0; j < 5; ++j) nf[j] = uniform_u64(reinterpret_cast<const uint64_t*>(nfw)[j]);
     FM_T(7);                                                           // new fire words back
   }
-  template <int WI>
-  static __device__ void continue_pass(const uint64_t (&o)[5], uint64_t (&nf)[5], double cont, Ring& g, Ctx& cx) {
-    const uint64_t ow = o[WI];                                        // FM:619-621: one draw per ORIGINAL fire cell
-    if (ow == 0) return;
-    ring_ready(g, cx);
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ow >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ow, 0u));
-    const double u = cx.draws[(g.consumed + rank) & 127];
-    nf[WI] &= ~(__ballot(!(u < cont)) & ow);
-    g.consumed += __builtin_popcountll(ow);
-  }
-
-  // FM:619-621 for all five words at once when the env's fire cells fit the ring's window (they do unless > 64 cells burn):
-  // one ring_ready, five independent LDS reads, instead of five dependent passes
+  // FM:619-621, one draw per ORIGINAL fire cell in row-major order: as many of the five words at once as the ring has draws
+  // readable (ring_ready leaves blocks blk and blk + 1 in LDS: at least 64 and up to 128 draws ahead of `consumed`) -- one
+  // ring_ready and one batch of independent LDS reads per stage instead of five dependent passes.  A burning env has ~100 fire
+  // cells: two stages.
   static __device__ void continue_all(const uint64_t (&o)[5], uint64_t (&nf)[5], double cont, Ring& g, Ctx& cx) {
-    const int total = __builtin_popcountll(o[0]) + __builtin_popcountll(o[1]) + __builtin_popcountll(o[2]) +
-                      __builtin_popcountll(o[3]) + __builtin_popcountll(o[4]);
-    if (total == 0) return;
-    if (total > 64) {
-      continue_pass<0>(o, nf, cont, g, cx); continue_pass<1>(o, nf, cont, g, cx); continue_pass<2>(o, nf, cont, g, cx);
-      continue_pass<3>(o, nf, cont, g, cx); continue_pass<4>(o, nf, cont, g, cx);
-      return;
-    }
-    ring_ready(g, cx);                                                // draws [consumed, consumed + 64) are readable
-    int base = g.consumed;
-    double u[5];
+    int n[5];
 #pragma unroll
-    for (int wi = 0; wi < 5; ++wi) {
-      const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(o[wi] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)o[wi], 0u));
-      u[wi] = cx.draws[(base + rank) & 127];                          // lanes that are no fire cell of this word read a neighbour's draw
-      base += __builtin_popcountll(o[wi]);
-    }
+    for (int wi = 0; wi < 5; ++wi) n[wi] = __builtin_popcountll(o[wi]);
+    if (n[0] + n[1] + n[2] + n[3] + n[4] == 0) return;
+    int first = 0;                                                     // scalar: the first word that has not drawn yet
 #pragma unroll
-    for (int wi = 0; wi < 5; ++wi) nf[wi] &= ~(__ballot(!(u[wi] < cont)) & o[wi]);
-    g.consumed = base;
+    for (int stage = 0; stage < 5; ++stage) {                         // (a word has at most 64 cells: every stage takes at least one)
+      if (first >= 5) break;
+      ring_ready(g, cx);
+      const int avail = (g.blk + 2) * 64 - g.consumed;                // draws [consumed, consumed + avail) are readable
+      int used = 0, next = first;
+      bool open = true, take[5];
+      double u[5];
+#pragma unroll
+      for (int wi = 0; wi < 5; ++wi) {
+        take[wi] = open && wi >= first && used + n[wi] <= avail;
+        if (wi >= first && !take[wi]) open = false;
+        if (take[wi]) {
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(o[wi] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)o[wi], 0u));
+          u[wi] = cx.draws[(g.consumed + used + rank) & 127];         // lanes that are no fire cell of this word read a neighbour's draw
+          used += n[wi]; next = wi + 1;
+        }
+      }
+#pragma unroll
+      for (int wi = 0; wi < 5; ++wi) if (take[wi] && n[wi]) nf[wi] &= ~(__ballot(!(u[wi] < cont)) & o[wi]);
+      g.consumed += used; first = next;
+    }
   }
 
   // FireDrape.update (FM:536-629).  Runs with all 64 lanes of all 4 waves active (see k_engine).
