@@ -77,7 +77,7 @@ One collection per round is kept: **`r03_{tag}_*` (round 3, final)**, `r02_v7_*`
 | `r03_{tag}_pmc.json`, `r03_traffic.json` | per-launch medians of the PMC passes (separate `--pmc` runs: FETCH_SIZE / WRITE_SIZE / SQ_*); HBM bytes per launch of the step kernel, read by `bench.py` into `roofline.traffic` |
 | `r03_{tag}_bench_<workload>.json`, `r03_{tag}_bench_island_n<N>.json` | every other family through `bench.py --workload â€¦`; the headline kernel at 131 072 / 262 144 / 1 048 576 envs |
 | `r03_{tag}_side_probe.json / .txt` | device time (HIP events, unprofiled), algorithmic bytes, HBM fraction of every side kernel at the BASELINE sizes |
-| `r03_{tag}_vec_probe.txt`, `r03_{tag}_zoo_vector_probe.txt` | the Python facades: `GridworldVectorEnv.step` (default and `full_info=True`), `GridworldZooVectorEnv.step` |
+| `r03_{tag}_host_probe.txt`, `r03_{tag}_zoo_vector_probe.txt`, `r03_{tag}_agent_views_probe.txt` | host vs end-to-end time of every way to issue one step (bare C call, engine, graph replay, `GridworldVectorEnv.step` default and `full_info=True`); `GridworldZooVectorEnv.step` next to the round kernel alone; `sgw_agent_views` alone |
 | `r03_{tag}_phase_stamps.txt` | in-kernel phase stamps of the headline kernel (diagnostic build `tools/diag/stamp_probe.hip`) |
 | `r03_pmc_firemaker_ex_ma.json`, `r03_pmc_aintelope_savanna.json` | SQ counters of the two instruction-bound round kernels (`bench.py` reads SQ_INSTS_VALU from them) |
 | `r03_kernel_registers.md` | VGPR / AGPR / SGPR / spills / scratch of every kernel in `libsgw.so` + the exec-restore lint verdict |
@@ -95,11 +95,11 @@ One collection per round is kept: **`r03_{tag}_*` (round 3, final)**, `r02_v7_*`
 | roofline: achieved / peak / frac | {b["roofline"]["achieved"]:.0f} GB/s / 8 000 GB/s / **{b["roofline"]["frac"]:.3f}** ({b["roofline"]["frac_of_measured_copy_rate"]:.2f} of the guide's measured 6.29 TB/s copy rate) | 0.35-0.37 | 0.285 | r03_{tag}_bench.json |
 | HBM traffic / launch (PMC) | **{pmc["hbm_bytes_per_launch"]/1e6:.2f} MB** = 2Ã—FETCH_SIZE {pm["FETCH_SIZE"]:.0f} KiB + WRITE_SIZE {pm["WRITE_SIZE"]:.0f} KiB | 20.0-20.3 MB | 29.8 MB | r03_{tag}_pmc.json |
 | fused rollout (512 steps / launch, all outputs every step) | {sci(b["fused_rollout"]["value"])}, {b["fused_rollout"]["frac_of_hbm_peak"]:.3f} | 2.73 Ã— 10^10, 0.46-0.47 | 2.0 Ã— 10^10, 0.35 | r03_{tag}_bench.json |
-| **everything `env.step()` returns** (`full_observation`: board, float board, reward, cumulative, metrics + RGB + unoccluded layers + gini / variances / average reward + performance bookkeeping; ONE `sgw_step_full` call per step) | **{sci(fo["value"])} env-steps/s**, {fo["us_per_step"]:.1f} Âµs per step, {fo["host_us_per_call"]:.1f} Âµs of host time per call | four launches from Python (~15.8 Âµs of host time for the step alone) | - | r03_{tag}_bench.json |
+| **everything `env.step()` returns** (`full_observation`: board, float board, reward, cumulative, metrics + RGB + unoccluded layers + gini / variances / average reward + performance bookkeeping; ONE `sgw_step_full` call per step, launches issued directly) | **{sci(fo["value"])} env-steps/s**, {fo["us_per_step"]:.1f} Âµs per step, {fo["host_us_per_call"]:.1f} Âµs of host time per call incl. the action copy (`extras.replay`: one hipGraph per step, 5 Âµs of host time, 44 Âµs per step) | four launches from Python (~15.8 Âµs of host time for the step alone) | - | r03_{tag}_bench.json |
 | CPU baseline ("port": C oracle, same stream) | {sci(b["cpu_baseline"]["value"])} env-steps/s on {b["cpu_baseline"]["cores"]} threads ({sci(b["cpu_baseline"]["single_thread_value"])} on one) | 4.8 Ã— 10^7 | | r03_{tag}_bench.json |
 | reference CPython (build container, 1 core) | 2.5 Ã— 10^3 env-steps/s | | | reference_cpython.json |
 
-The step kernel itself did not change in round 3 (bounded experiments were measured and not kept: DESIGN.md Â§4.10).  At this size the
+The step kernel itself did not change in round 3 beyond the `done / obs_dir / act_dir` outputs of ABI 8, whose pointers are read from the kernarg segment only when asked for (bounded experiments were measured and not kept: DESIGN.md Â§4.10).  At this size the
 launch is 1 024 waves = one per SIMD and its 14 MB working set is L2 / Infinity-Cache resident: the kernel is **latency-bound**, the
 HBM label is nominal (PMC: `SQ_WAIT_ANY / SQ_WAVE_CYCLES` = {pm["SQ_WAIT_ANY"]/pm["SQ_WAVE_CYCLES"]:.2f}; VALU {pm["SQ_INSTS_VALU"]/1024:.0f}, SALU {pm["SQ_INSTS_SALU"]/1024:.0f}, LDS {pm["SQ_INSTS_LDS"]/1024:.0f} instructions per wave).
 Phase stamps (`r03_{tag}_phase_stamps.txt`): loads arrive 0.60 Âµs after issue Â· rules 1.85 Â· output phase 1.43 Â· state stores 0.23 â‡’ 4.1 Âµs of
@@ -114,7 +114,7 @@ wave life; all waves end 4.4-5.2 Âµs after the first starts; the other â‰ˆ 1.5 Â
 |---|---|---|---|
 | firemaker_ex_ma, 16 384 envs x 3 agents: Âµs per round | **{fm["ms_per_step"]*1e3:.1f}** ({fm["roofline"]["frac"]:.3f} of VALU issue) | 80.4-80.7 | r03_{tag}_bench_firemaker_ex_ma.json |
 | ... with the three agents' windows (the Zoo API's observation) | **{wv["us_per_round"]:.1f} Âµs from ONE launch** (`sgw_out.views`) | 101.9 Âµs in two launches | `with_agent_views` |
-| `GridworldZooVectorEnv.step` (dict in, dicts of device tensors out) | 82.5-87 Âµs per round | 125 Âµs | r03_{tag}_zoo_vector_probe.txt |
+| `GridworldZooVectorEnv.step` (dict in, dicts of device tensors out) | 84-93 Âµs per round = the round kernel with the Zoo outputs (87-89 Âµs alone) | 125 Âµs | r03_{tag}_zoo_vector_probe.txt |
 | rocprofv3 avg of `k_engine<Firemaker, 0>` over the run (both variants, {fm_calls} calls) | {fm_us:.1f} Âµs | 80.7 Âµs | r03_{tag}_kernel_stats_firemaker.csv |
 | mixed suite (island_navigation_ex + boat_race_ex + safe_interruptibility, 3 x 10 923 envs): three concurrent per-family launches per step | {sci(mx["value"])} env-steps/s, {mx["ms_per_step"]*1e3:.2f} Âµs per step, {mx["roofline"]["frac"]:.3f} of HBM over the whole step (rocprofv3: Boat {boat_us:.2f}, Island {mi_us:.2f}, SafeInt {si_us:.2f} Âµs) | 4.38 Ã— 10^9, 7.5 Âµs | r03_{tag}_bench_mixed.json, r03_{tag}_kernel_stats_mixed.csv |
 | ... as ONE heterogeneous launch per step (`k_engine_group<0>`) | {sci(gl["value"])}, {gl["us_per_step"]:.2f} Âµs (rocprofv3 avg {g0_us:.2f} Âµs over {g0_calls} calls) | - | `group_launch` |
@@ -128,15 +128,17 @@ overlap their latencies -- hence one launch per step is 6 % slower than three an
 | kernel | Âµs / launch | MB | GB/s | frac of 8 TB/s |
 |---|---|---|---|---|
 {sidetab}
-rocprofv3 durations of the same launches (`r03_{tag}_kernel_stats_side.csv`; `k_observe*` rows average several board sizes; `k_agent_layer_views_lds` averages its layer-cube launches, 121 Âµs, and the one-plane launches of `sgw_agent_views`, 17.5 Âµs): {side_rp}.
+rocprofv3 durations of the same launches (`r03_{tag}_kernel_stats_side.csv`; `k_observe*` rows average several board sizes; `k_agent_layer_views_lds<1>` = the layer cubes, `<4>` = the one-plane launches of `sgw_agent_views`): {side_rp}.
 History inside the round: `k_derived_stats` 29.7 Âµs with 2.6 KB of scratch per lane (round 2) â†’ 23.1 Âµs (vectors streamed from LDS at run-time
 indices: serial LDS round trips) â†’ 7.2-7.4 Âµs (compile-time K, vectors in registers).  `k_observe` RGB 9.0 â†’ 4.6 Âµs, RGB + occluded layers 23.2
 â†’ 10.6 Âµs, `k_observe_layers` 21.8 â†’ 12.9 Âµs (first LDS-staged version, 16 output bytes per lane â†’ four cells and a dword store per lane and
 plane; unaligned dword stores where HÂ·W is odd).  Firemaker's 17 Ã— 17 layers 88 â†’ 51 (dword path) â†’ 23.8 Âµs (16 instead of 64 envs per
 workgroup: 24 instead of 95 KB of LDS).  `k_savanna_layers` 137 â†’ 45 Âµs (state words and code vectors in LDS, the same plane writer).
 `k_agent_layer_views` 208 â†’ 160 (a workgroup per env, planes and the env's output row in LDS) â†’ 121 Âµs (lane constants hoisted out of the env loop,
-dword pad fill); `sgw_agent_views` 26.3 â†’ 17.5 Âµs through the same kernel with one plane (one wave per env; firemaker's windows normally come
-from the round's own launch).
+dword pad fill) â†’ 106 Âµs (per-agent table and per-env words read from LDS instead of select chains over kernel-argument arrays, rows out as
+aligned 16-byte chunks); `sgw_agent_views` 26.3 â†’ 17.5 Âµs through the same kernel with one plane (four envs per one-wave workgroup;
+firemaker's windows normally come from the round's own launch); 65 536 savanna envs' 21 Ã— 21 windows 60 â†’ 56 Âµs (`r03_{tag}_agent_views_probe.txt`).
+Both are instruction-bound: a whole wave issues every instruction of a window's assembly (DESIGN.md Â§4.8).
 
 ## Other workloads (`r03_{tag}_bench_*.json`; in brackets round 2's Âµs per launch)
 
@@ -147,11 +149,15 @@ island_navigation_ex_ma and aintelope_savanna trade 9 % / 2.5 % at this size for
 the rules run: 230 VGPR / 0 AGPR and 297 + 41 instead of 278 + 22 and 349 + 93); at 262 144 envs they run 59 instead of 70 Âµs and 175
 instead of 282 Âµs per round (DESIGN.md Â§4.9).  The firemaker VALU fraction uses this collection's SQ_INSTS_VALU ({fm_valu/1e6:.1f} M wave-instructions per launch).
 
-Python-level step paths (`r03_{tag}_vec_probe.txt`, `r03_{tag}_zoo_vector_probe.txt`): `GridworldVectorEnv.step` 18-19 Âµs per call including the
-in-place action copy (default outputs), 20-25 Âµs of host time with `full_info=True` (51 Âµs end to end: device-bound); `GridworldZooVectorEnv.step`
-firemaker 82.5-87 Âµs per round (125 in round 2), island_navigation_ex_ma 43.6 (51), aintelope_savanna 105 (103; its default 21 Ã— 21 windows are
-larger than the board and stay a separate launch); with the layer cubes (`layers_in_observation=True`) firemaker 233 Âµs (377 before the layer
-kernels' rewrite), ima 186 Âµs.
+Python-level step paths (`r03_{tag}_host_probe.txt`, `r03_{tag}_zoo_vector_probe.txt`).  The wrappers' per-step decodes (`terminated`, the
+observation / action directions) are outputs of the step launch since ABI 8 (`sgw_out.done / obs_dir / act_dir`), so a Python step launches no
+torch kernel of its own and costs what the kernel under it costs: `GridworldVectorEnv.step` 9.0 Âµs end to end with 5.4 Âµs of host time (the step
+kernel with these outputs: 9.0 Âµs; 12.3 Âµs host-bound before), `full_info=True` 39 Âµs end to end with 25 Âµs of host time (direct launches;
+44 Âµs and 5 Âµs as one hipGraph replay per step); `GridworldZooVectorEnv.step` island_navigation_ex_ma 28.6 Âµs per round (kernel 28.4; 44.6 before,
+51 in round 2), firemaker 84-93 (kernel 87-89; 125 in round 2), aintelope_savanna 91 (kernel 32 + its 21 Ã— 21 windows, larger than the board,
+from the separate window kernel: 56 Âµs); with the layer cubes (`layers_in_observation=True`) firemaker 225 Âµs (377 before the layer kernels'
+rewrite), ima 170 Âµs.  A bare `sgw_step` call costs 4.0 Âµs of host time; a ONE-node hipGraph replay of the same kernel runs 13.7 Âµs end to end
+instead of 9.0 (the graph launch's own device-side cost: why `sgw_step_full` issues its launches directly by default).
 
 '''
 open(P + "README.md", "w").write(new + earlier)
