@@ -313,9 +313,9 @@ def main():
   if a.workload == "mixed" and not grouped:
     # the same suite stepped by ONE heterogeneous launch per step (sgw_group_step_n), on fresh engines, after the headline
     engs3 = build_engines(parts, device, streams=False)
-    g3 = EngineGroup([e["eng"] for e in engs3])
     for e3, e in zip(engs3, engines):
       e3["acts"] = e["acts"]
+    g3 = EngineGroup([e["eng"] for e in engs3])
     nb3 = int(max(3, min(R, -(-0.4 * max(a.min_seconds, 0.05) // max(t_batch, 1e-6)))))
     run_batches(engs3, K, 0, 2 * n_distinct, True, g3)         # first sighting + capture of every resident batch
     torch.cuda.synchronize(device)
