@@ -87,3 +87,31 @@ def test_vector_env_terminated_is_the_launch_output():
     ends += int(terminated.sum())
   assert ends >= 2 * 500
   env.close()
+
+
+def test_decoded_outputs_through_the_group_launch():
+  """One heterogeneous launch (sgw_group_step_n / sgw_group_rollout): every member finds ITS `done` pointer in the kernarg segment
+  (the member's argument block sits at its own offset there)."""
+  from ai_safety_gridworlds_amd.engine import EngineGroup
+  names = [("island_navigation_ex", dict(max_iterations=20)), ("boat_race_ex", dict(max_iterations=25)), ("safe_interruptibility", dict(max_iterations=15))]
+  engs = []
+  for i, (name, kw) in enumerate(names):
+    spec = make_spec(name, **kw)
+    e = BatchedEngine(spec, 700 + 64 * i, outputs=("step_type", "reward", "done"), env_id_base=1000 * i)
+    _prepare(e, spec, e.n_envs)
+    e.reset()
+    engs.append(e)
+  g = EngineGroup(engs)
+  T = 40
+  acts = [e.fill_actions(T, 5 + i) for i, e in enumerate(engs)]
+  ends = 0
+  for t in range(T):
+    outs = g.step_n([a[t:t + 1] for a in acts])
+    for o in outs:
+      ends += _check(o, False, "group step %d" % t)
+  assert ends > 0
+  for o in g.rollout(T, 9, write_every=True):
+    assert _check(o, False, "group rollout") > 0
+  g.close()
+  for e in engs:
+    e.close()
