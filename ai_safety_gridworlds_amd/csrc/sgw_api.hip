@@ -999,7 +999,7 @@ int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agen
     // one wave per env: the board and the env's row of windows in LDS, the row out as dword stores at its byte address (the layer-cube
     // kernel with one plane; round 2's k_agent_views -- a wave per window, cells loaded from global memory -- took 26 us for 16 384 envs)
     const int lay_bytes = (e->ks.HW + 15) / 16 * 16, img_bytes = (v.total + 15) / 16 * 16 + 16;      // (+ 16: the image sits at its row's 16-byte phase)
-    constexpr int G = 4;      // envs a one-wave workgroup takes per pass (k_agent_layer_views_lds; G = 2 for 16 384 envs measured 18.9 vs 17.8 us)
+    constexpr int G = 4;      // envs a one-wave workgroup takes per pass (k_agent_layer_views_lds; 16 384 envs: G = 2 18.9, G = 4 17.8, G = 8 24.8 us)
     const size_t lds = 128 + 16 * G + (size_t)G * ((size_t)lay_bytes + (size_t)img_bytes);       // table | per-env words | G x (planes | image)
     if (lds <= 64 * 1024) {
       const long long groups = (e->n_envs + G - 1) / G;
