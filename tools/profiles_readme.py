@@ -55,7 +55,7 @@ for r in side["rows"]:
 pm = pmc["pmc_median_per_launch"]
 fo, wv, gl = b["full_observation"], fm["with_agent_views"], mx["group_launch"]
 isl_us, isl_calls = rocprof(T + "kernel_stats.csv", "IslandT<false, true>, 0>")
-fm_us, fm_calls = rocprof(T + "kernel_stats_firemaker.csv", "Firemaker, 0>")
+fm_us, fm_calls = rocprof(T + "kernel_stats_firemaker.csv", "FiremakerT<false>, 0>")
 g0_us, g0_calls = rocprof(T + "kernel_stats_mixed.csv", "k_engine_group<0>")
 boat_us, _ = rocprof(T + "kernel_stats_mixed.csv", "sgw::Boat, 0>")
 mi_us, _ = rocprof(T + "kernel_stats_mixed.csv", "IslandT<false, true>, 0>")
@@ -115,7 +115,7 @@ wave life; all waves end 4.4-5.2 Âµs after the first starts; the other â‰ˆ 1.5 Â
 | firemaker_ex_ma, 16 384 envs x 3 agents: Âµs per round | **{fm["ms_per_step"]*1e3:.1f}** ({fm["roofline"]["frac"]:.3f} of VALU issue) | 80.4-80.7 | r03_{tag}_bench_firemaker_ex_ma.json |
 | ... with the three agents' windows (the Zoo API's observation) | **{wv["us_per_round"]:.1f} Âµs from ONE launch** (`sgw_out.views`) | 101.9 Âµs in two launches | `with_agent_views` |
 | `GridworldZooVectorEnv.step` (dict in, dicts of device tensors out) | 84-93 Âµs per round = the round kernel with the Zoo outputs (87-89 Âµs alone) | 125 Âµs | r03_{tag}_zoo_vector_probe.txt |
-| rocprofv3 avg of `k_engine<Firemaker, 0>` over the run (both variants, {fm_calls} calls) | {fm_us:.1f} Âµs | 80.7 Âµs | r03_{tag}_kernel_stats_firemaker.csv |
+| rocprofv3 avg of `k_engine<FiremakerT<false>, 0>` over the run (both variants, {fm_calls} calls) | {fm_us:.1f} Âµs | 80.7 Âµs | r03_{tag}_kernel_stats_firemaker.csv |
 | mixed suite (island_navigation_ex + boat_race_ex + safe_interruptibility, 3 x 10 923 envs): three concurrent per-family launches per step | {sci(mx["value"])} env-steps/s, {mx["ms_per_step"]*1e3:.2f} Âµs per step, {mx["roofline"]["frac"]:.3f} of HBM over the whole step (rocprofv3: Boat {boat_us:.2f}, Island {mi_us:.2f}, SafeInt {si_us:.2f} Âµs) | 4.38 Ã— 10^9, 7.5 Âµs | r03_{tag}_bench_mixed.json, r03_{tag}_kernel_stats_mixed.csv |
 | ... as ONE heterogeneous launch per step (`k_engine_group<0>`) | {sci(gl["value"])}, {gl["us_per_step"]:.2f} Âµs (rocprofv3 avg {g0_us:.2f} Âµs over {g0_calls} calls) | - | `group_launch` |
 | ... fused: one group launch advances every member 512 steps (`k_engine_group<1>`) | **{sci(mx["fused_rollout"]["value"])} env-steps/s** ({mx["fused_rollout"]["ms_per_step"]*1e3:.2f} Âµs per step) | no fused leg | `fused_rollout` |
