@@ -100,7 +100,7 @@ static int family_words(const sgw_spec& sp) {
     case SGW_BOAT_RACE: return Boat::words(sp.K, sp.H * sp.W);
     case SGW_SAFE_INTERRUPTIBILITY: return SafeInt::words();
     case SGW_FIREMAKER_EX_MA: return Firemaker::words();
-    case SGW_ISLAND_NAVIGATION_EX_MA: return IslandMa::words(sp.K);
+    case SGW_ISLAND_NAVIGATION_EX_MA: return sp.H * sp.W > 64 ? IslandMaWide::words(sp.K) : IslandMa::words(sp.K);
     case SGW_TILE_EVENTS: return Tile::words();
     case SGW_SIDE_EFFECTS_SOKOBAN: return Sokoban::words();
     case SGW_CONVEYOR_BELT: return Conveyor::words();
@@ -174,8 +174,8 @@ int sgw_create(const sgw_spec* spec, int64_t n_envs, int64_t env_id_base, int de
       return fail(SGW_ERR_ARG, "sgw_create: metric_slot >= M");
   if (spec->family == SGW_AINTELOPE_SAVANNA && (HW > 192 || spec->A != 2))
     return fail(SGW_ERR_ARG, "sgw_create: aintelope_savanna holds a layer in 3 x 64 bits (H*W <= 192) and lays out two agents (A = 2)");
-  if (spec->family == SGW_ISLAND_NAVIGATION_EX_MA && (HW > 64 || spec->A != 2))
-    return fail(SGW_ERR_ARG, "sgw_create: island_navigation_ex_ma keeps its map in 4 x 16 nibbles (H*W <= 64) and has two agents");
+  if (spec->family == SGW_ISLAND_NAVIGATION_EX_MA && (HW > 128 || spec->A != 2))
+    return fail(SGW_ERR_ARG, "sgw_create: island_navigation_ex_ma keeps its map in 4 or 8 x 16 nibbles (H*W <= 128) and has two agents");
   const int words = family_words(*spec);
   if (words < 0) return fail(SGW_ERR_UNSUPPORTED, "sgw_create: unknown game family");
   if ((spec->family == SGW_ISLAND_NAVIGATION_EX || spec->family == SGW_ISLAND_NAVIGATION_EX_MA ||
@@ -373,7 +373,9 @@ template <class Fn> static int with_family(const sgw_engine* e, Fn&& fn) {
     case SGW_FIREMAKER_EX_MA:
       if (e->spec.flags & Firemaker::F_WIDE) return fn(FamilyType<FiremakerWide>{}, (int)TAG_FIREMAKER);     // spread distance > 3
       return fn(FamilyType<Firemaker>{}, (int)TAG_FIREMAKER);
-    case SGW_ISLAND_NAVIGATION_EX_MA: return fn(FamilyType<IslandMa>{}, (int)TAG_ISLAND_MA);
+    case SGW_ISLAND_NAVIGATION_EX_MA:
+      if (e->spec.H * e->spec.W > 64) return fn(FamilyType<IslandMaWide>{}, (int)TAG_ISLAND_MA);      // resized maps of 65..128 cells
+      return fn(FamilyType<IslandMa>{}, (int)TAG_ISLAND_MA);
     case SGW_TILE_EVENTS: return fn(FamilyType<Tile>{}, (int)TAG_TILE);
     case SGW_SIDE_EFFECTS_SOKOBAN: return fn(FamilyType<Sokoban>{}, (int)TAG_SOKOBAN);
     case SGW_CONVEYOR_BELT: return fn(FamilyType<Conveyor>{}, (int)TAG_CONVEYOR);

@@ -30,7 +30,7 @@
 // agent_flags output: bits 1-2 action direction, bits 3-4 observation direction (Directions LEFT=0 RIGHT=1 UP=2 DOWN=3)
 // state words: 0 core (step_type / term / buffered-uint32 flag where every family has them) | 1 positions, episode counters |
 //              2 rng buffer | 3-6 PCG64 | 7-9 visits | 10-13 satiations |
-//              14-17 availabilities | 18-21 map | 22.. cumulative [2][K]
+//              14-17 availabilities | 18.. map (NW words) | then cumulative [2][K]
 #pragma once
 
 #include "sgw_common.hpp"
@@ -38,7 +38,7 @@
 
 namespace sgw {
 
-struct Map4 { uint64_t a, b, c, d; };      // 64 cells x 4 bits
+struct Map8 { uint64_t a, b, c, d, e, f, g, h; };      // 4 bits per cell: 64 cells in a..d (NW = 4), 128 in a..h (NW = 8: the wide instantiation)
 
 // out byte k = table byte sel.byte[k], table = {hi, lo} (bytes 0-3 of lo, then bytes 0-3 of hi); every selector byte is 0..7
 __device__ inline uint32_t byte_lut8(uint32_t hi, uint32_t lo, uint32_t sel) {
@@ -52,7 +52,11 @@ __device__ inline uint32_t byte_lut8(uint32_t hi, uint32_t lo, uint32_t sel) {
 #endif
 }
 
-struct IslandMa {
+// NW: state words of the per-env map (16 cells each).  4 = every level of the reference (<= 64 cells); 8 = resized maps of up to 128
+// cells (map_width x map_height, safety_game_ma.py:1113-1170) -- its own kernel instantiations, the default ones are unchanged
+template <int NW>
+struct IslandMaT {
+  static_assert(NW == 4 || NW == 8, "");
   static constexpr int NA = 2;
   static constexpr int NUA = 12;            // reward units per agent
   static constexpr int NU = NA * NUA;
@@ -87,7 +91,7 @@ struct IslandMa {
     P_D_EXPONENT, P_D_GROWTH_LIMIT, P_D_AVAIL_INITIAL,
     P_F_EXPONENT, P_F_GROWTH_LIMIT, P_F_AVAIL_INITIAL,
     P_D_OVERTHRESH, P_D_DEFTHRESH, P_F_OVERTHRESH, P_F_DEFTHRESH,
-    P_ART0, P_ART1, P_ART2, P_ART3,
+    P_ART0, P_ART1, P_ART2, P_ART3, P_ART4, P_ART5, P_ART6, P_ART7,
     P_COUNT
   };
   // map codes
@@ -104,11 +108,11 @@ struct IslandMa {
     uint64_t rs_hi, rs_lo, ri_hi, ri_lo;
     uint32_t gap_v[2], drink_v[2], food_v[2], gold_v[2], silver_v[2];
     double drink_sat[2], food_sat[2], d_avail, d_frac, f_avail, f_frac;
-    Map4 map;
+    Map8 map;
     double cum[NU];
   };
 
-  static __host__ __device__ int words(int K) { return 22 + 2 * K; }
+  static __host__ __device__ int words(int K) { return 18 + NW + 2 * K; }
   static __device__ int slot(const KSpec& sp, int u) { return sp.dim_slot[u / NUA][u % NUA]; }
 
   static __device__ void load(State& s, const KArgs& a, long long env) {
@@ -135,6 +139,7 @@ struct IslandMa {
     s.drink_sat[0] = c.getf(); s.drink_sat[1] = c.getf(); s.food_sat[0] = c.getf(); s.food_sat[1] = c.getf();
     s.d_avail = c.getf(); s.d_frac = c.getf(); s.f_avail = c.getf(); s.f_frac = c.getf();
     s.map.a = c.get(); s.map.b = c.get(); s.map.c = c.get(); s.map.d = c.get();
+    if constexpr (NW == 8) { s.map.e = c.get(); s.map.f = c.get(); s.map.g = c.get(); s.map.h = c.get(); }
 #pragma unroll
     for (int u = 0; u < NU; ++u) s.cum[u] = c.getf_if(slot(a.sp, u) >= 0, 0.0);   // slots ascend with u
   }
@@ -156,6 +161,7 @@ struct IslandMa {
     c.putf(s.drink_sat[0]); c.putf(s.drink_sat[1]); c.putf(s.food_sat[0]); c.putf(s.food_sat[1]);
     c.putf(s.d_avail); c.putf(s.d_frac); c.putf(s.f_avail); c.putf(s.f_frac);
     c.put(s.map.a); c.put(s.map.b); c.put(s.map.c); c.put(s.map.d);
+    if constexpr (NW == 8) { c.put(s.map.e); c.put(s.map.f); c.put(s.map.g); c.put(s.map.h); }
 #pragma unroll
     for (int u = 0; u < NU; ++u) if (slot(a.sp, u) >= 0) c.putf(s.cum[u]);
   }
@@ -187,16 +193,23 @@ struct IslandMa {
   }
 
   // ---- 4-bit map ----------------------------------------------------------------------------------------------
-  static __device__ uint64_t mword(const Map4& m, int wi) {        // mask-select (see Firemaker::word_of)
+  static __device__ uint64_t mword(const Map8& m, int wi) {        // mask-select (see Firemaker::word_of)
     const uint64_t lo = wi == 0 ? m.a : m.b, hi = wi == 2 ? m.c : m.d;      // the words are register values here, not loads
-    return wi < 2 ? lo : hi;
+    const uint64_t q0 = wi < 2 ? lo : hi;
+    if constexpr (NW == 4) return q0;
+    const uint64_t lo2 = wi == 4 ? m.e : m.f, hi2 = wi == 6 ? m.g : m.h;
+    return wi < 4 ? q0 : (wi < 6 ? lo2 : hi2);
   }
-  static __device__ int mget(const Map4& m, int cell) { return (int)((mword(m, cell >> 4) >> ((cell & 15) * 4)) & 15ull); }
-  static __device__ void mset(Map4& m, int cell, int v) {
+  static __device__ int mget(const Map8& m, int cell) { return (int)((mword(m, cell >> 4) >> ((cell & 15) * 4)) & 15ull); }
+  static __device__ void mset(Map8& m, int cell, int v) {
     const int wi = cell >> 4, sh = (cell & 15) * 4;
     const uint64_t clr = ~(15ull << sh), bits = (uint64_t)v << sh;
     m.a = wi == 0 ? ((m.a & clr) | bits) : m.a; m.b = wi == 1 ? ((m.b & clr) | bits) : m.b;
     m.c = wi == 2 ? ((m.c & clr) | bits) : m.c; m.d = wi == 3 ? ((m.d & clr) | bits) : m.d;
+    if constexpr (NW == 8) {
+      m.e = wi == 4 ? ((m.e & clr) | bits) : m.e; m.f = wi == 5 ? ((m.f & clr) | bits) : m.f;
+      m.g = wi == 6 ? ((m.g & clr) | bits) : m.g; m.h = wi == 7 ? ((m.h & clr) | bits) : m.h;
+    }
   }
   static __device__ bool is_drape(int code) { return code >= C_WATER && code <= C_SILVER; }
   static __device__ uint64_t pword(const Lds& l, int i) { return (uint64_t)__double_as_longlong(l.params[i]); }
@@ -232,15 +245,17 @@ struct IslandMa {
     const bool played = have_state && (s.ast[0] != AST_FIRST || s.ast[1] != AST_FIRST);
     if (a.mode == MODE_RESET && played) s.episode_no += 1;
     if (!have_state) { s.episode_no = 1; s.map_cached = 0; s.map_episode = 0; }
-    Map4 level;
+    Map8 level;
     level.a = pword(l, P_ART0); level.b = pword(l, P_ART1); level.c = pword(l, P_ART2); level.d = pword(l, P_ART3);
+    level.e = level.f = level.g = level.h = 0ull;
+    if constexpr (NW == 8) { level.e = pword(l, P_ART4); level.f = pword(l, P_ART5); level.g = pword(l, P_ART6); level.h = pword(l, P_ART7); }
     if (mrf == 0) {
       s.map = level;
     } else {
       const bool hit = s.map_cached && (mrf != 3 || s.map_episode == s.episode_no);
       if (!hit) {
         // np_random.shuffle of the flattened interior (preserve_map_edges_when_randomizing=True), MB:1086-1100
-        Map4 m = level;
+        Map8 m = level;
         const int w = sp.W - 2, n = (sp.H - 2) * w;
         for (int i = n - 1; i >= 1; --i) {
           const int j = interval(s, (uint32_t)i);
@@ -492,8 +507,8 @@ struct IslandMa {
     const uint32_t inv = (65536u + (uint32_t)sp.W - 1u) / (uint32_t)sp.W;
     int best0 = 99, best1 = 99;
 #pragma unroll
-    for (int wi = 0; wi < 4; ++wi) {
-      const uint64_t w = wi == 0 ? s.map.a : (wi == 1 ? s.map.b : (wi == 2 ? s.map.c : s.map.d));
+    for (int wi = 0; wi < NW; ++wi) {
+      const uint64_t w = mword(s.map, wi);                          // (wi is a compile-time constant here: no selects)
       const uint64_t t = w ^ 0x2222222222222222ull;
       uint64_t z = ~(t | (t >> 1) | (t >> 2) | (t >> 3)) & 0x1111111111111111ull;
       while (z) {
@@ -510,5 +525,7 @@ struct IslandMa {
     out[1] = (!s.acted[1] || none) ? 3 : best1;
   }
 };
+using IslandMa = IslandMaT<4>;
+using IslandMaWide = IslandMaT<8>;      // maps of 65..128 cells
 
 }  // namespace sgw

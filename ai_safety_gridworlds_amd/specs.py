@@ -731,8 +731,8 @@ def _island_ma_spec(kwargs):
     mh, mw = int(mh if mh is not None else len(art)), int(mw if mw is not None else len(art[0]))
     if mh < 3 or mw < 3:
       raise AssertionError("map_height > 2 and map_width > 2")                                # safety_game_ma.py:1132
-    if mh * mw > 64:
-      raise NotImplementedError("island_navigation_ex_ma: maps of more than 64 cells are not implemented (4 bits per cell in 4 state words)")
+    if mh * mw > 128:
+      raise NotImplementedError("island_navigation_ex_ma: maps of more than 128 cells are not implemented (4 bits per cell in 8 state words)")
     if (mh - 2) * (mw - 2) < 2:
       raise AssertionError("tile counts exceed the map interior")                             # safety_game_ma.py:1144
     interior = "12" + ' ' * ((mh - 2) * (mw - 2) - 2)
@@ -753,7 +753,7 @@ def _island_ma_spec(kwargs):
     params.append(cfg[item[0]][item[1]] if isinstance(item, tuple) else cfg[item])
   params += [cfg["DRINK_OVERSATIATION_THRESHOLD"], cfg["DRINK_DEFICIENCY_THRESHOLD"], cfg["FOOD_OVERSATIATION_THRESHOLD"],
              cfg["FOOD_DEFICIENCY_THRESHOLD"]]
-  words = [0, 0, 0, 0]                                 # the level map, 4 bits per cell
+  words = [0] * 8                                      # the level map, 4 bits per cell (> 64 cells: the 8-word kernel instantiation)
   for i, c in enumerate(flat):
     words[i >> 4] |= _ISLAND_MA_CODES[c] << ((i & 15) * 4)
   params += [struct.unpack("<d", struct.pack("<Q", w))[0] for w in words]

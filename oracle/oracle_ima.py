@@ -5,7 +5,7 @@ import numpy as np
 
 from . import oracle as _o
 
-A, NU, MAXCELLS, MAXM, VIEW = 2, 12, 64, 16, 25
+A, NU, MAXCELLS, MAXM, VIEW = 2, 12, 128, 16, 25
 
 _INT_FIELDS = ("level", "max_iterations", "randomize_agent_actions_order", "sustainability_challenge",
                "thirst_hunger_death", "penalise_oversatiation", "use_satiation_proportional_reward",

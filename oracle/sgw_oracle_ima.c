@@ -32,7 +32,7 @@
 
 #include "sgw_pcg.h"
 
-#define IM_MAXCELLS 64
+#define IM_MAXCELLS 128
 #define IM_A 2
 #define IM_NU 12
 #define IM_MAXM 16

@@ -54,8 +54,8 @@ def ma_case(rnd, which, E=800, T=150, nthreads=16, strict=False):
               penalise_oversatiation=bool(rnd.integers(2)), use_satiation_proportional_reward=bool(rnd.integers(2)),
               map_randomization_frequency=int(rnd.integers(4)), action_direction_mode=modes[0],
               observation_direction_mode=modes[1], max_iterations=int(rnd.integers(12, 80)))
-    if kw["map_randomization_frequency"] >= 1 and rnd.integers(3) == 0:      # resized island: up to 64 cells
-      w = int(rnd.integers(4, 10)); kw.update(map_width=w, map_height=int(rnd.integers(4, min(9, 64 // w + 1))))
+    if kw["map_randomization_frequency"] >= 1 and rnd.integers(3) == 0:      # resized island: up to 128 cells (> 64: the 8-word map kernels)
+      w = int(rnd.integers(4, 17)); kw.update(map_width=w, map_height=int(rnd.integers(4, min(13, 128 // w + 1))))
     name, Or = "island_navigation_ex_ma", OI
   else:
     two = bool(rnd.integers(2))

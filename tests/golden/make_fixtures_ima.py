@@ -51,6 +51,9 @@ CONFIGS = {
     # map_width / map_height: make_game's tile_type_counts only lists the agent characters (IM:484-492), so a resized island is a
     # water frame around two agents and gaps
     "ima_resize_7x9": (dict(level=9, map_width=9, map_height=7, map_randomization_frequency=3, max_iterations=30), 10, 90, (20, 21, 60)),
+    # more than 64 cells (the 8-word map of the wide kernel instantiation): 120 cells, and the 128-cell ceiling
+    "ima_resize_10x12": (dict(level=9, map_width=12, map_height=10, map_randomization_frequency=3, max_iterations=40), 10, 100, (25, 26, 70)),
+    "ima_resize_8x16": (dict(level=9, map_width=16, map_height=8, map_randomization_frequency=2, max_iterations=36), 8, 90, (30,)),
     # remove_unused_tile_types_from_layers (safety_game_mo_base.py:1113-1120): the game is built without the drapes of tile types that
     # are not on its map: no such layer, things.get() finds nothing (safety_ stays 3), the drape's update() never runs (metrics None)
     "ima_L10_unused_removed": (dict(level=10, remove_unused_tile_types_from_layers=True, max_iterations=40), 10, 80, (30,)),

@@ -56,6 +56,7 @@ template <> int words_of<Island>(const sgw_spec& sp) { return Island::words(sp.K
 template <> int words_of<IslandGeneral>(const sgw_spec& sp) { return IslandGeneral::words(sp.K); }
 template <> int words_of<IslandPacked>(const sgw_spec& sp) { return IslandPacked::words(sp.K); }
 template <> int words_of<IslandMa>(const sgw_spec& sp) { return IslandMa::words(sp.K); }
+template <> int words_of<IslandMaWide>(const sgw_spec& sp) { return IslandMaWide::words(sp.K); }
 template <> int words_of<Savanna>(const sgw_spec& sp) { return Savanna::words(sp.K); }
 template <> int words_of<Boat>(const sgw_spec& sp) { return Boat::words(sp.K, sp.H * sp.W); }
 template <> int words_of<Sokoban>(const sgw_spec&) { return Sokoban::words(); }
@@ -228,7 +229,8 @@ int main(int argc, char** argv) {
   if (hd[0] == SGW_ISLAND_NAVIGATION_EX) rc = (h.spec.flags & Island::F_GENERAL) ? run<IslandGeneral>(h, hd[2], hd[3], nullptr, actions.data(), out)
                                                                                    : (Island::packable(h.spec) ? run<IslandPacked>(h, hd[2], hd[3], nullptr, actions.data(), out)
                                                                                                                 : run<Island>(h, hd[2], hd[3], nullptr, actions.data(), out));
-  else if (hd[0] == SGW_ISLAND_NAVIGATION_EX_MA) rc = run<IslandMa>(h, hd[2], hd[3], rng.data(), actions.data(), out);
+  else if (hd[0] == SGW_ISLAND_NAVIGATION_EX_MA) rc = h.spec.H * h.spec.W > 64 ? run<IslandMaWide>(h, hd[2], hd[3], rng.data(), actions.data(), out)      // 8-word maps
+                                                                               : run<IslandMa>(h, hd[2], hd[3], rng.data(), actions.data(), out);
   else if (hd[0] == SGW_AINTELOPE_SAVANNA) rc = run<Savanna>(h, hd[2], hd[3], rng.data(), actions.data(), out);
   else if (hd[0] == SGW_BOAT_RACE_EX || hd[0] == SGW_BOAT_RACE) rc = run<Boat>(h, hd[2], hd[3], nullptr, actions.data(), out);
   else if (hd[0] == SGW_SIDE_EFFECTS_SOKOBAN) rc = run<Sokoban>(h, hd[2], hd[3], nullptr, actions.data(), out);

@@ -93,6 +93,10 @@ def test_island_ma_hip_matches_reference_fixture(name):
     (dict(level=10, map_randomization_frequency=3, penalise_oversatiation=True, sustainability_challenge=True,
           max_iterations=24), 600, 120, (10, 30, 31, 77)),
     (dict(level=4, map_randomization_frequency=2, randomize_agent_actions_order=False, max_iterations=30), 300, 80, (33,)),
+    # resized maps of more than 64 cells: the 8-word map instantiation (IslandMaT<8>), 126 cells and the 128-cell ceiling
+    (dict(level=9, map_width=14, map_height=9, map_randomization_frequency=3, action_direction_mode=2, observation_direction_mode=2,
+          max_iterations=40), 500, 110, (20, 21, 80)),
+    (dict(level=9, map_width=8, map_height=16, map_randomization_frequency=1, sustainability_challenge=True, max_iterations=36), 400, 90, (45,)),
 ])
 def test_island_ma_hip_matches_oracle_fresh_seed(kw, E, T, resets):
   from oracle import oracle_ima as OI
