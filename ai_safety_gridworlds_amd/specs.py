@@ -518,7 +518,10 @@ def _firemaker_spec(kwargs):
     raise AssertionError("firemaker_ex_ma: map resizing needs map randomisation, which this env never enables "
                          "(safety_game_mo_base.py:991)")
   if cfg["remove_unused_tile_types_from_layers"]:
-    raise NotImplementedError("firemaker_ex_ma: remove_unused_tile_types_from_layers")
+    # the level has no 'F' tile, so the reference builds the game without its FireDrape and the first play raises KeyError('F')
+    # (run here against the reference with amount_agents 1, 2 and 3): there is no behaviour to restate
+    raise NotImplementedError("firemaker_ex_ma: remove_unused_tile_types_from_layers=True removes the fire drape in the reference "
+                              "(the level starts without fire) and its first step raises KeyError('F')")
   flat = "".join(art)
   if any(c != '#' for c in art[0] + art[-1]) or any(r[0] != '#' or r[-1] != '#' for r in art):
     raise NotImplementedError("firemaker_ex_ma: the fire kernel assumes a walled border")
