@@ -1005,7 +1005,7 @@ int sgw_agent_views(sgw_engine* e, const uint8_t* board_dev, const uint8_t* agen
     const size_t lds = 128 + 16 * G + (size_t)G * ((size_t)lay_bytes + (size_t)img_bytes);       // table | per-env words | G x (planes | image)
     if (lds <= 64 * 1024) {
       const long long groups = (e->n_envs + G - 1) / G;
-      const int blocks = (int)(groups < 8192 ? groups : 8192);           // (256 CUs x 32 one-wave workgroups: each walks its groups)
+      const int blocks = (int)(groups < 8192 ? groups : 8192);           // (each walks its groups; 4 096..16 384 workgroups measured the same, fewer are slower)
       hipLaunchKernelGGL(k_agent_layer_views_lds<G>, dim3(blocks), dim3(WAVE), lds, (hipStream_t)stream, board_dev, agent_pos_dev, agent_flags_dev,
                          (long long)e->n_envs, v, (const uint8_t*)nullptr, 1, outside_chr, views_dev, lay_bytes, img_bytes, 1);
       HIP_TRY(hipGetLastError());

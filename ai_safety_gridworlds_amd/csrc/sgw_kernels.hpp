@@ -1600,7 +1600,10 @@ __global__ __launch_bounds__(256) void k_agent_layer_views_lds(const uint8_t* la
   int prr[NP], pcc[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) { const int k = lane + WAVE * j; prr[j] = k / W; pcc[j] = k - prr[j] * W; }
-  const int npass = (HW + WAVE - 1) / WAVE;
+  bool inb[NP];                                             // plane cell lane + 64 j exists
+#pragma unroll
+  for (int j = 0; j < NP; ++j) inb[j] = lane + WAVE * j < HW;
+  uint8_t* const trash = view_lds + 124;                    // where the scatter's out-of-window cells land (no exec juggling per store)
   constexpr int PF = G > 1 ? 5 : 12;                        // plane bytes per thread held in registers between the load and the LDS write
   const int nbytes = L * HW;
   const bool in_regs = nbytes <= PF * (int)blockDim.x;
@@ -1632,6 +1635,10 @@ __global__ __launch_bounds__(256) void k_agent_layer_views_lds(const uint8_t* la
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       uint8_t* lay = envs + g * env_lds;
+      if (pad_is_char) {                                       // ascii planes: one pad character for every window of the row -- the whole
+        uint32_t* im4 = reinterpret_cast<uint32_t*>(lay + lay_bytes);      // image (its phase slack included) is filled here, once
+        for (int k = threadIdx.x; k < (img_bytes >> 2); k += blockDim.x) im4[k] = 0x01010101u * outside;
+      }
       if (in_regs) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
@@ -1675,27 +1682,29 @@ __global__ __launch_bounds__(256) void k_agent_layer_views_lds(const uint8_t* la
           for (int j = 0; j < NP; ++j) {
             const int t = useQ ? Q[j] : P[j];
             at[j] = (neg ? -t : t) + base;
-            ok[j] = j < npass && lane + WAVE * j < HW;
+            ok[j] = inb[j];
             if (!covers) ok[j] = ok[j] && (unsigned)(prr[j] - pr) < (unsigned)vh && (unsigned)(pcc[j] - pc) < (unsigned)vw;
           }
           for (int l = wave; l < L; l += nwave) {
             const uint32_t pad = pad_is_char ? 0x01010101u * outside : (chars[l] == outside ? 0x01010101u : 0u);
             const uint8_t* plane = lay + l * HW;
             uint8_t* dst = img + off + l * cells;
-            // pad fill: bytes up to the first dword boundary, dwords, tail bytes (dst is byte-aligned only)
-            const int head = (int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3), nh = head < cells ? head : cells;
-            if (lane < nh) dst[lane] = (uint8_t)pad;
-            uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + nh);
-            const int nd = (cells - nh) >> 2;
-            for (int k = lane; k < nd; k += WAVE) d4[k] = pad;
-            const int done = nh + 4 * nd;
-            if (lane < cells - done) dst[done + lane] = (uint8_t)pad;
-            lds_wave_sync();
+            if (!pad_is_char) {
+              // pad fill: bytes up to the first dword boundary, dwords, tail bytes (dst is byte-aligned only)
+              const int head = (int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3), nh = head < cells ? head : cells;
+              if (lane < nh) dst[lane] = (uint8_t)pad;
+              uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + nh);
+              const int nd = (cells - nh) >> 2;
+              for (int k = lane; k < nd; k += WAVE) d4[k] = pad;
+              const int done = nh + 4 * nd;
+              if (lane < cells - done) dst[done + lane] = (uint8_t)pad;
+              lds_wave_sync();
+            }
             uint8_t val[NP];
 #pragma unroll
             for (int j = 0; j < NP; ++j) val[j] = plane[ok[j] ? lane + WAVE * j : 0];
 #pragma unroll
-            for (int j = 0; j < NP; ++j) if (ok[j]) dst[at[j]] = val[j];
+            for (int j = 0; j < NP; ++j) *(ok[j] ? dst + at[j] : trash) = val[j];
           }
         } else {
           for (int l = wave; l < L; l += nwave) {
