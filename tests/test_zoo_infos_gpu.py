@@ -224,3 +224,35 @@ def test_step_full_of_the_multi_agent_families_equals_the_separate_kernels(name,
     for k in ("gini_index", "cumulative_gini_index", "mo_variance", "cumulative_mo_variance", "average_mo_variance", "average_reward"):
       assert torch.equal(torch.nan_to_num(o[k], nan=-7.0), torch.nan_to_num(ds[k], nan=-7.0)), (t, k)
   a.close(); b.close()
+
+
+def test_zoo_parallel_firemaker_direction_modes_against_the_oracle():
+  """The single-env PettingZoo-parallel facade over firemaker_ex_ma with relative moves / turning actions: observations (the
+  windows rot90-ed by the observation direction), INFO_OBSERVATION_DIRECTION / INFO_ACTION_DIRECTION, rewards and positions of
+  every round == the multi-agent oracle on the same generator (firemaker_ex_ma.py:224-226, 472; gridworld_zoo_parallel_env.py:325-335)."""
+  from oracle import oracle_ma as OM
+  for adm, odm, n_act in ((1, 1, 5), (2, 2, 9)):
+    T, seed = 40, 123 + adm
+    rs = np.random.RandomState(seed)
+    actions = rs.randint(0, n_act, size=(1, T, 3)).astype(np.int8)
+    kw = dict(amount_agents=3, max_iterations=60, action_direction_mode=adm, observation_direction_mode=odm,
+              FIRE_SPREAD_PROBABILITY_AT_DISTANCE_ONE=0.05)
+    want = OM.run_streams(OM.make_config(**kw), actions, np.stack([OM.rng_state_words(seed)]))
+    env = Z.GridworldZooParallelEnv("firemaker_ex_ma", seed=seed, **kw)
+    names = ["agent_1", "agent_2", "agent_S"]
+    assert env.possible_agents == names and env.action_space("agent_1").n == n_act
+
+    def check(t, obs, infos):
+      for q, a in enumerate(names):
+        view = want["view_worker"][0, t, q] if q < 2 else want["view_supervisor"][0, t]
+        assert np.array_equal(np.asarray(obs[a])[-1] if np.asarray(obs[a]).ndim == 3 else np.asarray(obs[a]), np.vectorize(chr)(view)), (adm, t, a)
+        assert infos[a][Z.INFO_OBSERVATION_DIRECTION] == want["observation_direction"][0, t, q], (adm, t, a)
+        assert infos[a][Z.INFO_ACTION_DIRECTION] == want["action_direction"][0, t, q], (adm, t, a)
+        assert infos[a]["info_agent_position"] == tuple(want["pos"][0, t, q]), (adm, t, a)
+
+    obs, infos = env.reset()
+    check(0, obs, infos)
+    for t in range(T):
+      obs, rewards, terms, truncs, infos = env.step({a: int(actions[0, t, q]) for q, a in enumerate(names)})
+      check(t + 1, obs, infos)
+    env.close()
