@@ -81,6 +81,7 @@ One collection per round is kept: **`r03_{tag}_*` (round 3, final)**, `r02_v7_*`
 | `r03_{tag}_host_probe.txt`, `r03_{tag}_zoo_vector_probe.txt`, `r03_{tag}_agent_views_probe.txt` | host vs end-to-end time of every way to issue one step (bare C call, engine, graph replay, `GridworldVectorEnv.step` default and `full_info=True`); `GridworldZooVectorEnv.step` next to the round kernel alone; `sgw_agent_views` alone |
 | `r03_{tag}_phase_stamps.txt` | in-kernel phase stamps of the headline kernel (diagnostic build `tools/diag/stamp_probe.hip`) |
 | `r03_pmc_firemaker_ex_ma.json`, `r03_pmc_aintelope_savanna.json` | SQ counters of the two instruction-bound round kernels (`bench.py` reads SQ_INSTS_VALU from them) |
+| `r03_pmc_agent_views.json` | SQ counters of the window kernel (`sgw_agent_views`) at the two BASELINE sizes: 314 VALU + 287 SALU + 34 LDS wave-instructions per savanna env, 0.04 bank conflicts per LDS instruction (DESIGN.md §4.8) |
 | `r03_kernel_registers.md` | VGPR / AGPR / SGPR / spills / scratch of every kernel in `libsgw.so` + the exec-restore lint verdict |
 | `r02_ima_miscompile.txt` | the evidence for DESIGN.md §8 "the fused-kernel fault of round 1" |
 | `reference_cpython.json` | the reference itself timed under CPython in the build container (`tools/time_reference.py`) |
